@@ -1,0 +1,199 @@
+"""ctypes / numpy mirror of ``include/gpuspectral_pt.h`` (the C-ABI boundary).
+
+Nothing here computes anything: it only describes the POD layouts so that
+Python callers (tests, bench.py) can hand arrays to the C ABI.  Layouts follow
+the reference's scalar structs (S/renderer/Scene.h:29-109).
+"""
+import ctypes as C
+
+import numpy as np
+
+GSP_ABI_VERSION = 1
+
+BSDF_DIFFUSE = 0
+BSDF_SMOOTH_DIELECTRIC = 1
+BSDF_SMOOTH_CONDUCTOR = 2
+BSDF_SMOOTH_PLASTIC = 3
+BSDF_ROUGH_CONDUCTOR = 4
+BSDF_SMOOTH_FLOOR = 5
+BSDF_ROUGH_FLOOR = 6
+BSDF_ROUGH_PLASTIC = 7
+BSDF_TYPE_COUNT = 8
+
+BSDF_NAMES = (
+    "diffuse",
+    "smooth_dielectric",
+    "smooth_conductor",
+    "smooth_plastic",
+    "rough_conductor",
+    "smooth_floor",
+    "rough_floor",
+    "rough_plastic",
+)
+
+
+def bsdf_handle(btype, index):
+    """(type << 16) | index -- S/renderer/Scene.h:83-97."""
+    return ((int(btype) & 0xFFFF) << 16) | (int(index) & 0xFFFF)
+
+
+# numpy record layouts (all tightly packed, 4-byte scalars)
+DIFFUSE_DT = np.dtype([("reflectance", "<f4", 3), ("has_texture", "<i4")])
+SMOOTH_DIELECTRIC_DT = np.dtype([("ior_in", "<f4"), ("ior_out", "<f4")])
+SMOOTH_CONDUCTOR_DT = np.dtype([("ior_in", "<f4"), ("ior_out", "<f4")])
+SMOOTH_PLASTIC_DT = np.dtype([("diffuse", "<f4", 3), ("ior_in", "<f4"), ("ior_out", "<f4"), ("r0", "<f4")])
+ROUGH_CONDUCTOR_DT = np.dtype(
+    [("eta", "<f4", 3), ("k", "<f4", 3), ("reflectance", "<f4", 3), ("alpha", "<f4"), ("has_texture", "<i4")]
+)
+SMOOTH_FLOOR_DT = np.dtype([("diffuse", "<f4", 3), ("r0", "<f4")])
+ROUGH_FLOOR_DT = np.dtype([("diffuse", "<f4", 3), ("r0", "<f4"), ("alpha", "<f4")])
+ROUGH_PLASTIC_DT = np.dtype(
+    [
+        ("diffuse", "<f4", 3),
+        ("ior_in", "<f4"),
+        ("ior_out", "<f4"),
+        ("r0", "<f4"),
+        ("alpha", "<f4"),
+        ("has_texture", "<i4"),
+    ]
+)
+BSDF_DTYPES = (
+    DIFFUSE_DT,
+    SMOOTH_DIELECTRIC_DT,
+    SMOOTH_CONDUCTOR_DT,
+    SMOOTH_PLASTIC_DT,
+    ROUGH_CONDUCTOR_DT,
+    SMOOTH_FLOOR_DT,
+    ROUGH_FLOOR_DT,
+    ROUGH_PLASTIC_DT,
+)
+BSDF_SIZES = (16, 8, 8, 24, 44, 16, 20, 32)
+assert tuple(d.itemsize for d in BSDF_DTYPES) == BSDF_SIZES
+
+LIGHT_DT = np.dtype([("positions", "<f4", (3, 4)), ("radiance", "<f4", 4)])
+assert LIGHT_DT.itemsize == 64
+
+INSTANCE_DT = np.dtype(
+    [
+        ("transform", "<f4", 16),
+        ("emission", "<f4", 3),
+        ("bsdf", "<u4"),
+        ("twofaced", "<u4"),
+        ("first_vertex", "<u4"),
+        ("vertex_count", "<u4"),
+    ]
+)
+assert INSTANCE_DT.itemsize == 92
+
+
+class Camera(C.Structure):
+    _fields_ = [("to_world", C.c_float * 16), ("fov", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("instances", C.c_void_p),
+        ("num_instances", C.c_uint32),
+        ("positions", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("num_vertices", C.c_uint64),
+        ("diffuse_bsdfs", C.c_void_p),
+        ("smooth_dielectric_bsdfs", C.c_void_p),
+        ("smooth_conductor_bsdfs", C.c_void_p),
+        ("smooth_plastic_bsdfs", C.c_void_p),
+        ("rough_conductor_bsdfs", C.c_void_p),
+        ("smooth_floor_bsdfs", C.c_void_p),
+        ("rough_floor_bsdfs", C.c_void_p),
+        ("rough_plastic_bsdfs", C.c_void_p),
+        ("num_bsdfs", C.c_uint32 * BSDF_TYPE_COUNT),
+        ("lights", C.c_void_p),
+        ("num_lights", C.c_uint32),
+        ("camera", Camera),
+    ]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [
+        ("spp", C.c_uint32),
+        ("first_timestamp", C.c_uint32),
+        ("max_depth", C.c_uint32),
+        ("rr_start_depth", C.c_uint32),
+        ("clamp", C.c_float),
+        ("timestamps_in_flight", C.c_uint32),
+        ("collect_traversal_stats", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+def default_render_params(spp=1, first_timestamp=0):
+    """The reference's shader literals: raygen.rgen:27,60,66."""
+    return RenderParams(spp, first_timestamp, 50, 10, 20.0, 0, 0, 0)
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("extension_rays", C.c_uint64),
+        ("shadow_rays", C.c_uint64),
+        ("shaded_vertices", C.c_uint64),
+        ("samples", C.c_uint64),
+        ("nodes_visited", C.c_uint64),
+        ("tris_tested", C.c_uint64),
+        ("stat_rays", C.c_uint64),
+        ("render_seconds", C.c_double),
+        ("extend_kernel_ms", C.c_double),
+        ("extend_launches", C.c_uint64),
+        ("shade_kernel_ms", C.c_double),
+        ("connect_kernel_ms", C.c_double),
+        ("bvh_build_ms", C.c_double),
+        ("num_triangles", C.c_uint64),
+        ("num_bvh_nodes", C.c_uint64),
+        ("device_bytes", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class SceneArrays:
+    """A flattened scene held in numpy arrays, convertible to ``SceneDesc``.
+
+    This is the POD form of the reference's ``Scene`` (S/renderer/Scene.h:140-186)
+    that crosses the C ABI.
+    """
+
+    def __init__(self):
+        self.instances = np.zeros(0, INSTANCE_DT)
+        self.positions = np.zeros((0, 3), np.float32)
+        self.normals = np.zeros((0, 3), np.float32)
+        self.bsdfs = [np.zeros(0, dt) for dt in BSDF_DTYPES]
+        self.lights = np.zeros(0, LIGHT_DT)
+        self.to_world = np.eye(4, dtype=np.float32).T.reshape(16).copy()  # glm memory order
+        self.fov = np.float32(0.5)
+
+    @property
+    def num_triangles(self):
+        return int(self.instances["vertex_count"].sum() // 3) if len(self.instances) else 0
+
+    def desc(self):
+        """Build a ``SceneDesc`` pointing at this object's arrays (keep `self` alive)."""
+        self.instances = np.ascontiguousarray(self.instances, INSTANCE_DT)
+        self.positions = np.ascontiguousarray(self.positions, np.float32).reshape(-1, 3)
+        self.normals = np.ascontiguousarray(self.normals, np.float32).reshape(-1, 3)
+        self.bsdfs = [np.ascontiguousarray(b, dt) for b, dt in zip(self.bsdfs, BSDF_DTYPES)]
+        self.lights = np.ascontiguousarray(self.lights, LIGHT_DT)
+        d = SceneDesc()
+        d.instances = self.instances.ctypes.data
+        d.num_instances = len(self.instances)
+        d.positions = self.positions.ctypes.data
+        d.normals = self.normals.ctypes.data
+        d.num_vertices = len(self.positions)
+        for name, arr in zip(BSDF_NAMES, self.bsdfs):
+            setattr(d, name + "_bsdfs", arr.ctypes.data if len(arr) else None)
+        for i, arr in enumerate(self.bsdfs):
+            d.num_bsdfs[i] = len(arr)
+        d.lights = self.lights.ctypes.data if len(self.lights) else None
+        d.num_lights = len(self.lights)
+        for i in range(16):
+            d.camera.to_world[i] = float(self.to_world[i])
+        d.camera.fov = float(self.fov)
+        return d

@@ -1,0 +1,275 @@
+/*
+ * gpuspectral_pt.h -- C ABI of the MI355X-native path-tracing integrator.
+ *
+ * This is the drop-in boundary for the reference's PathTracer render pass
+ * (sunho/GPUSpectral).  Everything a reference maintainer needs in order to
+ * replace `PathTracer::createRenderPass` + the Vulkan ray-tracing pipeline
+ * with the HIP wavefront tracer is declared here: plain pointers and sizes,
+ * `extern "C"`, no C++/torch types.
+ *
+ * Reference interfaces each entry point replaces (S/ = src/GPUSpectral/):
+ *   gsp_ctx_create / gsp_ctx_destroy
+ *        PathTracer::PathTracer(Renderer&) + setup()           S/renderer/PathTracer.h:50-53, PathTracer.cpp:5-7
+ *        (the Vulkan device/driver objects it borrows)         S/renderer/Renderer.cpp:19-45
+ *   gsp_upload_scene
+ *        PathTracer::prepareScene (instance table, 8 BSDF
+ *        arrays, light array)                                  S/renderer/PathTracer.cpp:58-93
+ *        Renderer::getOrCreateBLAS / HwDriver::createTLAS      S/renderer/Renderer.cpp:122-131, PathTracer.cpp:10-19
+ *        (vkCmdBuildAccelerationStructuresKHR)                 S/backend/vulkan/VulkanRays.cpp:6-86,91-181
+ *   gsp_frame_begin
+ *        accumulateBuffer = createTexture(RGBA32F, W, H)       S/renderer/PathTracer.cpp:5-7
+ *   gsp_render
+ *        driver.traceRays(pipeline, W, H) once per sample      S/renderer/PathTracer.cpp:24-39,
+ *        (raygen.rgen + rayhit.rchit + miss shaders)           S/backend/vulkan/VulkanDriver.cpp:319-347
+ *   gsp_download / gsp_download_compact / gsp_copy_accum_to_device
+ *        the RGBA32F accumulateBuffer the blit pass samples    S/renderer/PathTracer.cpp:41-55, raygen.rgen:84-108
+ *   gsp_last_error
+ *        std::runtime_error thrown by the driver               e.g. S/backend/vulkan/VulkanDevice.cpp:31,58,66
+ *
+ * All structs are POD with the reference's scalar layouts
+ * (S/renderer/Scene.h:29-109) so the reference's std::vectors can be passed
+ * by pointer without repacking.
+ *
+ * Threading: one host thread per context.  All device work is queued on the
+ * context's own HIP stream; gsp_render is asynchronous, the download calls and
+ * gsp_sync block.
+ */
+#ifndef GPUSPECTRAL_PT_H
+#define GPUSPECTRAL_PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSP_ABI_VERSION 1
+
+/* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
+#define GSP_OK 0
+#define GSP_ERR_INVALID 1 /* bad argument / call order            */
+#define GSP_ERR_DEVICE 2  /* HIP runtime error                    */
+#define GSP_ERR_NOMEM 3   /* device or host allocation failed     */
+#define GSP_ERR_SCENE 4   /* scene description is inconsistent    */
+
+/* ---- BSDF type ids: S/assets/shaders/BSDF.inc:1-8, rayhit.rchit:332-339 ---- */
+#define GSP_BSDF_DIFFUSE 0
+#define GSP_BSDF_SMOOTH_DIELECTRIC 1
+#define GSP_BSDF_SMOOTH_CONDUCTOR 2
+#define GSP_BSDF_SMOOTH_PLASTIC 3
+#define GSP_BSDF_ROUGH_CONDUCTOR 4
+#define GSP_BSDF_SMOOTH_FLOOR 5
+#define GSP_BSDF_ROUGH_FLOOR 6
+#define GSP_BSDF_ROUGH_PLASTIC 7
+#define GSP_BSDF_TYPE_COUNT 8
+
+/* handle = (type << 16) | index        S/renderer/Scene.h:83-97, pt_common.glsl:30-42 */
+#define GSP_BSDF_HANDLE(type, index) ((((uint32_t)(type)) << 16) | ((uint32_t)(index) & 0xFFFFu))
+
+/* ---- BSDF parameter records, scalar layout = S/renderer/Scene.h:29-81 ---- */
+typedef struct gsp_diffuse_bsdf {
+  float reflectance[3];
+  int32_t has_texture; /* never set by the reference loader; ignored */
+} gsp_diffuse_bsdf; /* 16 B */
+
+typedef struct gsp_smooth_dielectric_bsdf {
+  float ior_in;
+  float ior_out;
+} gsp_smooth_dielectric_bsdf; /* 8 B */
+
+typedef struct gsp_smooth_conductor_bsdf {
+  float ior_in;
+  float ior_out;
+} gsp_smooth_conductor_bsdf; /* 8 B */
+
+typedef struct gsp_smooth_plastic_bsdf {
+  float diffuse[3];
+  float ior_in;
+  float ior_out;
+  float r0;
+} gsp_smooth_plastic_bsdf; /* 24 B */
+
+typedef struct gsp_rough_conductor_bsdf {
+  float eta[3];
+  float k[3];
+  float reflectance[3];
+  float alpha;
+  int32_t has_texture;
+} gsp_rough_conductor_bsdf; /* 44 B */
+
+typedef struct gsp_smooth_floor_bsdf {
+  float diffuse[3];
+  float r0;
+} gsp_smooth_floor_bsdf; /* 16 B */
+
+typedef struct gsp_rough_floor_bsdf {
+  float diffuse[3];
+  float r0;
+  float alpha;
+} gsp_rough_floor_bsdf; /* 20 B */
+
+typedef struct gsp_rough_plastic_bsdf {
+  float diffuse[3];
+  float ior_in;
+  float ior_out;
+  float r0;
+  float alpha;
+  int32_t has_texture;
+} gsp_rough_plastic_bsdf; /* 32 B */
+
+/* S/renderer/Scene.h:106-109; rayhit.rchit:17-20 (world space, built on the host) */
+typedef struct gsp_triangle_light {
+  float positions[3][4];
+  float radiance[4];
+} gsp_triangle_light; /* 64 B */
+
+/*
+ * One render object = one TLAS instance (S/renderer/PathTracer.cpp:12-17,60-70).
+ * `transform` is the glm::mat4 object-to-world matrix in glm's memory order
+ * (column-major: transform[4*c + r]).  Vertices [first_vertex, first_vertex +
+ * vertex_count) of the shared position/normal arrays are the instance's
+ * de-indexed mesh: three consecutive vertices form one triangle
+ * (S/renderer/Mesh.cpp:7-51, rayhit.rchit:670).
+ */
+typedef struct gsp_instance {
+  float transform[16];
+  float emission[3];
+  uint32_t bsdf;     /* GSP_BSDF_HANDLE */
+  uint32_t twofaced; /* Material::twofaced */
+  uint32_t first_vertex;
+  uint32_t vertex_count; /* multiple of 3 */
+} gsp_instance; /* 92 B */
+
+/* S/renderer/PathTracer.h:10-15: eye = to_world column 3, fov in radians */
+typedef struct gsp_camera {
+  float to_world[16]; /* glm memory order (column-major) */
+  float fov;
+} gsp_camera;
+
+typedef struct gsp_scene_desc {
+  const gsp_instance* instances;
+  uint32_t num_instances;
+  const float* positions; /* tight float3, object space */
+  const float* normals;   /* tight float3, object space */
+  uint64_t num_vertices;
+
+  const gsp_diffuse_bsdf* diffuse_bsdfs;
+  const gsp_smooth_dielectric_bsdf* smooth_dielectric_bsdfs;
+  const gsp_smooth_conductor_bsdf* smooth_conductor_bsdfs;
+  const gsp_smooth_plastic_bsdf* smooth_plastic_bsdfs;
+  const gsp_rough_conductor_bsdf* rough_conductor_bsdfs;
+  const gsp_smooth_floor_bsdf* smooth_floor_bsdfs;
+  const gsp_rough_floor_bsdf* rough_floor_bsdfs;
+  const gsp_rough_plastic_bsdf* rough_plastic_bsdfs;
+  uint32_t num_bsdfs[GSP_BSDF_TYPE_COUNT]; /* indexed by GSP_BSDF_* */
+
+  const gsp_triangle_light* lights;
+  uint32_t num_lights;
+
+  gsp_camera camera;
+} gsp_scene_desc;
+
+/*
+ * Integrator constants.  Defaults (gsp_default_render_params) are the
+ * reference's shader literals: MAX_DEPTH 50 (raygen.rgen:27), Russian
+ * roulette when depth > 10 (raygen.rgen:66), firefly cutoff 20 (raygen.rgen:60).
+ */
+typedef struct gsp_render_params {
+  uint32_t spp;             /* samples per pixel to add in this call      */
+  uint32_t first_timestamp; /* RenderParams.timestamp of the first sample */
+  uint32_t max_depth;
+  uint32_t rr_start_depth;
+  float clamp;
+  uint32_t timestamps_in_flight; /* samples traced concurrently; 0 = auto */
+  uint32_t collect_traversal_stats; /* 1: count BVH nodes / triangles per ray (slower) */
+  uint32_t reserved;
+} gsp_render_params;
+
+typedef struct gsp_stats {
+  uint64_t extension_rays;
+  uint64_t shadow_rays;
+  uint64_t shaded_vertices;
+  uint64_t samples;          /* pixels * spp completed                           */
+  uint64_t nodes_visited;    /* BVH nodes popped, both ray kinds (stats mode)    */
+  uint64_t tris_tested;      /* triangle tests, both ray kinds (stats mode)      */
+  uint64_t stat_rays;        /* rays over which the two counters above were taken*/
+  double render_seconds;     /* host wall time inside gsp_render.. sync          */
+  double extend_kernel_ms;   /* sum of HIP-event durations of the extend kernel  */
+  uint64_t extend_launches;
+  double shade_kernel_ms;
+  double connect_kernel_ms;
+  double bvh_build_ms;       /* last gsp_upload_scene                            */
+  uint64_t num_triangles;
+  uint64_t num_bvh_nodes;
+  uint64_t device_bytes;     /* device memory currently held by the context      */
+} gsp_stats;
+
+typedef struct gsp_context gsp_context;
+
+/* Fill `p` with the reference's literals.  */
+void gsp_default_render_params(gsp_render_params* p);
+
+/* ABI version of the loaded library (== GSP_ABI_VERSION of this header). */
+int gsp_abi_version(void);
+
+/* Number of HIP devices visible (0 if none / runtime unavailable). */
+int gsp_device_count(void);
+
+/* Create a context on HIP device `device`.  Fails (GSP_ERR_DEVICE) when no
+ * gfx950-capable device is present: there is no CPU fallback. */
+int gsp_ctx_create(int device, gsp_context** out);
+void gsp_ctx_destroy(gsp_context* ctx);
+
+/* Copy the scene to the device, bake world-space triangles and build the BVH
+ * on the device.  The caller keeps ownership of every array in `scene`. */
+int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
+
+/*
+ * Allocate (and zero) the accumulate buffer for a width x height frame.
+ * `pixel_ids` optionally restricts this context to `num_pixels` pixels of the
+ * frame (global index = width*y + x, strictly increasing); NULL = the whole
+ * frame.  Seeds depend only on the global pixel index (raygen.rgen:37), so any
+ * partition of the frame over contexts/GPUs reproduces the same image.
+ */
+int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height,
+                    const uint32_t* pixel_ids, uint64_t num_pixels);
+
+/* Trace params->spp more samples for every owned pixel and fold them into the
+ * accumulate buffer with the reference's running mean (raygen.rgen:84-108). */
+int gsp_render(gsp_context* ctx, const gsp_render_params* params);
+
+/* Block until all queued work of the context has finished. */
+int gsp_sync(gsp_context* ctx);
+
+/* Full frame, RGBA32F row-major, width*height*4 floats; pixels this context
+ * does not own are written as 0. */
+int gsp_download(gsp_context* ctx, float* out_rgba);
+/* Only the owned pixels, in pixel_ids order: num_pixels*4 floats. */
+int gsp_download_compact(gsp_context* ctx, float* out_rgba);
+/* Device-to-device copy of the compact accumulate buffer into caller-owned
+ * device memory (e.g. a tensor handed to an RCCL gather). */
+int gsp_copy_accum_to_device(gsp_context* ctx, void* device_dst, uint64_t bytes);
+/* Overwrite the compact accumulate buffer from host memory (checkpoint/resume:
+ * buffer + next timestamp are the whole integrator state). */
+int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels);
+
+int gsp_get_stats(gsp_context* ctx, gsp_stats* out);
+int gsp_reset_stats(gsp_context* ctx);
+
+/*
+ * Test hook: closest-hit / any-hit queries against the uploaded BVH.
+ * rays = n * 8 floats {ox,oy,oz,tmin, dx,dy,dz,tmax}; hits = n * 4 words
+ * {t (f32), u (f32), v (f32), prim (i32, -1 = miss)}.  any_hit != 0 runs the
+ * shadow-ray kernel (prim = 0 when occluded, -1 when not).
+ */
+int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void* hits);
+
+/* Last error message of this context (or of the failed gsp_ctx_create when
+ * ctx == NULL).  Never NULL. */
+const char* gsp_last_error(const gsp_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUSPECTRAL_PT_H */

@@ -1,0 +1,353 @@
+"""oracle/mitsuba_loader.py -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+
+numpy restatement of the reference's Mitsuba-XML + OBJ scene loader,
+``S/engine/Loader.cpp:19-64,145-234,253-349`` (S/ = src/GPUSpectral/), used to
+check the product's C++ loader (gpuspectral_amd/host/Loader.cpp) array by array.
+
+The two libraries the reference loader calls are NOT in /root/reference (empty
+submodules, R/.gitmodules:10-12,34-36), so their behaviour is inferred from the
+call sites -- PARITY UNPINNED for these points:
+  * TinyParser-Mitsuba: camelCase property names are normalised to snake_case
+    (toWorld -> to_world, intIOR -> int_ior); ``<ref id>`` resolves to the
+    top-level object and appears among the anonymous children; a missing or
+    wrongly-typed property yields the getter's default (number 0, colour 0,0,0,
+    bool given default); ``<rgb value>`` takes 1 or 3 comma/space separated numbers.
+  * tinyobjloader: faces with more than 3 corners are fan-triangulated
+    (0, k-1, k); negative indices are relative to the current count.
+"""
+import math
+import os
+import re
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from gpuspectral_amd import abi
+
+F = np.float32
+
+# S/assets/rect.obj and S/assets/box.obj restated from their definition
+# (SURVEY.md Appendix C): unit rectangle in z=0 with normal +z, faces
+# "1 3 2 / 3 4 2"; cube of half-extent 1 with the same winding per face.
+_RECT_V = [(-1.0, 1.0, 0.0), (1.0, 1.0, 0.0), (-1.0, -1.0, 0.0), (1.0, -1.0, 0.0)]
+_BOX_FACES = [
+    # (normal, four corners in rect.obj order)
+    ((1, 0, 0), [(1, 1, 1), (1, 1, -1), (1, -1, 1), (1, -1, -1)]),
+    ((-1, 0, 0), [(-1, 1, -1), (-1, 1, 1), (-1, -1, -1), (-1, -1, 1)]),
+    ((0, 1, 0), [(-1, 1, -1), (1, 1, -1), (-1, 1, 1), (1, 1, 1)]),
+    ((0, -1, 0), [(-1, -1, 1), (1, -1, 1), (-1, -1, -1), (1, -1, -1)]),
+    ((0, 0, 1), [(-1, 1, 1), (1, 1, 1), (-1, -1, 1), (1, -1, 1)]),
+    ((0, 0, -1), [(1, 1, -1), (-1, 1, -1), (1, -1, -1), (-1, -1, -1)]),
+]
+
+
+def _quad(corners, normal):
+    order = (0, 2, 1, 2, 3, 1)  # f 1 3 2 / f 3 4 2
+    pos = np.array([corners[i] for i in order], F)
+    nrm = np.tile(np.array(normal, F), (6, 1))
+    return pos, nrm
+
+
+def rect_mesh():
+    return _quad(_RECT_V, (0.0, 0.0, 1.0))
+
+
+def box_mesh():
+    ps, ns = zip(*[_quad(c, n) for n, c in _BOX_FACES])
+    return np.concatenate(ps), np.concatenate(ns)
+
+
+def load_obj(path):
+    """Loader.cpp:19-64: de-indexed position/normal arrays, all shapes concatenated."""
+    v, vn = [], []
+    pos_idx, nrm_idx = [], []
+    with open(path, "r", errors="replace") as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                v.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("vn "):
+                p = line.split()
+                vn.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                corners = []
+                for tok in line.split()[1:]:
+                    parts = tok.split("/")
+                    vi = int(parts[0])
+                    vi = vi - 1 if vi > 0 else len(v) + vi
+                    ni = -1
+                    if len(parts) >= 3 and parts[2]:
+                        ni = int(parts[2])
+                        ni = ni - 1 if ni > 0 else len(vn) + ni
+                    corners.append((vi, ni))
+                for k in range(2, len(corners)):
+                    for c in (corners[0], corners[k - 1], corners[k]):
+                        pos_idx.append(c[0])
+                        nrm_idx.append(c[1])
+    va = np.array(v, F).reshape(-1, 3)
+    pos = va[np.array(pos_idx, np.int64)] if pos_idx else np.zeros((0, 3), F)
+    ni = np.array(nrm_idx, np.int64)
+    if len(vn) and (ni >= 0).all():
+        nrm = np.array(vn, F).reshape(-1, 3)[ni]
+    else:
+        # the reference indexes attrib.normals unchecked (Loader.cpp:56-59); files
+        # without vn are outside its contract.  Flat face normals are substituted.
+        tri = pos.reshape(-1, 3, 3)
+        fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(F)
+        ln = np.sqrt((fn * fn).sum(1, keepdims=True)).astype(F)
+        fn = np.where(ln > 0, fn / np.where(ln > 0, ln, 1), 0).astype(F)
+        nrm = np.repeat(fn, 3, axis=0)
+    return np.ascontiguousarray(pos, F), np.ascontiguousarray(nrm, F)
+
+
+def snake(name):
+    """toWorld -> to_world, intIOR -> int_ior."""
+    return re.sub(r"(?<=[a-z0-9])(?=[A-Z])", "_", name).lower()
+
+
+class Obj:
+    """Minimal stand-in for tinyparser_mitsuba::Object."""
+
+    def __init__(self, kind, plugin):
+        self.kind = kind  # 'shape' | 'bsdf' | 'sensor' | 'emitter' | other tag
+        self.plugin = plugin
+        self.props = {}  # snake name -> (type, value)
+        self.children = []  # anonymous children (Obj)
+        self.named = []  # (name, Obj)
+
+    def number(self, name, default=0.0):
+        p = self.props.get(name)
+        return F(p[1]) if p and p[0] == "number" else F(default)
+
+    def has(self, name):
+        return name in self.props
+
+    def color(self, name):
+        p = self.props.get(name)
+        if p and p[0] == "color":
+            return np.array(p[1], F)
+        return np.zeros(3, F)
+
+    def string(self, name, default=""):
+        p = self.props.get(name)
+        return p[1] if p and p[0] == "string" else default
+
+    def boolean(self, name, default=False):
+        p = self.props.get(name)
+        return p[1] if p and p[0] == "bool" else default
+
+
+_OBJECT_TAGS = {"shape", "bsdf", "sensor", "emitter", "texture", "medium", "integrator", "sampler", "film", "rfilter"}
+
+
+def _floats(text):
+    return [float(t) for t in re.split(r"[\s,]+", text.strip()) if t]
+
+
+def _parse_object(el, ids):
+    o = Obj(el.tag, el.get("type", ""))
+    for ch in el:
+        tag = ch.tag
+        name = snake(ch.get("name", ""))
+        if tag in ("float", "integer"):
+            o.props[name] = ("number", float(ch.get("value")))
+        elif tag == "boolean":
+            o.props[name] = ("bool", ch.get("value").strip().lower() == "true")
+        elif tag == "string":
+            o.props[name] = ("string", ch.get("value"))
+        elif tag in ("rgb", "srgb"):
+            vals = _floats(ch.get("value"))
+            if len(vals) == 1:
+                vals = vals * 3
+            o.props[name] = ("color", vals[:3])
+        elif tag in ("point", "vector"):
+            if ch.get("value") is not None:
+                vals = _floats(ch.get("value"))
+            else:
+                vals = [float(ch.get(k, "0")) for k in ("x", "y", "z")]
+            o.props[name] = ("vector", vals[:3])
+        elif tag == "transform":
+            m = np.eye(4, dtype=np.float64)
+            for t in ch:
+                if t.tag == "matrix":
+                    vals = _floats(t.get("value"))
+                    m = np.array(vals, np.float64).reshape(4, 4)
+            o.props[name] = ("transform", m.astype(F).reshape(16))  # 16 floats, row-major
+        elif tag == "ref":
+            target = ids.get(ch.get("id"))
+            if target is not None:
+                o.children.append(target)
+        elif tag in _OBJECT_TAGS:
+            child = _parse_object(ch, ids)
+            if ch.get("id"):
+                ids[ch.get("id")] = child
+            if ch.get("name"):
+                o.named.append((name, child))
+            else:
+                o.children.append(child)
+    return o
+
+
+def glm_mul_point(m, p):
+    """glm::mat4 * vec4(p, 1) in glm's association: (m0*x + m1*y) + (m2*z + m3*w)."""
+    m = m.reshape(4, 4)  # m[c] = column c (glm memory order)
+    x, y, z = F(p[0]), F(p[1]), F(p[2])
+    return ((m[0] * x + m[1] * y) + (m[2] * z + m[3] * F(1.0))).astype(F)
+
+
+class _Builder:
+    def __init__(self, asset_dir):
+        self.asset_dir = asset_dir
+        self.sc = abi.SceneArrays()
+        self.meshes = {}  # path -> (first_vertex, vertex_count)
+        self.pos, self.nrm = [], []
+        self.nverts = 0
+        self.instances = []
+        self.bsdfs = [[] for _ in range(abi.BSDF_TYPE_COUNT)]
+        self.lights = []
+        self.warnings = []
+
+    def mesh(self, path):
+        if path in self.meshes:
+            return self.meshes[path]
+        base = os.path.basename(path)
+        if not os.path.exists(path) and base == "rect.obj":
+            pos, nrm = rect_mesh()
+        elif not os.path.exists(path) and base == "box.obj":
+            pos, nrm = box_mesh()
+        else:
+            pos, nrm = load_obj(path)
+        rec = (self.nverts, len(pos))
+        self.pos.append(pos)
+        self.nrm.append(nrm)
+        self.nverts += len(pos)
+        self.meshes[path] = rec
+        return rec
+
+    def add_bsdf(self, btype, fields):
+        rec = np.zeros(1, abi.BSDF_DTYPES[btype])
+        for k, v in fields.items():
+            rec[k] = v
+        self.bsdfs[btype].append(rec)
+        return abi.bsdf_handle(btype, len(self.bsdfs[btype]) - 1)
+
+    # Loader.cpp:145-234
+    def load_material(self, mat, obj):
+        t = obj.plugin
+        if t == "twosided":
+            mat["twofaced"] = 1
+        if t == "diffuse":
+            mat["bsdf"] = self.add_bsdf(abi.BSDF_DIFFUSE, {"reflectance": obj.color("reflectance")})
+        elif t == "roughplastic":
+            diffuse = obj.color("diffuse_reflectance")
+            alpha = obj.number("alpha")
+            ior = obj.number("int_ior") if obj.has("int_ior") else F(1.3)
+            r0 = (ior - F(1.0)) / (ior + F(1.0))
+            r0 = F(r0 * r0)
+            mat["bsdf"] = self.add_bsdf(
+                abi.BSDF_ROUGH_PLASTIC,
+                {"diffuse": diffuse, "ior_in": ior, "ior_out": F(1.0), "r0": r0, "alpha": F(F(math.sqrt(2.0)) * alpha)},
+            )
+        elif t == "dielectric":
+            mat["bsdf"] = self.add_bsdf(
+                abi.BSDF_SMOOTH_DIELECTRIC, {"ior_in": obj.number("int_ior"), "ior_out": obj.number("ext_ior")}
+            )
+        elif t == "conductor":
+            ior = obj.number("eta") if obj.has("eta") else F(0.0)
+            mat["bsdf"] = self.add_bsdf(abi.BSDF_SMOOTH_CONDUCTOR, {"ior_in": ior, "ior_out": F(1.0)})
+        elif t == "plastic":
+            diffuse = obj.color("diffuse_reflectance")
+            ior = obj.number("int_ior") if obj.has("int_ior") else F(1.3)
+            r0 = (ior - F(1.0)) / (ior + F(1.0))
+            r0 = F(r0 * r0)
+            mat["bsdf"] = self.add_bsdf(
+                abi.BSDF_SMOOTH_PLASTIC, {"diffuse": diffuse, "ior_in": ior, "ior_out": F(1.0), "r0": r0}
+            )
+        elif t == "roughconductor":
+            mat["bsdf"] = self.add_bsdf(
+                abi.BSDF_ROUGH_CONDUCTOR,
+                {
+                    "eta": obj.color("eta"),
+                    "k": obj.color("k"),
+                    "reflectance": obj.color("specular_reflectance"),
+                    "alpha": F(F(math.sqrt(2.0)) * obj.number("alpha")),
+                },
+            )
+        for child in obj.children:
+            if child.kind == "bsdf":
+                self.load_material(mat, child)
+
+
+def load_scene(path, asset_dir=None):
+    """Loader.cpp:253-349 -> abi.SceneArrays."""
+    parent = os.path.dirname(os.path.abspath(path))
+    asset_dir = asset_dir or parent
+    root = ET.parse(path).getroot()
+    ids = {}
+    top = _parse_object(root, ids)
+    b = _Builder(asset_dir)
+    sc = b.sc
+    for obj in top.children:
+        if obj.kind == "shape":
+            pt = obj.plugin
+            if pt == "obj":
+                filename = os.path.join(parent, obj.string("filename"))
+            elif pt == "rectangle":
+                filename = os.path.join(asset_dir, "rect.obj")
+            elif pt == "cube":
+                filename = os.path.join(asset_dir, "box.obj")
+            elif pt == "disk":
+                filename = os.path.join(asset_dir, "disk.obj")
+            else:
+                b.warnings.append("unsupported shape type '%s' skipped" % pt)
+                continue
+            if not (os.path.exists(filename) or os.path.basename(filename) in ("rect.obj", "box.obj")):
+                b.warnings.append("missing mesh '%s' skipped" % filename)
+                continue
+            first, count = b.mesh(filename)
+            tr = obj.props.get("to_world")
+            rowmajor = tr[1] if tr and tr[0] == "transform" else np.eye(4, dtype=F).reshape(16)
+            matrix = rowmajor.reshape(4, 4).T.copy().reshape(16)  # glm::transpose(make_mat4(row-major))
+            c = obj.props.get("center")
+            if c and c[0] == "vector":  # Loader.cpp:288-293
+                matrix[12:16] = np.array([c[1][0], c[1][1], c[1][2], 1.0], F)
+            mat = {"emission": np.zeros(3, F), "twofaced": 0, "bsdf": 0}
+            emitting = False
+            for child in obj.children:
+                if child.kind == "bsdf":
+                    b.load_material(mat, child)
+                elif child.kind == "emitter" and child.plugin == "area":
+                    mat["emission"] = child.color("radiance")
+                    emitting = True
+            inst = np.zeros(1, abi.INSTANCE_DT)
+            inst["transform"] = matrix
+            inst["emission"] = mat["emission"]
+            inst["bsdf"] = mat["bsdf"]
+            inst["twofaced"] = mat["twofaced"]
+            inst["first_vertex"] = first
+            inst["vertex_count"] = count
+            b.instances.append(inst)
+            if emitting:  # Loader.cpp:316-330
+                pos = np.concatenate(b.pos)[first : first + count] if b.pos else np.zeros((0, 3), F)
+                for i in range(0, count - 2, 3):
+                    lt = np.zeros(1, abi.LIGHT_DT)
+                    for k in range(3):
+                        lt["positions"][0, k] = glm_mul_point(matrix, pos[i + k])
+                    lt["radiance"][0, :3] = mat["emission"]
+                    lt["radiance"][0, 3] = 1.0
+                    b.lights.append(lt)
+        elif obj.kind == "sensor":  # Loader.cpp:331-337
+            tr = obj.props.get("to_world")
+            rowmajor = tr[1] if tr and tr[0] == "transform" else np.eye(4, dtype=F).reshape(16)
+            fov = obj.number("fov")
+            sc.fov = F(np.float64(fov) * math.pi / np.float64(F(180.0)))
+            sc.to_world = rowmajor.reshape(4, 4).T.copy().reshape(16)
+    sc.instances = np.concatenate(b.instances) if b.instances else np.zeros(0, abi.INSTANCE_DT)
+    sc.positions = np.concatenate(b.pos) if b.pos else np.zeros((0, 3), F)
+    sc.normals = np.concatenate(b.nrm) if b.nrm else np.zeros((0, 3), F)
+    sc.bsdfs = [
+        np.concatenate(lst) if lst else np.zeros(0, dt) for lst, dt in zip(b.bsdfs, abi.BSDF_DTYPES)
+    ]
+    sc.lights = np.concatenate(b.lights) if b.lights else np.zeros(0, abi.LIGHT_DT)
+    sc.warnings = b.warnings
+    return sc
