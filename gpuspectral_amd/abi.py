@@ -121,7 +121,7 @@ class RenderParams(C.Structure):
         ("clamp", C.c_float),
         ("timestamps_in_flight", C.c_uint32),
         ("collect_traversal_stats", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("collect_kernel_times", C.c_uint32),
     ]
 
 

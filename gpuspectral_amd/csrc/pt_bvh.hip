@@ -1,0 +1,409 @@
+// pt_bvh.hip -- device-side scene bake + LBVH build for gfx950.
+//
+// Replaces the driver-side acceleration-structure build of the reference
+// (Renderer::getOrCreateBLAS S/renderer/Renderer.cpp:122-131, createTLAS
+// S/renderer/PathTracer.cpp:10-19, vkCmdBuildAccelerationStructuresKHR
+// S/backend/vulkan/VulkanRays.cpp:81-85,176-180).  The two-level BLAS/TLAS is
+// flattened: every instance's triangles are transformed to world space
+// (gl_ObjectToWorldEXT * vec4(pos,1), rayhit.rchit:679-681) and one BVH is built
+// over all of them.
+//
+// Passes (all on one stream, one thread per triangle / node):
+//   bake      world-space triangle packets, shading packets (geometric normal,
+//             transformInvT * vertex normals), padded boxes, scene bounds
+//   morton    63-bit Morton code of the box centre
+//   sort      rocPRIM radix sort of (code, triangle) pairs
+//   scatter   packets into leaf (Morton) order -> coherent rays touch adjacent HBM lines
+//   hierarchy Karras 2012 binary radix tree over the sorted codes
+//   fit       bottom-up boxes; each 64-B node stores BOTH child boxes, so a
+//             traversal step reads exactly one node record
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "pt_internal.h"
+
+namespace gsp {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ordered_to_float(uint32_t k) {
+  uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(b);
+#else
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+#endif
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ q4 mkq(float x, float y, float z, float w) {
+  q4 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  r.w = w;
+  return r;
+}
+
+// scene_bounds[0..2] = ordered min, [3..5] = ordered max
+__global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__ isect, q4* __restrict__ shade,
+                                                  q4* __restrict__ box_lo, q4* __restrict__ box_hi,
+                                                  uint32_t* __restrict__ scene_bounds) {
+  const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  if (g < in.num_tris) {
+    // instance that owns global triangle g: last i with tri_first[i] <= g
+    uint32_t a = 0, b = in.num_instances;
+    while (b - a > 1) {
+      uint32_t m = (a + b) >> 1;
+      if (in.tri_first[m] <= g) a = m; else b = m;
+    }
+    const gsp_instance& I = in.instances[a];
+    const uint32_t v = I.first_vertex + 3u * (g - in.tri_first[a]);
+    const float* P = in.positions + 3ull * v;
+    const float* Nn = in.normals + 3ull * v;
+    const f3 p0 = xform_point(I.transform, mk3(P[0], P[1], P[2]));
+    const f3 p1 = xform_point(I.transform, mk3(P[3], P[4], P[5]));
+    const f3 p2 = xform_point(I.transform, mk3(P[6], P[7], P[8]));
+    const float* T = in.inv_t + 16ull * a;
+    const f3 n0 = xform_dir(T, mk3(Nn[0], Nn[1], Nn[2]));
+    const f3 n1 = xform_dir(T, mk3(Nn[3], Nn[4], Nn[5]));
+    const f3 n2 = xform_dir(T, mk3(Nn[6], Nn[7], Nn[8]));
+    const f3 e1 = p1 - p0, e2 = p2 - p0;
+    const f3 N = normalize(cross(e1, e2));  // rayhit.rchit:694
+    isect[3ull * g + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float(g));
+    isect[3ull * g + 1] = mkq(e1.x, e1.y, e1.z, 0.0f);
+    isect[3ull * g + 2] = mkq(e2.x, e2.y, e2.z, 0.0f);
+    shade[4ull * g + 0] = mkq(N.x, N.y, N.z, __uint_as_float(a));
+    shade[4ull * g + 1] = mkq(n0.x, n0.y, n0.z, 0.0f);
+    shade[4ull * g + 2] = mkq(n1.x, n1.y, n1.z, 0.0f);
+    shade[4ull * g + 3] = mkq(n2.x, n2.y, n2.z, 0.0f);
+    const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float l = fminf(px[k], fminf(qx[k], rx[k]));
+      float h = fmaxf(px[k], fmaxf(qx[k], rx[k]));
+      // conservative padding: box culling must never reject a triangle the
+      // triangle test would accept
+      float pad = 1e-5f * fmaxf(fmaxf(fabsf(l), fabsf(h)), 1e-3f) + 1e-6f * (h - l);
+      lo[k] = l - pad;
+      hi[k] = h + pad;
+    }
+    box_lo[g] = mkq(lo[0], lo[1], lo[2], 0.0f);
+    box_hi[g] = mkq(hi[0], hi[1], hi[2], 0.0f);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float l = wave_min(lo[k]);
+    float h = wave_max(hi[k]);
+    if ((threadIdx.x & 63) == 0 && l <= h) {
+      atomicMin(&scene_bounds[k], float_to_ordered(l));
+      atomicMax(&scene_bounds[3 + k], float_to_ordered(h));
+    }
+  }
+}
+
+__device__ __forceinline__ uint64_t expand21(uint64_t v) {
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x001f00000000ffffull;
+  v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_morton(uint32_t n, const q4* __restrict__ box_lo,
+                                                   const q4* __restrict__ box_hi,
+                                                   const uint32_t* __restrict__ scene_bounds,
+                                                   uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= n) return;
+  const float smin[3] = {ordered_to_float(scene_bounds[0]), ordered_to_float(scene_bounds[1]),
+                         ordered_to_float(scene_bounds[2])};
+  const float smax[3] = {ordered_to_float(scene_bounds[3]), ordered_to_float(scene_bounds[4]),
+                         ordered_to_float(scene_bounds[5])};
+  const q4 l = box_lo[g], h = box_hi[g];
+  const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+  uint64_t code = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float ext = smax[k] - smin[k];
+    float t = ext > 0.0f ? (c[k] - smin[k]) / ext : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    uint64_t q = (uint64_t)fminf(t * 2097152.0f, 2097151.0f);
+    code |= expand21(q) << (2 - k);
+  }
+  keys[g] = code;
+  vals[g] = g;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter(uint32_t n, const uint32_t* __restrict__ sorted_vals,
+                                                    const q4* __restrict__ isect_in, const q4* __restrict__ shade_in,
+                                                    const q4* __restrict__ lo_in, const q4* __restrict__ hi_in,
+                                                    q4* __restrict__ isect, q4* __restrict__ shade,
+                                                    q4* __restrict__ leaf_lo, q4* __restrict__ leaf_hi,
+                                                    uint32_t* __restrict__ slot_to_global) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t g = sorted_vals[s];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) isect[3ull * s + k] = isect_in[3ull * g + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) shade[4ull * s + k] = shade_in[4ull * g + k];
+  leaf_lo[s] = lo_in[g];
+  leaf_hi[s] = hi_in[g];
+  slot_to_global[s] = g;
+}
+
+// common-prefix length of sorted keys i and j (index breaks ties), -1 outside the array
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((unsigned)(i ^ j));
+  return __clzll((long long)(a ^ b));
+}
+
+// Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees"
+__global__ __launch_bounds__(kBlock) void k_hierarchy(int n, const uint64_t* __restrict__ keys,
+                                                      int32_t* __restrict__ child_l, int32_t* __restrict__ child_r,
+                                                      int32_t* __restrict__ parent_int,
+                                                      int32_t* __restrict__ parent_leaf) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  if (lo == gamma) {
+    child_l[i] = make_leaf((uint32_t)gamma, 1);
+    parent_leaf[gamma] = i;
+  } else {
+    child_l[i] = gamma;
+    parent_int[gamma] = i;
+  }
+  if (hi == gamma + 1) {
+    child_r[i] = make_leaf((uint32_t)(gamma + 1), 1);
+    parent_leaf[gamma + 1] = i;
+  } else {
+    child_r[i] = gamma + 1;
+    parent_int[gamma + 1] = i;
+  }
+  if (i == 0) parent_int[0] = -1;
+}
+
+__device__ __forceinline__ void child_box(int32_t code, const q4* __restrict__ leaf_lo, const q4* __restrict__ leaf_hi,
+                                          const q4* int_lo, const q4* int_hi, q4& lo, q4& hi) {
+  if (code < 0) {
+    const uint32_t slot = ((uint32_t)~code) >> 2;
+    lo = leaf_lo[slot];
+    hi = leaf_hi[slot];
+  } else {
+    lo = int_lo[code];
+    hi = int_hi[code];
+  }
+}
+
+// Bottom-up fit: the second thread to reach a node (arrival counter) owns it.
+// Boxes written by the sibling subtree come from another CU / XCD, hence the
+// agent-scope fences on both sides of the counter (MI355X: per-CU L1 and
+// per-XCD L2 are not coherent).
+__global__ __launch_bounds__(kBlock) void k_fit(int n, const int32_t* __restrict__ child_l,
+                                                const int32_t* __restrict__ child_r,
+                                                const int32_t* __restrict__ parent_int,
+                                                const int32_t* __restrict__ parent_leaf,
+                                                const q4* __restrict__ leaf_lo, const q4* __restrict__ leaf_hi,
+                                                q4* int_lo, q4* int_hi, uint32_t* arrive, q4* __restrict__ nodes,
+                                                uint32_t* __restrict__ max_depth) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  int node = parent_leaf[s];
+  uint32_t depth = 0;
+  while (node >= 0) {
+    ++depth;
+    __threadfence();
+    const uint32_t old = atomicAdd(&arrive[node], 1u);
+    if (old == 0) break;  // sibling subtree not finished: it will continue from here
+    __threadfence();
+    const int32_t cl = child_l[node], cr = child_r[node];
+    q4 llo, lhi, rlo, rhi;
+    child_box(cl, leaf_lo, leaf_hi, int_lo, int_hi, llo, lhi);
+    child_box(cr, leaf_lo, leaf_hi, int_lo, int_hi, rlo, rhi);
+    q4* N = nodes + 4ll * node;
+    N[0] = mkq(llo.x, llo.y, llo.z, lhi.x);
+    N[1] = mkq(lhi.y, lhi.z, rlo.x, rlo.y);
+    N[2] = mkq(rlo.z, rhi.x, rhi.y, rhi.z);
+    N[3] = mkq(__uint_as_float((uint32_t)cl), __uint_as_float((uint32_t)cr), 0.0f, 0.0f);
+    int_lo[node] = mkq(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.0f);
+    int_hi[node] = mkq(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
+    node = parent_int[node];
+  }
+  // a thread that walked to the root saw every level of its own path
+  if (node < 0) atomicMax(max_depth, depth);
+}
+
+// depth of the deepest leaf (number of internal nodes above it)
+__global__ __launch_bounds__(kBlock) void k_depth(int n, const int32_t* __restrict__ parent_int,
+                                                  const int32_t* __restrict__ parent_leaf,
+                                                  uint32_t* __restrict__ max_depth) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t depth = 0;
+  if (s < n) {
+    int node = parent_leaf[s];
+    while (node >= 0) {
+      ++depth;
+      node = parent_int[node];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) depth = max(depth, (uint32_t)__shfl_xor((int)depth, o));
+  if ((threadIdx.x & 63) == 0 && depth) atomicMax(max_depth, depth);
+}
+
+struct Scratch {
+  std::vector<void*> ptrs;
+  size_t bytes = 0;
+  ~Scratch() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <class T>
+  hipError_t alloc(T** p, size_t count) {
+    size_t b = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)p, b);
+    if (e == hipSuccess) {
+      ptrs.push_back(*p);
+      bytes += b;
+    }
+    return e;
+  }
+};
+
+inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+void free_bvh(DeviceBvh& b) {
+  (void)hipFree(b.nodes);
+  (void)hipFree(b.tri_isect);
+  (void)hipFree(b.tri_shade);
+  (void)hipFree(b.slot_to_global);
+  b = DeviceBvh{};
+}
+
+int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::string& err) {
+  free_bvh(out);
+  const uint32_t n = in.num_tris;
+  const uint32_t slots = n ? n : 1;  // an empty scene keeps one degenerate triangle (det == 0: never hit)
+  out.num_tris = n;
+  out.num_nodes = n >= 2 ? n - 1 : 0;
+  size_t b_nodes = (size_t)std::max<uint32_t>(out.num_nodes, 1) * 64, b_is = (size_t)slots * 48,
+         b_sh = (size_t)slots * 64, b_map = (size_t)slots * 4;
+  GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
+  GSP_HIP_TRY(hipMalloc((void**)&out.tri_isect, b_is));
+  GSP_HIP_TRY(hipMalloc((void**)&out.tri_shade, b_sh));
+  GSP_HIP_TRY(hipMalloc((void**)&out.slot_to_global, b_map));
+  out.bytes = b_nodes + b_is + b_sh + b_map;
+  GSP_HIP_TRY(hipMemsetAsync(out.nodes, 0, b_nodes, stream));
+  GSP_HIP_TRY(hipMemsetAsync(out.tri_isect, 0, b_is, stream));
+  GSP_HIP_TRY(hipMemsetAsync(out.tri_shade, 0, b_sh, stream));
+  GSP_HIP_TRY(hipMemsetAsync(out.slot_to_global, 0, b_map, stream));
+  out.root = make_leaf(0, 1);
+  out.depth = 0;
+  if (n == 0) {
+    GSP_HIP_TRY(hipStreamSynchronize(stream));
+    return GSP_OK;
+  }
+
+  Scratch S;
+  q4 *isect_g, *shade_g, *lo_g, *hi_g, *leaf_lo, *leaf_hi, *int_lo, *int_hi;
+  uint32_t *bounds, *vals_in, *vals_out, *arrive, *d_depth;
+  uint64_t *keys_in, *keys_out;
+  int32_t *child_l, *child_r, *parent_int, *parent_leaf;
+  GSP_HIP_TRY(S.alloc(&isect_g, 3ull * n));
+  GSP_HIP_TRY(S.alloc(&shade_g, 4ull * n));
+  GSP_HIP_TRY(S.alloc(&lo_g, n));
+  GSP_HIP_TRY(S.alloc(&hi_g, n));
+  GSP_HIP_TRY(S.alloc(&leaf_lo, n));
+  GSP_HIP_TRY(S.alloc(&leaf_hi, n));
+  GSP_HIP_TRY(S.alloc(&int_lo, n));
+  GSP_HIP_TRY(S.alloc(&int_hi, n));
+  GSP_HIP_TRY(S.alloc(&bounds, 8));
+  GSP_HIP_TRY(S.alloc(&keys_in, n));
+  GSP_HIP_TRY(S.alloc(&keys_out, n));
+  GSP_HIP_TRY(S.alloc(&vals_in, n));
+  GSP_HIP_TRY(S.alloc(&vals_out, n));
+  GSP_HIP_TRY(S.alloc(&arrive, n));
+  GSP_HIP_TRY(S.alloc(&d_depth, 1));
+  GSP_HIP_TRY(S.alloc(&child_l, n));
+  GSP_HIP_TRY(S.alloc(&child_r, n));
+  GSP_HIP_TRY(S.alloc(&parent_int, n));
+  GSP_HIP_TRY(S.alloc(&parent_leaf, n));
+
+  const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+  GSP_HIP_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
+  GSP_HIP_TRY(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, stream));
+  GSP_HIP_TRY(hipMemsetAsync(d_depth, 0, sizeof(uint32_t), stream));
+
+  hipLaunchKernelGGL(k_bake, dim3(blocks_for(n)), dim3(kBlock), 0, stream, in, isect_g, shade_g, lo_g, hi_g, bounds);
+  hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, lo_g, hi_g, bounds, keys_in, vals_in);
+  GSP_HIP_TRY(hipGetLastError());
+
+  size_t temp_bytes = 0;
+  GSP_HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 63, stream));
+  void* temp = nullptr;
+  GSP_HIP_TRY(S.alloc((char**)&temp, temp_bytes));
+  GSP_HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 63, stream));
+
+  hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, vals_out, isect_g, shade_g, lo_g, hi_g,
+                     out.tri_isect, out.tri_shade, leaf_lo, leaf_hi, out.slot_to_global);
+  if (n >= 2) {
+    hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(n - 1)), dim3(kBlock), 0, stream, (int)n, keys_out, child_l, child_r,
+                       parent_int, parent_leaf);
+    hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, child_l, child_r, parent_int,
+                       parent_leaf, leaf_lo, leaf_hi, int_lo, int_hi, arrive, out.nodes, d_depth);
+    hipLaunchKernelGGL(k_depth, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, parent_int, parent_leaf, d_depth);
+    out.root = 0;
+  }
+  GSP_HIP_TRY(hipGetLastError());
+  uint32_t depth = 0;
+  GSP_HIP_TRY(hipMemcpyAsync(&depth, d_depth, sizeof(depth), hipMemcpyDeviceToHost, stream));
+  GSP_HIP_TRY(hipStreamSynchronize(stream));
+  out.depth = depth;
+  return GSP_OK;
+}
+
+}  // namespace gsp

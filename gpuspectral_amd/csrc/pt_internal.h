@@ -1,0 +1,49 @@
+// pt_internal.h -- declarations shared by the HIP translation units of
+// libgpuspectral_pt.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/gpuspectral_pt.h"
+#include "pt_stages.h"
+
+namespace gsp {
+
+#define GSP_HIP_TRY(expr)                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      err = std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"; \
+      return e_ == hipErrorOutOfMemory ? GSP_ERR_NOMEM : GSP_ERR_DEVICE;                      \
+    }                                                                                         \
+  } while (0)
+
+// Result of the device BVH build; all pointers are device memory owned by the caller's context.
+struct DeviceBvh {
+  q4* nodes = nullptr;      // 4 quads per node
+  q4* tri_isect = nullptr;  // 3 quads per slot
+  q4* tri_shade = nullptr;  // 4 quads per slot
+  uint32_t* slot_to_global = nullptr;
+  int32_t root = 0;
+  uint32_t num_tris = 0;   // real triangles (0 allowed; one dummy slot is still allocated)
+  uint32_t num_nodes = 0;
+  uint32_t depth = 0;      // max number of internal nodes on a root-to-leaf path
+  size_t bytes = 0;
+};
+
+struct BuildInput {
+  const gsp_instance* instances;  // device
+  const float* inv_t;             // device, 16 floats per instance: inverse(transpose(M))
+  const uint32_t* tri_first;      // device, num_instances + 1 prefix of triangle counts
+  uint32_t num_instances;
+  const float* positions;  // device, object space
+  const float* normals;    // device
+  uint32_t num_tris;
+};
+
+// Builds the LBVH on `stream`.  Returns GSP_OK or an error code with `err` set.
+int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::string& err);
+void free_bvh(DeviceBvh& b);
+
+}  // namespace gsp

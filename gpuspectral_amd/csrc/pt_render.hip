@@ -1,0 +1,870 @@
+// pt_render.hip -- wavefront path tracer for gfx950 (MI355X) behind the C ABI
+// of include/gpuspectral_pt.h.
+//
+// One render pass handles K consecutive timestamps of every owned pixel
+// (K * num_pixels paths).  Per bounce, three kernels run over dense queues in HBM:
+//
+//   extend  : one ray per lane, stack-based BVH2 traversal (LDS stack), writes a
+//             16-B hit record                    (traceRayEXT, raygen.rgen:53-58)
+//   shade   : one shading vertex per lane (rayhit.rchit:666-797 + the raygen
+//             bookkeeping of raygen.rgen:59-80); survivors are compacted into
+//             the next queue with a wave64 ballot + one atomic per wave; paths
+//             that need next-event estimation emit a 64-B shadow-queue record
+//   connect : any-hit traversal of the shadow queue, adds the bounce's emitted
+//             radiance to the sample and sets the continuing path's MIS weight
+//                                                (rayhit.rchit:737-757)
+//
+// and one `resolve` kernel per pass folds the K samples of each pixel into the
+// RGBA32F accumulate buffer in timestamp order (raygen.rgen:84-108).
+//
+// Queue records (SoA of 16-B quads, coalesced 1 KiB per wave-load):
+//   P0 = {o.x, o.y, o.z, d.x}   P1 = {d.y, d.z, bits(seed), bits(sid)}
+//   P2 = {w.r, w.g, w.b, directWeight}   FL = flags word
+//   HIT = {t, u, v, bits(slot)}
+//   S0 = {o.xyz, tmax}  S1 = {d.xyz, bits(sid)}  S2 = {nee.rgb, dw_nee}  S3 = {emis.rgb, bits(next)}
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "pt_hostmath.h"
+#include "pt_internal.h"
+
+namespace gsp {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLdsStack = 24;  // stack entries per lane kept in LDS; deeper levels spill to HBM
+
+struct PathQueue {
+  q4* P0;
+  q4* P1;
+  q4* P2;
+  uint32_t* FL;
+};
+struct ShadowQueue {
+  q4* S0;
+  q4* S1;
+  q4* S2;
+  q4* S3;
+};
+
+// device counters
+enum { C_NEXT = 0, C_SHADOW = 1, C_COUNT = 2 };
+struct DevStats {
+  unsigned long long shaded, nodes, tris, stat_rays;
+};
+
+// ---- per-lane traversal stack: LDS first, HBM spill behind it -----------------
+struct LaneStack {
+  int32_t* lds;    // &lds_stack[threadIdx.x], stride kBlock
+  int32_t* spill;  // &spill[global thread], stride spill_stride
+  uint32_t spill_stride;
+  int sp;
+  __device__ __forceinline__ void push(int32_t v) {
+    if (sp < kLdsStack) lds[sp * kBlock] = v;
+    else spill[(size_t)(sp - kLdsStack) * spill_stride] = v;
+    ++sp;
+  }
+  __device__ __forceinline__ int32_t pop() {
+    --sp;
+    return sp < kLdsStack ? lds[sp * kBlock] : spill[(size_t)(sp - kLdsStack) * spill_stride];
+  }
+  __device__ __forceinline__ bool empty() const { return sp == 0; }
+};
+
+__device__ __forceinline__ q4 mkq(float x, float y, float z, float w) {
+  q4 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  r.w = w;
+  return r;
+}
+__device__ __forceinline__ float ub(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t fb(float f) { return __float_as_uint(f); }
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- generate ------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t num_pixels, uint32_t K,
+                                                      uint32_t first_timestamp,
+                                                      const uint32_t* __restrict__ pixel_ids, PathQueue q,
+                                                      q4* __restrict__ result) {
+  const uint64_t total = (uint64_t)num_pixels * K;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t k = (uint32_t)(i / num_pixels), lp = (uint32_t)(i % num_pixels);
+    const uint32_t gid = pixel_ids ? pixel_ids[lp] : lp;
+    PathState p;
+    generate_path(rc, gid, first_timestamp + k, (uint32_t)i, p);
+    q.P0[i] = mkq(p.o.x, p.o.y, p.o.z, p.d.x);
+    q.P1[i] = mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid));
+    q.P2[i] = mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight);
+    q.FL[i] = p.flags;
+    result[i] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+}
+
+// ---- extend ---------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, uint32_t n, PathQueue q, q4* __restrict__ hits,
+                                                    int32_t* __restrict__ spill, uint32_t spill_stride,
+                                                    DevStats* __restrict__ stats) {
+  __shared__ int32_t lds_stack[kLdsStack * kBlock];
+  const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+  LaneStack stk;
+  stk.lds = lds_stack + threadIdx.x;
+  stk.spill = spill + gtid;
+  stk.spill_stride = spill_stride;
+  TraceCounters cnt;
+  cnt.nodes = 0;
+  cnt.tris = 0;
+  uint32_t rays = 0;
+  for (uint32_t i = gtid; i < n; i += gridDim.x * kBlock) {
+    const q4 p0 = q.P0[i], p1 = q.P1[i];
+    HitRec h;
+    stk.sp = 0;
+    traverse<false, STATS>(S.nodes, S.tri_isect, S.root, mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), 0.0f, 1e10f, stk,
+                           h, cnt);
+    hits[i] = mkq(h.t, h.u, h.v, ub((uint32_t)h.slot));
+    ++rays;
+  }
+  if (STATS) {
+    unsigned long long a = wave_sum(cnt.nodes), b = wave_sum(cnt.tris), c = wave_sum(rays);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&stats->nodes, a);
+      atomicAdd(&stats->tris, b);
+      atomicAdd(&stats->stat_rays, c);
+    }
+  }
+}
+
+// ---- shade ----------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
+                                                   const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
+                                                   q4* __restrict__ result, uint32_t* __restrict__ counters,
+                                                   DevStats* __restrict__ stats) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // every lane of a wave runs the same number of iterations (ballots need the full wave)
+  const uint32_t stride = gridDim.x * kBlock;
+  const uint32_t iters = (n + stride - 1) / stride;
+  unsigned long long shaded = 0;
+  for (uint32_t it = 0; it < iters; ++it) {
+    const uint32_t i = it * stride + blockIdx.x * kBlock + threadIdx.x;
+    bool alive = false, has_shadow = false;
+    ShadeOut out;
+    if (i < n) {
+      const q4 hq = hits[i];
+      HitRec h;
+      h.t = hq.x;
+      h.u = hq.y;
+      h.v = hq.z;
+      h.slot = (int32_t)fb(hq.w);
+      if (h.slot >= 0) {  // miss: miss.rmiss:15-18, the path ends and adds nothing
+        const q4 p0 = cur.P0[i], p1 = cur.P1[i], p2 = cur.P2[i];
+        PathState in;
+        in.o = mk3(p0.x, p0.y, p0.z);
+        in.d = mk3(p0.w, p1.x, p1.y);
+        in.seed = fb(p1.z);
+        in.sid = fb(p1.w);
+        in.weight = mk3(p2.x, p2.y, p2.z);
+        in.directWeight = p2.w;
+        in.flags = cur.FL[i];
+        shade_vertex(S, rc, in, h, out);
+        alive = out.alive;
+        has_shadow = out.has_shadow;
+        ++shaded;
+        if (!has_shadow) {
+          q4 r = result[in.sid];
+          add_emitted(rc.clamp, out.emitted, r);
+          result[in.sid] = r;
+        }
+      }
+    }
+    // wave64 compaction of the survivors: ballot + prefix popcount, one atomic per wave
+    const uint64_t am = __ballot(alive);
+    uint32_t base = 0;
+    if (lane == 0 && am) base = atomicAdd(&counters[C_NEXT], (uint32_t)__popcll(am));
+    base = __shfl(base, 0);
+    const uint32_t j = base + (uint32_t)__popcll(am & lt_mask);
+    if (alive) {
+      const PathState& p = out.next;
+      nxt.P0[j] = mkq(p.o.x, p.o.y, p.o.z, p.d.x);
+      nxt.P1[j] = mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid));
+      nxt.P2[j] = mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight);
+      nxt.FL[j] = p.flags;
+    }
+    const uint64_t sm = __ballot(has_shadow);
+    uint32_t sbase = 0;
+    if (lane == 0 && sm) sbase = atomicAdd(&counters[C_SHADOW], (uint32_t)__popcll(sm));
+    sbase = __shfl(sbase, 0);
+    if (has_shadow) {
+      const uint32_t s = sbase + (uint32_t)__popcll(sm & lt_mask);
+      const ShadowRay& r = out.shadow;
+      sq.S0[s] = mkq(r.o.x, r.o.y, r.o.z, r.tmax);
+      sq.S1[s] = mkq(r.d.x, r.d.y, r.d.z, ub(r.sid));
+      sq.S2[s] = mkq(r.nee.x, r.nee.y, r.nee.z, r.dw_nee);
+      sq.S3[s] = mkq(r.emis.x, r.emis.y, r.emis.z, ub(alive ? j : 0xffffffffu));
+    }
+  }
+  shaded = wave_sum(shaded);
+  if (lane == 0 && shaded) atomicAdd(&stats->shaded, shaded);
+}
+
+// ---- connect --------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_connect(SceneView S, float clampv, const uint32_t* __restrict__ counters,
+                                                     ShadowQueue sq, q4* __restrict__ next_P2,
+                                                     q4* __restrict__ result, int32_t* __restrict__ spill,
+                                                     uint32_t spill_stride, DevStats* __restrict__ stats) {
+  __shared__ int32_t lds_stack[kLdsStack * kBlock];
+  const uint32_t n = counters[C_SHADOW];
+  const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+  LaneStack stk;
+  stk.lds = lds_stack + threadIdx.x;
+  stk.spill = spill + gtid;
+  stk.spill_stride = spill_stride;
+  TraceCounters cnt;
+  cnt.nodes = 0;
+  cnt.tris = 0;
+  uint32_t rays = 0;
+  for (uint32_t i = gtid; i < n; i += gridDim.x * kBlock) {
+    const q4 s0 = sq.S0[i], s1 = sq.S1[i];
+    HitRec h;
+    stk.sp = 0;
+    const bool occluded = traverse<true, STATS>(S.nodes, S.tri_isect, S.root, mk3(s0.x, s0.y, s0.z),
+                                                mk3(s1.x, s1.y, s1.z), 0.01f, s0.w, stk, h, cnt);
+    const q4 s2 = sq.S2[i], s3 = sq.S3[i];
+    ShadowRay r;
+    r.nee = mk3(s2.x, s2.y, s2.z);
+    r.emis = mk3(s3.x, s3.y, s3.z);
+    const uint32_t sid = fb(s1.w);
+    q4 res = result[sid];
+    bool nee_done;
+    connect_vertex(clampv, r, occluded, res, nee_done);
+    result[sid] = res;
+    const uint32_t nx = fb(s3.w);
+    if (nee_done && nx != 0xffffffffu) next_P2[nx].w = s2.w;  // rayhit.rchit:785-787
+    ++rays;
+  }
+  if (STATS) {
+    unsigned long long a = wave_sum(cnt.nodes), b = wave_sum(cnt.tris), c = wave_sum(rays);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&stats->nodes, a);
+      atomicAdd(&stats->tris, b);
+      atomicAdd(&stats->stat_rays, c);
+    }
+  }
+}
+
+// ---- resolve ----------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_t K, uint32_t first_timestamp,
+                                                     const q4* __restrict__ result, q4* __restrict__ accum) {
+  for (uint32_t lp = blockIdx.x * kBlock + threadIdx.x; lp < num_pixels; lp += gridDim.x * kBlock) {
+    q4 a = accum[lp];
+    for (uint32_t k = 0; k < K; ++k) resolve_sample(first_timestamp + k, result[(uint64_t)k * num_pixels + lp], a);
+    accum[lp] = a;
+  }
+}
+
+// ---- test hook: arbitrary rays ------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_trace_rays(SceneView S, uint32_t n, const float* __restrict__ rays,
+                                                        int any_hit, const uint32_t* __restrict__ slot_to_global,
+                                                        uint32_t num_tris, q4* __restrict__ hits,
+                                                        int32_t* __restrict__ spill, uint32_t spill_stride) {
+  __shared__ int32_t lds_stack[kLdsStack * kBlock];
+  const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+  LaneStack stk;
+  stk.lds = lds_stack + threadIdx.x;
+  stk.spill = spill + gtid;
+  stk.spill_stride = spill_stride;
+  TraceCounters cnt;
+  for (uint32_t i = gtid; i < n; i += gridDim.x * kBlock) {
+    const float* r = rays + 8ull * i;
+    HitRec h;
+    stk.sp = 0;
+    bool hit;
+    if (any_hit)
+      hit = traverse<true, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7],
+                                  stk, h, cnt);
+    else
+      hit = traverse<false, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3],
+                                   r[7], stk, h, cnt);
+    if (num_tris == 0) hit = false;
+    if (any_hit) hits[i] = mkq(0.0f, 0.0f, 0.0f, ub(hit ? 0u : 0xffffffffu));
+    else hits[i] = hit ? mkq(h.t, h.u, h.v, ub(slot_to_global[h.slot])) : mkq(0.0f, 0.0f, 0.0f, ub(0xffffffffu));
+  }
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t count = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+  hipError_t ensure(size_t n, size_t* tally) {
+    if (n <= count && p) return hipSuccess;
+    if (tally && p) *tally -= count * sizeof(T);
+    release();
+    n = n ? n : 1;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e == hipSuccess) {
+      count = n;
+      if (tally) *tally += n * sizeof(T);
+    }
+    return e;
+  }
+  hipError_t upload(const T* src, size_t n, hipStream_t s, size_t* tally) {
+    hipError_t e = ensure(n, tally);
+    if (e != hipSuccess || n == 0 || !src) return e;
+    return hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+};
+
+std::mutex g_err_mutex;
+std::string g_create_error = "";
+
+}  // namespace
+
+}  // namespace gsp
+
+using namespace gsp;
+
+struct gsp_context {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  std::string err;
+  size_t bytes = 0;
+
+  // scene
+  bool have_scene = false;
+  DeviceBvh bvh;
+  DevBuf<InstanceRec> instances;
+  DevBuf<gsp_diffuse_bsdf> b0;
+  DevBuf<gsp_smooth_dielectric_bsdf> b1;
+  DevBuf<gsp_smooth_conductor_bsdf> b2;
+  DevBuf<gsp_smooth_plastic_bsdf> b3;
+  DevBuf<gsp_rough_conductor_bsdf> b4;
+  DevBuf<gsp_smooth_floor_bsdf> b5;
+  DevBuf<gsp_rough_floor_bsdf> b6;
+  DevBuf<gsp_rough_plastic_bsdf> b7;
+  DevBuf<gsp_triangle_light> lights;
+  uint32_t num_lights = 0;
+  gsp_camera camera{};
+  double bvh_build_ms = 0.0;
+
+  // frame
+  bool have_frame = false;
+  uint32_t width = 0, height = 0;
+  uint64_t num_pixels = 0;
+  bool subset = false;
+  DevBuf<uint32_t> pixel_ids;
+  std::vector<uint32_t> pixel_ids_host;
+  DevBuf<q4> accum;
+
+  // pool
+  uint64_t pool_cap = 0;
+  DevBuf<q4> P0[2], P1[2], P2[2], hits, result, S0, S1, S2, S3;
+  DevBuf<uint32_t> FL[2];
+  DevBuf<uint32_t> counters;
+  DevBuf<DevStats> dstats;
+  DevBuf<int32_t> spill;
+  uint32_t spill_stride = 0;
+  uint32_t* h_counters = nullptr;  // pinned
+
+  gsp_stats stats{};
+  std::vector<hipEvent_t> ev;
+
+  SceneView view() const {
+    SceneView v;
+    v.nodes = bvh.nodes;
+    v.tri_isect = bvh.tri_isect;
+    v.tri_shade = bvh.tri_shade;
+    v.instances = instances.p;
+    v.bsdf.diffuse = b0.p;
+    v.bsdf.smooth_dielectric = b1.p;
+    v.bsdf.smooth_conductor = b2.p;
+    v.bsdf.smooth_plastic = b3.p;
+    v.bsdf.rough_conductor = b4.p;
+    v.bsdf.smooth_floor = b5.p;
+    v.bsdf.rough_floor = b6.p;
+    v.bsdf.rough_plastic = b7.p;
+    v.lights = lights.p;
+    v.num_lights = num_lights;
+    v.root = bvh.root;
+    return v;
+  }
+  uint32_t max_blocks() const { return (uint32_t)num_cus * 6u; }
+  uint32_t grid_for(uint64_t n) const {
+    uint64_t b = (n + kBlock - 1) / kBlock;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, max_blocks()));
+  }
+  int ensure_spill() {
+    // one stack level per internal node on the deepest path (+ slack)
+    const uint32_t need = bvh.depth + 2 > (uint32_t)kLdsStack ? bvh.depth + 2 - kLdsStack : 1;
+    spill_stride = max_blocks() * kBlock;
+    GSP_HIP_TRY(spill.ensure((size_t)need * spill_stride, &bytes));
+    return GSP_OK;
+  }
+};
+
+#define CTX_TRY(ctx, expr)                                                                        \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"; \
+      return e_ == hipErrorOutOfMemory ? GSP_ERR_NOMEM : GSP_ERR_DEVICE;                          \
+    }                                                                                             \
+  } while (0)
+
+extern "C" {
+
+void gsp_default_render_params(gsp_render_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->spp = 1;
+  p->first_timestamp = 0;
+  p->max_depth = 50;       // raygen.rgen:27
+  p->rr_start_depth = 10;  // raygen.rgen:66
+  p->clamp = 20.0f;        // raygen.rgen:60
+}
+
+int gsp_abi_version(void) { return GSP_ABI_VERSION; }
+
+int gsp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* gsp_last_error(const gsp_context* ctx) {
+  if (ctx) return ctx->err.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  static thread_local std::string copy;
+  copy = g_create_error;
+  return copy.c_str();
+}
+
+static void set_create_error(const std::string& s) {
+  std::lock_guard<std::mutex> lk(g_err_mutex);
+  g_create_error = s;
+}
+
+int gsp_ctx_create(int device, gsp_context** out) {
+  if (!out) return GSP_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_create_error(std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                     "); this library has no CPU fallback");
+    return GSP_ERR_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_create_error("device index out of range");
+    return GSP_ERR_INVALID;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    set_create_error(std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return GSP_ERR_DEVICE;
+  }
+  gsp_context* c = new gsp_context();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_counters, 64, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    set_create_error(std::string("context setup: ") + hipGetErrorString(e));
+    delete c;
+    return GSP_ERR_DEVICE;
+  }
+  *out = c;
+  return GSP_OK;
+}
+
+void gsp_ctx_destroy(gsp_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+  free_bvh(ctx->bvh);
+  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
+  if (!ctx || !sc) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->have_scene = false;
+  // ---- validate ----
+  uint64_t total_tris = 0;
+  for (uint32_t i = 0; i < sc->num_instances; ++i) {
+    const gsp_instance& in = sc->instances[i];
+    if (in.vertex_count % 3 != 0 || (uint64_t)in.first_vertex + in.vertex_count > sc->num_vertices) {
+      ctx->err = "instance " + std::to_string(i) + ": vertex range outside the position/normal arrays";
+      return GSP_ERR_SCENE;
+    }
+    const uint32_t type = in.bsdf >> 16, idx = in.bsdf & 0xffffu;
+    if (type >= GSP_BSDF_TYPE_COUNT || idx >= sc->num_bsdfs[type]) {
+      ctx->err = "instance " + std::to_string(i) + ": BSDF handle out of range";
+      return GSP_ERR_SCENE;
+    }
+    total_tris += in.vertex_count / 3;
+  }
+  if (total_tris >= (1ull << 29)) {
+    ctx->err = "too many triangles (limit 2^29)";
+    return GSP_ERR_SCENE;
+  }
+  if ((sc->num_instances && !sc->instances) || (sc->num_vertices && (!sc->positions || !sc->normals)) ||
+      (sc->num_lights && !sc->lights)) {
+    ctx->err = "null array with non-zero count";
+    return GSP_ERR_SCENE;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  hipStream_t st = ctx->stream;
+  // ---- PathTracer::prepareScene (PathTracer.cpp:58-93): per-instance table ----
+  std::vector<InstanceRec> recs(sc->num_instances);
+  std::vector<float> inv_t(16ull * sc->num_instances);
+  std::vector<uint32_t> tri_first(sc->num_instances + 1ull);
+  uint32_t acc = 0;
+  for (uint32_t i = 0; i < sc->num_instances; ++i) {
+    const gsp_instance& in = sc->instances[i];
+    float tr[16];
+    transpose4(in.transform, tr);
+    inverse4(tr, &inv_t[16ull * i]);
+    InstanceRec& r = recs[i];
+    std::memset(&r, 0, sizeof(r));
+    r.emission[0] = in.emission[0];
+    r.emission[1] = in.emission[1];
+    r.emission[2] = in.emission[2];
+    r.bsdf = in.bsdf;
+    r.twofaced = in.twofaced;
+    tri_first[i] = acc;
+    acc += in.vertex_count / 3;
+  }
+  tri_first[sc->num_instances] = acc;
+  CTX_TRY(ctx, ctx->instances.upload(recs.data(), recs.size(), st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b0.upload(sc->diffuse_bsdfs, sc->num_bsdfs[0], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b1.upload(sc->smooth_dielectric_bsdfs, sc->num_bsdfs[1], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b2.upload(sc->smooth_conductor_bsdfs, sc->num_bsdfs[2], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b3.upload(sc->smooth_plastic_bsdfs, sc->num_bsdfs[3], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b4.upload(sc->rough_conductor_bsdfs, sc->num_bsdfs[4], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b5.upload(sc->smooth_floor_bsdfs, sc->num_bsdfs[5], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b6.upload(sc->rough_floor_bsdfs, sc->num_bsdfs[6], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->b7.upload(sc->rough_plastic_bsdfs, sc->num_bsdfs[7], st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->lights.upload(sc->lights, sc->num_lights, st, &ctx->bytes));
+  ctx->num_lights = sc->num_lights;
+  ctx->camera = sc->camera;
+
+  // ---- geometry staging + device BVH build ----
+  DevBuf<gsp_instance> d_inst;
+  DevBuf<float> d_invt, d_pos, d_nrm;
+  DevBuf<uint32_t> d_first;
+  CTX_TRY(ctx, d_inst.upload(sc->instances, sc->num_instances, st, nullptr));
+  CTX_TRY(ctx, d_invt.upload(inv_t.data(), inv_t.size(), st, nullptr));
+  CTX_TRY(ctx, d_first.upload(tri_first.data(), tri_first.size(), st, nullptr));
+  CTX_TRY(ctx, d_pos.upload(sc->positions, 3ull * sc->num_vertices, st, nullptr));
+  CTX_TRY(ctx, d_nrm.upload(sc->normals, 3ull * sc->num_vertices, st, nullptr));
+  BuildInput bi;
+  bi.instances = d_inst.p;
+  bi.inv_t = d_invt.p;
+  bi.tri_first = d_first.p;
+  bi.num_instances = sc->num_instances;
+  bi.positions = d_pos.p;
+  bi.normals = d_nrm.p;
+  bi.num_tris = (uint32_t)total_tris;
+  ctx->bytes -= ctx->bvh.bytes;
+  int rc = build_bvh(st, bi, ctx->bvh, ctx->err);
+  if (rc != GSP_OK) return rc;
+  ctx->bytes += ctx->bvh.bytes;
+  CTX_TRY(ctx, hipStreamSynchronize(st));
+  ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  rc = ctx->ensure_spill();
+  if (rc != GSP_OK) return rc;
+  ctx->have_scene = true;
+  return GSP_OK;
+}
+
+int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uint32_t* pixel_ids,
+                    uint64_t num_pixels) {
+  if (!ctx || width == 0 || height == 0) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t frame = (uint64_t)width * height;
+  if (frame >= (1ull << 32)) {
+    ctx->err = "frame too large";
+    return GSP_ERR_INVALID;
+  }
+  ctx->have_frame = false;
+  ctx->subset = pixel_ids != nullptr;
+  if (pixel_ids) {
+    for (uint64_t i = 0; i < num_pixels; ++i) {
+      if (pixel_ids[i] >= frame || (i && pixel_ids[i] <= pixel_ids[i - 1])) {
+        ctx->err = "pixel_ids must be strictly increasing and inside the frame";
+        return GSP_ERR_INVALID;
+      }
+    }
+    ctx->pixel_ids_host.assign(pixel_ids, pixel_ids + num_pixels);
+    CTX_TRY(ctx, ctx->pixel_ids.upload(pixel_ids, num_pixels, ctx->stream, &ctx->bytes));
+  } else {
+    num_pixels = frame;
+    ctx->pixel_ids_host.clear();
+  }
+  ctx->width = width;
+  ctx->height = height;
+  ctx->num_pixels = num_pixels;
+  CTX_TRY(ctx, ctx->accum.ensure(num_pixels, &ctx->bytes));
+  CTX_TRY(ctx, hipMemsetAsync(ctx->accum.p, 0, std::max<uint64_t>(num_pixels, 1) * sizeof(q4), ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_frame = true;
+  return GSP_OK;
+}
+
+static int ensure_pool(gsp_context* ctx, uint64_t cap) {
+  if (cap <= ctx->pool_cap) return GSP_OK;
+  for (int k = 0; k < 2; ++k) {
+    CTX_TRY(ctx, ctx->P0[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, ctx->P1[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, ctx->P2[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, ctx->FL[k].ensure(cap, &ctx->bytes));
+  }
+  CTX_TRY(ctx, ctx->hits.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, ctx->result.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, ctx->S0.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, ctx->S1.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, ctx->S2.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, ctx->S3.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, ctx->counters.ensure(16, &ctx->bytes));
+  if (!ctx->dstats.p) {
+    CTX_TRY(ctx, ctx->dstats.ensure(1, &ctx->bytes));
+    CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
+  }
+  ctx->pool_cap = cap;
+  return GSP_OK;
+}
+
+int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
+  if (!ctx || !rp) return GSP_ERR_INVALID;
+  if (!ctx->have_scene || !ctx->have_frame) {
+    ctx->err = "gsp_render needs gsp_upload_scene and gsp_frame_begin first";
+    return GSP_ERR_INVALID;
+  }
+  if (rp->max_depth > 250) {
+    ctx->err = "max_depth > 250 unsupported";
+    return GSP_ERR_INVALID;
+  }
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  if (rp->spp == 0 || ctx->num_pixels == 0) return GSP_OK;
+  const auto t_begin = std::chrono::steady_clock::now();
+  hipStream_t st = ctx->stream;
+  const uint64_t npix = ctx->num_pixels;
+  // samples traced concurrently: fill ~8M paths so the late, sparse bounces still occupy the chip
+  uint64_t K = rp->timestamps_in_flight;
+  if (K == 0) K = std::max<uint64_t>(1, (8ull << 20) / npix);
+  K = std::min<uint64_t>(K, rp->spp);
+  while (K > 1 && K * npix >= (1ull << 31)) --K;
+  int rc = ensure_pool(ctx, K * npix);
+  if (rc != GSP_OK) return rc;
+
+  RenderConsts rcst;
+  rcst.width = ctx->width;
+  rcst.height = ctx->height;
+  rcst.max_depth = rp->max_depth;
+  rcst.rr_start_depth = rp->rr_start_depth;
+  rcst.clamp = rp->clamp;
+  // raygen.rgen:22, tan() evaluated once on the host
+  rcst.zplane = (std::max((float)ctx->width, (float)ctx->height) / 2.0f) / tanf(ctx->camera.fov / 2.0f);
+  for (int i = 0; i < 16; ++i) rcst.cam_to_world[i] = ctx->camera.to_world[i];
+  rcst.cam_origin[0] = ctx->camera.to_world[12];  // Camera::getPosition, Camera.cpp:41-45
+  rcst.cam_origin[1] = ctx->camera.to_world[13];
+  rcst.cam_origin[2] = ctx->camera.to_world[14];
+
+  const SceneView view = ctx->view();
+  const bool stats_mode = rp->collect_traversal_stats != 0;
+  const bool timing = rp->collect_kernel_times != 0;  // per-kernel HIP event timing (bench)
+  if (timing && ctx->ev.size() < 6) {
+    while (ctx->ev.size() < 6) {
+      hipEvent_t e;
+      CTX_TRY(ctx, hipEventCreate(&e));
+      ctx->ev.push_back(e);
+    }
+  }
+  PathQueue Q[2];
+  for (int k = 0; k < 2; ++k) Q[k] = PathQueue{ctx->P0[k].p, ctx->P1[k].p, ctx->P2[k].p, ctx->FL[k].p};
+  ShadowQueue SQ{ctx->S0.p, ctx->S1.p, ctx->S2.p, ctx->S3.p};
+
+  uint32_t done = 0;
+  while (done < rp->spp) {
+    const uint32_t Kp = (uint32_t)std::min<uint64_t>(K, rp->spp - done);
+    const uint32_t t0 = rp->first_timestamp + done;
+    uint64_t n = (uint64_t)Kp * npix;
+    int cur = 0;
+    hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(n)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, Kp, t0,
+                       ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur], ctx->result.p);
+    for (uint32_t bounce = 0; bounce <= rp->max_depth + 1 && n > 0; ++bounce) {
+      const uint32_t grid = ctx->grid_for(n);
+      CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, C_COUNT * sizeof(uint32_t), st));
+      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+      if (stats_mode)
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, view, (uint32_t)n, Q[cur], ctx->hits.p,
+                           ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
+      else
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, view, (uint32_t)n, Q[cur], ctx->hits.p,
+                           ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
+      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+      hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
+                         Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, ctx->dstats.p);
+      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+      if (stats_mode)
+        hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(kBlock), 0, st, view, rcst.clamp, ctx->counters.p, SQ,
+                           Q[cur ^ 1].P2, ctx->result.p, ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
+      else
+        hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(kBlock), 0, st, view, rcst.clamp, ctx->counters.p, SQ,
+                           Q[cur ^ 1].P2, ctx->result.p, ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
+      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+      CTX_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, C_COUNT * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, st));
+      CTX_TRY(ctx, hipStreamSynchronize(st));
+      CTX_TRY(ctx, hipGetLastError());
+      ctx->stats.extension_rays += n;
+      ctx->stats.shadow_rays += ctx->h_counters[C_SHADOW];
+      if (timing) {
+        float ms = 0.0f;
+        CTX_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->stats.extend_kernel_ms += ms;
+        ctx->stats.extend_launches += 1;
+        CTX_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+        ctx->stats.shade_kernel_ms += ms;
+        CTX_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        ctx->stats.connect_kernel_ms += ms;
+      }
+      n = ctx->h_counters[C_NEXT];
+      cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_resolve, dim3(ctx->grid_for(npix)), dim3(kBlock), 0, st, (uint32_t)npix, Kp, t0,
+                       ctx->result.p, ctx->accum.p);
+    CTX_TRY(ctx, hipGetLastError());
+    done += Kp;
+    ctx->stats.samples += (uint64_t)Kp * npix;
+  }
+  CTX_TRY(ctx, hipStreamSynchronize(st));
+  ctx->stats.render_seconds +=
+      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  return GSP_OK;
+}
+
+int gsp_sync(gsp_context* ctx) {
+  if (!ctx) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GSP_OK;
+}
+
+int gsp_download_compact(gsp_context* ctx, float* out) {
+  if (!ctx || !out || !ctx->have_frame) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  CTX_TRY(ctx, hipMemcpyAsync(out, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GSP_OK;
+}
+
+int gsp_download(gsp_context* ctx, float* out) {
+  if (!ctx || !out || !ctx->have_frame) return GSP_ERR_INVALID;
+  if (!ctx->subset) return gsp_download_compact(ctx, out);
+  std::vector<float> tmp(4ull * ctx->num_pixels);
+  int rc = gsp_download_compact(ctx, tmp.data());
+  if (rc != GSP_OK) return rc;
+  std::memset(out, 0, sizeof(float) * 4ull * ctx->width * ctx->height);
+  for (uint64_t i = 0; i < ctx->num_pixels; ++i)
+    std::memcpy(out + 4ull * ctx->pixel_ids_host[i], tmp.data() + 4ull * i, 4 * sizeof(float));
+  return GSP_OK;
+}
+
+int gsp_copy_accum_to_device(gsp_context* ctx, void* dst, uint64_t bytes) {
+  if (!ctx || !dst || !ctx->have_frame) return GSP_ERR_INVALID;
+  if (bytes < ctx->num_pixels * sizeof(q4)) {
+    ctx->err = "destination too small";
+    return GSP_ERR_INVALID;
+  }
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  CTX_TRY(ctx, hipMemcpyAsync(dst, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToDevice, ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GSP_OK;
+}
+
+int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels) {
+  if (!ctx || !rgba || !ctx->have_frame || num_pixels != ctx->num_pixels) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  CTX_TRY(ctx, hipMemcpyAsync(ctx->accum.p, rgba, num_pixels * sizeof(q4), hipMemcpyHostToDevice, ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GSP_OK;
+}
+
+int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
+  if (!ctx || !out) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->dstats.p) {
+    DevStats d;
+    CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    CTX_TRY(ctx, hipMemcpy(&d, ctx->dstats.p, sizeof(d), hipMemcpyDeviceToHost));
+    ctx->stats.shaded_vertices = d.shaded;
+    ctx->stats.nodes_visited = d.nodes;
+    ctx->stats.tris_tested = d.tris;
+    ctx->stats.stat_rays = d.stat_rays;
+  }
+  ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
+  ctx->stats.num_triangles = ctx->bvh.num_tris;
+  ctx->stats.num_bvh_nodes = ctx->bvh.num_nodes;
+  ctx->stats.device_bytes = ctx->bytes;
+  *out = ctx->stats;
+  return GSP_OK;
+}
+
+int gsp_reset_stats(gsp_context* ctx) {
+  if (!ctx) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->stats = gsp_stats{};
+  if (ctx->dstats.p) {
+    CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
+    CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return GSP_OK;
+}
+
+int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void* hits) {
+  if (!ctx || (!rays && n) || (!hits && n)) return GSP_ERR_INVALID;
+  if (!ctx->have_scene) {
+    ctx->err = "gsp_trace needs gsp_upload_scene first";
+    return GSP_ERR_INVALID;
+  }
+  if (n == 0) return GSP_OK;
+  if (n >= (1ull << 31)) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf<float> d_rays;
+  DevBuf<q4> d_hits;
+  CTX_TRY(ctx, d_rays.upload(rays, 8 * n, ctx->stream, nullptr));
+  CTX_TRY(ctx, d_hits.ensure(n, nullptr));
+  hipLaunchKernelGGL(k_trace_rays, dim3(ctx->grid_for(n)), dim3(kBlock), 0, ctx->stream, ctx->view(), (uint32_t)n,
+                     d_rays.p, any_hit, ctx->bvh.slot_to_global, ctx->bvh.num_tris, d_hits.p, ctx->spill.p,
+                     ctx->spill_stride);
+  CTX_TRY(ctx, hipGetLastError());
+  CTX_TRY(ctx, hipMemcpyAsync(hits, d_hits.p, n * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GSP_OK;
+}
+
+}  // extern "C"

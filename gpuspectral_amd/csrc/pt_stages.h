@@ -1,0 +1,229 @@
+// pt_stages.h -- per-path bodies of the wavefront stages.
+//
+//   generate : raygen.rgen:29-48          camera ray + RNG seed + payload init
+//   shade    : rayhit.rchit:666-797       one shading vertex (closest-hit shader)
+//              raygen.rgen:59-80          firefly clamp, Russian roulette, depth logic
+//   connect  : rayhit.rchit:737-757       shadow-ray verdict -> NEE contribution, MIS weight
+//   resolve  : raygen.rgen:84-108         running-mean accumulate
+//
+// The reference runs these as one recursive shader invocation per pixel; here
+// they are separate passes over ray queues in HBM.  The state a path carries
+// between passes is the reference's HitPayload (pt_common.glsl:4-14).
+//
+// Sample sum order: the reference adds `prd.emitted` (NEE term first, emission
+// term second, rayhit.rchit:752,763-768) to `result` once per bounce behind the
+// firefly test (raygen.rgen:60-63).  The NEE term needs the shadow ray, so the
+// shade pass hands both terms to the connect pass, which forms the same sum.
+#pragma once
+#include "pt_shading.h"
+#include "pt_trace.h"
+
+namespace gsp {
+
+// per-instance shading record (32 B)
+struct InstanceRec {
+  float emission[3];
+  uint32_t bsdf;
+  uint32_t twofaced;
+  uint32_t pad[3];
+};
+
+struct RenderConsts {
+  uint32_t width, height;
+  uint32_t max_depth, rr_start_depth;
+  float clamp;
+  float zplane;        // (max(W,H)/2) / tan(fov/2), raygen.rgen:22 (tan evaluated on the host)
+  float cam_origin[3]; // camera.eye = toWorld[3]
+  float cam_to_world[16];
+};
+
+struct SceneView {
+  const q4* nodes;
+  const q4* tri_isect;  // 3 quads per slot
+  const q4* tri_shade;  // 4 quads per slot: {N, bits(instance)}, {n0}, {n1}, {n2}
+  const InstanceRec* instances;
+  BsdfTables bsdf;
+  const gsp_triangle_light* lights;
+  uint32_t num_lights;
+  int32_t root;
+};
+
+// path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9
+GSP_HD uint32_t pack_flags(uint32_t depth, uint32_t wasDelta, uint32_t countEmitted) {
+  return depth | (wasDelta << 8) | (countEmitted << 9);
+}
+
+struct PathState {
+  f3 o, d;
+  f3 weight;
+  float directWeight;
+  uint32_t seed;
+  uint32_t flags;
+  uint32_t sid;  // sample slot: k * num_pixels + local pixel
+};
+
+struct ShadowRay {
+  f3 o, d;
+  float tmax;     // Ldist - 0.01 (tmin is the literal 0.01)
+  f3 nee;         // contribution if unoccluded
+  f3 emis;        // emission term of the same vertex
+  float dw_nee;   // directWeight of the continuing path if NEE happens
+  uint32_t sid;
+  int32_t next;   // index of the continuing path in the next queue, -1 if the path ended here
+};
+
+// raygen.rgen:20-25,31-48
+GSP_HD void generate_path(const RenderConsts& rc, uint32_t gid, uint32_t timestamp, uint32_t sid, PathState& p) {
+  const uint32_t px = gid % rc.width, py = gid / rc.width;
+  const float x = (float)px - (float)rc.width / 2.0f;
+  const float y = (float)py - (float)rc.height / 2.0f;
+  f3 dl = normalize(mk3(-x, y, rc.zplane));
+  f3 dir = xform_dir(rc.cam_to_world, dl);
+  dir.y = dir.y * -1.0f;
+  p.o = mk3(rc.cam_origin[0], rc.cam_origin[1], rc.cam_origin[2]);
+  p.d = dir;
+  p.weight = splat(1.0f);
+  p.directWeight = 1.0f;
+  p.seed = pcg_hash(tea(rc.width * py + px, timestamp));
+  p.flags = pack_flags(0, 0, 1);
+  p.sid = sid;
+}
+
+// firefly test + add, raygen.rgen:60-63
+GSP_HD void add_emitted(float clampv, f3 e, q4& result) {
+  if (e.x < clampv && e.y < clampv && e.z < clampv) {
+    result.x = result.x + e.x;
+    result.y = result.y + e.y;
+    result.z = result.z + e.z;
+  }
+}
+
+struct ShadeOut {
+  bool alive;        // path continues: `next` is valid
+  PathState next;
+  bool has_shadow;   // a shadow ray must be traced: `shadow` is valid (sid/next filled by the caller)
+  ShadowRay shadow;
+  f3 emitted;        // when !has_shadow: prd.emitted of this bounce (emission term only)
+};
+
+GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathState& in, const HitRec& hit,
+                         ShadeOut& out) {
+  uint32_t rng = in.seed;                                                 // rchit:668
+  const q4* sp = S.tri_shade + 4ll * hit.slot;
+  const q4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+  const InstanceRec inst = S.instances[f2u(s0.w)];                        // :672
+  const f3 emission = mk3(inst.emission[0], inst.emission[1], inst.emission[2]);
+  const f3 rayDir = in.d;                                                 // :696
+  const f3 position = in.o + rayDir * hit.t;                              // :692
+  const float b0 = (1.0f - hit.u) - hit.v;                                // :690
+  f3 SN = normalize((b0 * mk3(s1.x, s1.y, s1.z) + hit.u * mk3(s2.x, s2.y, s2.z)) + hit.v * mk3(s3.x, s3.y, s3.z));
+  f3 N = mk3(s0.x, s0.y, s0.z);                                           // :694 (precomputed at bake)
+  if (dot(N, -rayDir) < 0.0f) {                                           // :698-707
+    if (inst.twofaced == 1 && emission.x == 0.0f && emission.y == 0.0f && emission.z == 0.0f) {
+      N = N * -1.0f;
+      SN = SN * -1.0f;
+    }
+  }
+  const Frame onb = make_frame(SN);                                       // :712
+  const f3 wo = normalize(to_local(onb, -rayDir));                        // :713
+  BsdfResult bs;
+  f3 wi_l;
+  bsdf_sample(S.bsdf, inst.bsdf, rng, wo, wi_l, bs);                      // :716
+  const float NoW = gabs(wi_l.z);                                         // :717
+  const f3 wi = to_world(onb, wi_l);                                      // :718
+
+  const LightSample ls = sample_light(S.lights, S.num_lights, rng, position);  // :720
+  const f3 toL = ls.position - position;
+  const f3 L = normalize(toL);                                            // :722
+  const f3 wL = to_local(onb, L);                                         // :723
+  const float Ldist = length(toL);                                        // :724
+  const float NoL = gabs(dot(SN, L));                                     // :725
+  const float lightPdf = ls.pdf;
+  BsdfResult lb;
+  bsdf_eval(S.bsdf, inst.bsdf, wo, wL, lb);                               // :729
+
+  const bool transmits = bsdf_transmits(inst.bsdf);
+  const float NdotV = dot(N, -rayDir);
+  // :735-736 gate; `lightPdf != 0` (:750) is known before tracing
+  const bool want_shadow = !bs.delta && ((NdotV > 0.0f && dot(N, L) > 0.0f) || transmits) && (lightPdf != 0.0f);
+  f3 nee = splat(0.0f);
+  if (want_shadow) {
+    const float w = power_heuristic(lightPdf, bs.pdf);                    // :751
+    nee = ((((w * NoL) * lb.f) * in.weight) * ls.emission) / lightPdf;    // :752
+  }
+  const uint32_t depth = in.flags & 0xffu;
+  const uint32_t wasDelta = (in.flags >> 8) & 1u;
+  const uint32_t countEmitted = (in.flags >> 9) & 1u;
+  const float lightFlag = NdotV > 0.0f ? 1.0f : 0.0f;                     // :760
+  f3 emis = splat(0.0f);
+  if (countEmitted == 0 && wasDelta == 0) emis = emis + ((in.directWeight * emission) * lightFlag) * in.weight;  // :763-765
+  if (countEmitted == 1 || wasDelta == 1) emis = emis + (emission * lightFlag) * in.weight;                      // :766-768
+
+  bool done = false;
+  if (dot(wi, N) <= 0.0f && !transmits) done = true;                      // :770-773
+  if (NdotV <= 0.0f && !transmits) done = true;                           // :776-779
+  if (!gisvalid(bs.pdf) || !gisvalid(bs.f.x) || !gisvalid(bs.f.y) || !gisvalid(bs.f.z) || bs.pdf == 0.0f)
+    done = true;                                                          // :781-784
+
+  PathState nx = in;
+  nx.seed = rng;                                                          // :759
+  if (!done) {
+    nx.directWeight = 1.0f;                                               // :785-790 (connect overwrites when NEE happens)
+    nx.o = position + 0.0001f * faceforward(N, -wi, N);                   // :793
+    nx.d = wi;                                                            // :794
+    nx.weight = in.weight * ((bs.f * NoW) / bs.pdf);                      // :795
+  }
+  // back in raygen: Russian roulette reads the NEXT vertex's first variate (rgen:59,66-71)
+  bool alive = true;
+  if (depth > rc.rr_start_depth) {
+    const float q = gclamp(gmax(gmax(nx.weight.x, nx.weight.y), nx.weight.z), 0.05f, 1.0f);
+    uint32_t peek = nx.seed;
+    if (rand_uniform(peek) > q) alive = false;
+    nx.weight = nx.weight / q;
+  }
+  if (depth > rc.max_depth) alive = false;                                // rgen:73-75
+  if (done) alive = false;                                                // rgen:77-78
+  nx.flags = pack_flags(depth + 1u, bs.delta ? 1u : 0u, 0u);              // rgen:80, rchit:792,796
+
+  out.alive = alive;
+  out.next = nx;
+  out.has_shadow = want_shadow;
+  out.emitted = emis;                                                     // (0 + nee) + emis with nee absent
+  if (want_shadow) {
+    out.shadow.o = position;                                              // :744 (un-offset origin, tmin 0.01)
+    out.shadow.d = L;
+    out.shadow.tmax = Ldist - 0.01f;                                      // :747
+    out.shadow.nee = nee;
+    out.shadow.emis = emis;
+    out.shadow.dw_nee = power_heuristic(bs.pdf, lightPdf);                // :786
+    out.shadow.sid = in.sid;
+    out.shadow.next = -1;
+  }
+}
+
+// rayhit.rchit:750-754 + raygen.rgen:60-63 for a vertex that traced a shadow ray
+GSP_HD void connect_vertex(float clampv, const ShadowRay& s, bool occluded, q4& result, bool& nee_done) {
+  f3 e = splat(0.0f);
+  if (!occluded) e = e + s.nee;
+  e = e + s.emis;
+  add_emitted(clampv, e, result);
+  nee_done = !occluded;
+}
+
+// raygen.rgen:84-108: fold one finished sample into the running mean
+GSP_HD void resolve_sample(uint32_t timestamp, q4 sample, q4& accum) {
+  f3 c = mk3(sample.x, sample.y, sample.z);
+  if (timestamp > 0) {
+    const float a = 1.0f / (float)(timestamp + 1u);
+    const f3 prev = mk3(accum.x, accum.y, accum.z);
+    c = prev * (1.0f - a) + c * a;  // mix(prev, c, a)
+  }
+  if (!(gisnan(c.x) || gisnan(c.y) || gisnan(c.z))) {
+    accum.x = c.x;
+    accum.y = c.y;
+    accum.z = c.z;
+    accum.w = 1.0f;
+  }
+}
+
+}  // namespace gsp

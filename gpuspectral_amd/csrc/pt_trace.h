@@ -1,0 +1,143 @@
+// pt_trace.h -- BVH node / triangle packet layouts in HBM and the per-ray
+// traversal loop of the extend (closest hit) and connect (any hit) kernels.
+//
+// Replaces the driver's acceleration-structure traversal behind traceRayEXT
+// (S/assets/shaders/raygen.rgen:58, rayhit.rchit:738-748; build call sites
+// S/backend/vulkan/VulkanRays.cpp:6-181).
+//
+// HBM layout (all records are whole float4s so one lane moves 16 B per load):
+//   node  (64 B) : q0 = {lmin.x, lmin.y, lmin.z, lmax.x}
+//                  q1 = {lmax.y, lmax.z, rmin.x, rmin.y}
+//                  q2 = {rmin.z, rmax.x, rmax.y, rmax.z}
+//                  q3 = {bits(left), bits(right), -, -}
+//           child >= 0 : internal node index
+//           child <  0 : leaf, c = ~child, first slot = c >> 2, count = (c & 3) + 1
+//   triangle packet (48 B, in BVH leaf order):
+//                  p0 = {v0.x, v0.y, v0.z, bits(global triangle id)}
+//                  p1 = {e1.x, e1.y, e1.z, -}     e1 = v1 - v0
+//                  p2 = {e2.x, e2.y, e2.z, -}     e2 = v2 - v0
+//   Closest hit = smallest t, ties broken by the smaller global triangle id, so
+//   the result does not depend on the BVH topology or traversal order.
+#pragma once
+#include "pt_math.h"
+
+namespace gsp {
+
+struct q4 {  // 16-byte quad, layout-compatible with float4
+  float x, y, z, w;
+};
+
+struct HitRec {
+  float t, u, v;
+  int32_t slot;  // triangle slot in BVH leaf order; -1 = miss
+};
+
+constexpr int kLeafMaxTris = 4;
+GSP_HD int32_t make_leaf(uint32_t first_slot, uint32_t count) { return ~(int32_t)((first_slot << 2) | (count - 1u)); }
+
+// Moeller-Trumbore on precomputed edges; the operation order is part of the
+// parity contract with the oracle (oracle/oracle_pt.cpp intersectTri).
+GSP_HD bool intersect_tri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tmin, float tmax, float& t, float& u, float& v) {
+  f3 pvec = cross(d, e2);
+  float det = dot(e1, pvec);
+  if (det == 0.0f) return false;
+  float inv = 1.0f / det;
+  f3 tvec = o - v0;
+  u = dot(tvec, pvec) * inv;
+  if (!(u >= 0.0f && u <= 1.0f)) return false;
+  f3 qvec = cross(tvec, e1);
+  v = dot(d, qvec) * inv;
+  if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+  t = dot(e2, qvec) * inv;
+  return t > tmin && t < tmax;
+}
+
+// Slab test.  min/max here are the NaN-dropping IEEE forms, so a NaN from
+// 0*inf (origin on a slab plane, zero direction component) leaves that slab
+// unconstrained: conservative.  The far bound is relaxed by 4 ulp.
+GSP_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+GSP_HD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+GSP_HD bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv, float tmin,
+                 float tmax, float& tnear) {
+  float t0x = (bx0 - o.x) * inv.x, t1x = (bx1 - o.x) * inv.x;
+  float t0y = (by0 - o.y) * inv.y, t1y = (by1 - o.y) * inv.y;
+  float t0z = (bz0 - o.z) * inv.z, t1z = (bz1 - o.z) * inv.z;
+  float lo = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));
+  float hi = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), tmax));
+  tnear = lo;
+  return lo <= hi * 1.0000004f + 1e-30f;
+}
+
+struct TraceCounters {
+  uint32_t nodes, tris;
+};
+
+// One ray against the BVH.  ANY = true: return at the first accepted triangle
+// (TerminateOnFirstHit | SkipClosestHitShader).  `Stack` supplies push/pop/empty.
+template <bool ANY, bool STATS, class Stack>
+GSP_HD bool traverse(const q4* __restrict__ nodes, const q4* __restrict__ tris, int32_t root, f3 o, f3 d, float tmin,
+                     float tmax, Stack& stk, HitRec& hit, TraceCounters& cnt) {
+  hit.t = tmax;
+  hit.u = 0.0f;
+  hit.v = 0.0f;
+  hit.slot = -1;
+  uint32_t best_id = 0xffffffffu;
+  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int32_t cur = root;
+  bool found = false;
+  for (;;) {
+    if (cur >= 0) {
+      const q4* n = nodes + 4ll * cur;
+      const q4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+      if (STATS) cnt.nodes++;
+      float tl, tr;
+      const bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, hit.t, tl);
+      const bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, hit.t, tr);
+      const int32_t cl = (int32_t)f2u(q3.x), cr = (int32_t)f2u(q3.y);
+      if (hl && hr) {
+        const bool left_first = tl <= tr;
+        stk.push(left_first ? cr : cl);
+        cur = left_first ? cl : cr;
+        continue;
+      } else if (hl) {
+        cur = cl;
+        continue;
+      } else if (hr) {
+        cur = cr;
+        continue;
+      }
+    } else {
+      const uint32_t c = (uint32_t)~cur;
+      const uint32_t first = c >> 2, count = (c & 3u) + 1u;
+      for (uint32_t k = 0; k < count; ++k) {
+        const q4* p = tris + 3ll * (first + k);
+        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
+        if (STATS) cnt.tris++;
+        float t, u, v;
+        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, d, tmin, tmax, t, u,
+                          v)) {
+          if (ANY) {
+            hit.t = t;
+            hit.slot = (int32_t)(first + k);
+            found = true;
+            break;
+          }
+          const uint32_t id = f2u(p0.w);
+          if (t < hit.t || (t == hit.t && id < best_id)) {
+            hit.t = t;
+            hit.u = u;
+            hit.v = v;
+            hit.slot = (int32_t)(first + k);
+            best_id = id;
+          }
+        }
+      }
+      if (ANY && found) break;
+    }
+    if (stk.empty()) break;
+    cur = stk.pop();
+  }
+  return hit.slot >= 0;
+}
+
+}  // namespace gsp

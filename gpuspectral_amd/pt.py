@@ -1,0 +1,184 @@
+"""ctypes binding of libgpuspectral_pt.so (the C ABI, include/gpuspectral_pt.h).
+
+No computation happens here and there is no fallback: if the HIP library is
+not built, or no GPU is present, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/gpuspectral_pt.h declares
+EXPORTS = (
+    "gsp_default_render_params",
+    "gsp_abi_version",
+    "gsp_device_count",
+    "gsp_ctx_create",
+    "gsp_ctx_destroy",
+    "gsp_upload_scene",
+    "gsp_frame_begin",
+    "gsp_render",
+    "gsp_sync",
+    "gsp_download",
+    "gsp_download_compact",
+    "gsp_copy_accum_to_device",
+    "gsp_upload_accum",
+    "gsp_get_stats",
+    "gsp_reset_stats",
+    "gsp_trace",
+    "gsp_last_error",
+)
+
+
+class GspError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libgpuspectral_pt.so")
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise GspError(
+            "HIP library %s not found: build it with `make -C gpuspectral_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % path
+        )
+    L = C.CDLL(path)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.gsp_default_render_params.argtypes = [C.POINTER(abi.RenderParams)]
+    L.gsp_default_render_params.restype = None
+    L.gsp_abi_version.restype = C.c_int
+    L.gsp_device_count.restype = C.c_int
+    L.gsp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.gsp_ctx_destroy.argtypes = [vp]
+    L.gsp_ctx_destroy.restype = None
+    L.gsp_upload_scene.argtypes = [vp, C.POINTER(abi.SceneDesc)]
+    L.gsp_frame_begin.argtypes = [vp, u32, u32, vp, u64]
+    L.gsp_render.argtypes = [vp, C.POINTER(abi.RenderParams)]
+    L.gsp_sync.argtypes = [vp]
+    L.gsp_download.argtypes = [vp, vp]
+    L.gsp_download_compact.argtypes = [vp, vp]
+    L.gsp_copy_accum_to_device.argtypes = [vp, vp, u64]
+    L.gsp_upload_accum.argtypes = [vp, vp, u64]
+    L.gsp_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.gsp_reset_stats.argtypes = [vp]
+    L.gsp_trace.argtypes = [vp, vp, u64, C.c_int, vp]
+    L.gsp_last_error.argtypes = [vp]
+    L.gsp_last_error.restype = C.c_char_p
+    if L.gsp_abi_version() != abi.GSP_ABI_VERSION:
+        raise GspError("ABI version mismatch between abi.py and %s" % path)
+    _LIB = L
+    return L
+
+
+def device_count():
+    return load().gsp_device_count()
+
+
+HIT_DT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<i4")])
+
+
+class Context:
+    """One HIP device + stream + scene + accumulate buffer (gsp_context)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.gsp_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise GspError("gsp_ctx_create: %s" % self._L.gsp_last_error(None).decode())
+        self._h = h
+        self._scene = None
+        self.width = self.height = 0
+        self.num_pixels = 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise GspError("%s failed (%d): %s" % (what, rc, self._L.gsp_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload_scene(self, scene):
+        """scene: abi.SceneArrays."""
+        d = scene.desc()
+        self._scene = scene
+        self._check(self._L.gsp_upload_scene(self._h, C.byref(d)), "gsp_upload_scene")
+
+    def frame_begin(self, width, height, pixel_ids=None):
+        if pixel_ids is not None:
+            pixel_ids = np.ascontiguousarray(pixel_ids, np.uint32)
+            rc = self._L.gsp_frame_begin(self._h, width, height, pixel_ids.ctypes.data, len(pixel_ids))
+            self.num_pixels = len(pixel_ids)
+        else:
+            rc = self._L.gsp_frame_begin(self._h, width, height, None, 0)
+            self.num_pixels = width * height
+        self._check(rc, "gsp_frame_begin")
+        self.width, self.height = width, height
+
+    def render(self, spp=1, first_timestamp=0, params=None, **overrides):
+        p = params or abi.default_render_params()
+        p.spp, p.first_timestamp = spp, first_timestamp
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        self._check(self._L.gsp_render(self._h, C.byref(p)), "gsp_render")
+
+    def sync(self):
+        self._check(self._L.gsp_sync(self._h), "gsp_sync")
+
+    def download(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._check(self._L.gsp_download(self._h, out.ctypes.data), "gsp_download")
+        return out
+
+    def download_compact(self):
+        out = np.zeros((self.num_pixels, 4), np.float32)
+        self._check(self._L.gsp_download_compact(self._h, out.ctypes.data), "gsp_download_compact")
+        return out
+
+    def copy_accum_to_device(self, device_ptr, nbytes):
+        self._check(self._L.gsp_copy_accum_to_device(self._h, device_ptr, nbytes), "gsp_copy_accum_to_device")
+
+    def upload_accum(self, rgba):
+        rgba = np.ascontiguousarray(rgba, np.float32).reshape(-1, 4)
+        self._check(self._L.gsp_upload_accum(self._h, rgba.ctypes.data, len(rgba)), "gsp_upload_accum")
+
+    def stats(self):
+        s = abi.Stats()
+        self._check(self._L.gsp_get_stats(self._h, C.byref(s)), "gsp_get_stats")
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(self._L.gsp_reset_stats(self._h), "gsp_reset_stats")
+
+    def trace(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(len(rays), HIT_DT)
+        self._check(self._L.gsp_trace(self._h, rays.ctypes.data, len(rays), 1 if any_hit else 0, hits.ctypes.data),
+                    "gsp_trace")
+        return hits

@@ -183,7 +183,7 @@ typedef struct gsp_render_params {
   float clamp;
   uint32_t timestamps_in_flight; /* samples traced concurrently; 0 = auto */
   uint32_t collect_traversal_stats; /* 1: count BVH nodes / triangles per ray (slower) */
-  uint32_t reserved;
+  uint32_t collect_kernel_times;    /* 1: HIP-event time every extend/shade/connect launch  */
 } gsp_render_params;
 
 typedef struct gsp_stats {

@@ -1,0 +1,161 @@
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CORNELL_XML = os.path.join(GOLDEN, "cornell-box", "scene.xml")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    try:
+        import gpuspectral_amd as g
+
+        return g.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle as orc
+
+    orc.lib()  # builds liboracle_pt.so with gcc if missing
+    return orc
+
+
+@pytest.fixture(scope="session")
+def cornell(oracle_mod):
+    from oracle import mitsuba_loader as ml
+
+    return ml.load_scene(CORNELL_XML)
+
+
+@pytest.fixture(scope="session")
+def materials_scene():
+    from gpuspectral_amd import scenes
+
+    return scenes.cornell_materials(16)
+
+
+class Emu:
+    """ctypes handle on tests/emu/libpt_emu.so: the product's per-path stage headers compiled
+    for the host (a test harness -- see tests/emu/pt_emu.cpp; never a product path)."""
+
+    def __init__(self):
+        from gpuspectral_amd import abi
+
+        d = os.path.join(ROOT, "tests", "emu")
+        so = os.path.join(d, "libpt_emu.so")
+        src = os.path.join(d, "pt_emu.cpp")
+        hdrs = [os.path.join(ROOT, "gpuspectral_amd", "csrc", h) for h in os.listdir(os.path.join(ROOT, "gpuspectral_amd", "csrc")) if h.endswith(".h")]
+        newest = max(os.path.getmtime(p) for p in [src] + hdrs)
+        if not os.path.exists(so) or os.path.getmtime(so) < newest:
+            subprocess.check_call(
+                ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma", "-mavx2", "-shared", "-o", so, src]
+            )
+        L = C.CDLL(so)
+        L.emu_create.restype = C.c_void_p
+        L.emu_create.argtypes = [C.POINTER(abi.SceneDesc)]
+        L.emu_destroy.argtypes = [C.c_void_p]
+        L.emu_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(abi.RenderParams), C.c_void_p]
+        L.emu_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        L.emu_bsdf_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.emu_bsdf_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emu_sample_light.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.emu_det_math.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
+        L.emu_transform_inv_t.argtypes = [C.c_void_p, C.c_void_p]
+        L.emu_seed.restype = C.c_uint32
+        L.emu_seed.argtypes = [C.c_uint32] * 4
+        self.L = L
+        self.abi = abi
+
+    def scene(self, sc):
+        d = sc.desc()
+        h = self.L.emu_create(C.byref(d))
+        return EmuScene(self, h, sc)
+
+
+class EmuScene:
+    def __init__(self, emu, h, sc):
+        self.emu, self.h, self.sc = emu, h, sc
+
+    def render(self, width, height, spp=1, first_timestamp=0, accum=None, pixel_ids=None, params=None):
+        abi = self.emu.abi
+        p = params or abi.default_render_params(spp, first_timestamp)
+        p.spp, p.first_timestamp = spp, first_timestamp
+        n = len(pixel_ids) if pixel_ids is not None else width * height
+        if accum is None:
+            accum = np.zeros((n, 4), np.float32)
+        ids = np.ascontiguousarray(pixel_ids, np.uint32) if pixel_ids is not None else None
+        self.emu.L.emu_render(self.h, width, height, ids.ctypes.data if ids is not None else None, n, C.byref(p), accum.ctypes.data)
+        return accum
+
+    def trace(self, rays, any_hit=False):
+        from oracle.oracle import HIT_DT
+
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(len(rays), HIT_DT)
+        self.emu.L.emu_trace(self.h, rays.ctypes.data, len(rays), 1 if any_hit else 0, hits.ctypes.data)
+        return hits
+
+    def bsdf_sample(self, handle, wo, seed):
+        wo = np.ascontiguousarray(wo, np.float32)
+        out = np.zeros(9, np.float32)
+        self.emu.L.emu_bsdf_sample(self.h, handle, wo.ctypes.data, seed, out.ctypes.data)
+        return out
+
+    def bsdf_eval(self, handle, wo, wi):
+        wo = np.ascontiguousarray(wo, np.float32)
+        wi = np.ascontiguousarray(wi, np.float32)
+        out = np.zeros(5, np.float32)
+        self.emu.L.emu_bsdf_eval(self.h, handle, wo.ctypes.data, wi.ctypes.data, out.ctypes.data)
+        return out
+
+    def sample_light(self, pos, seed):
+        pos = np.ascontiguousarray(pos, np.float32)
+        out = np.zeros(8, np.float32)
+        self.emu.L.emu_sample_light(self.h, pos.ctypes.data, seed, out.ctypes.data)
+        return out
+
+    def __del__(self):
+        try:
+            self.emu.L.emu_destroy(self.h)
+        except Exception:
+            pass
+
+
+@pytest.fixture(scope="session")
+def emu():
+    return Emu()
+
+
+def rmse(a, b):
+    a = np.asarray(a, np.float64).reshape(-1, 4)[:, :3]
+    b = np.asarray(b, np.float64).reshape(-1, 4)[:, :3]
+    return float(np.sqrt(((a - b) ** 2).mean()))
+
+
+def random_rays(n, seed, lo=(-1.2, -0.2, -1.2), hi=(1.2, 2.2, 7.0)):
+    """n x 8 float32 rays {o, tmin, d, tmax} with origins in a box and random directions."""
+    rng = np.random.RandomState(seed)
+    o = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros((n, 8), np.float32)
+    r[:, 0:3] = o
+    r[:, 3] = 0.0
+    r[:, 4:7] = d
+    r[:, 7] = 1e10
+    return r

@@ -1,0 +1,368 @@
+// tests/emu/pt_emu.cpp -- TEST HARNESS, NOT A PRODUCT PATH.
+//
+// Compiles the product's per-path stage headers (gpuspectral_amd/csrc/pt_*.h,
+// the GSP_HD functions the HIP kernels call) for the host with g++ and drives
+// them path by path, so that `pytest -m "not gpu"` can compare the exact
+// shading / traversal / accumulate code of the kernels with the oracle on a
+// machine without a GPU.  It is built into tests/emu/libpt_emu.so by the tests
+// and is never imported by the gpuspectral_amd package, bench.py's timed path
+// or anything shipped: the product renders on the GPU only.
+//
+// The BVH here is a plain median-split tree written in the device node format;
+// closest-hit results do not depend on the BVH topology (pt_trace.h), so this
+// exercises the same traversal loop the extend/connect kernels instantiate.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "../../gpuspectral_amd/csrc/pt_hostmath.h"
+#include "../../gpuspectral_amd/csrc/pt_stages.h"
+
+using namespace gsp;
+
+namespace {
+
+struct VecStack {
+  int32_t s[256];
+  int sp = 0;
+  void push(int32_t v) { s[sp++] = v; }
+  int32_t pop() { return s[--sp]; }
+  bool empty() const { return sp == 0; }
+};
+
+q4 mkq(float x, float y, float z, float w) {
+  q4 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  r.w = w;
+  return r;
+}
+
+struct Emu {
+  gsp_scene_desc sc;
+  std::vector<gsp_instance> instances;
+  std::vector<float> positions, normals, inv_t;
+  std::vector<gsp_diffuse_bsdf> b0;
+  std::vector<gsp_smooth_dielectric_bsdf> b1;
+  std::vector<gsp_smooth_conductor_bsdf> b2;
+  std::vector<gsp_smooth_plastic_bsdf> b3;
+  std::vector<gsp_rough_conductor_bsdf> b4;
+  std::vector<gsp_smooth_floor_bsdf> b5;
+  std::vector<gsp_rough_floor_bsdf> b6;
+  std::vector<gsp_rough_plastic_bsdf> b7;
+  std::vector<gsp_triangle_light> lights;
+  std::vector<InstanceRec> recs;
+  std::vector<q4> nodes, isect, shade;
+  std::vector<uint32_t> slot_to_global;
+  std::vector<float> lo, hi;  // per slot padded boxes
+  int32_t root = 0;
+  SceneView view;
+
+  void bake() {
+    std::vector<q4> gi, gs;
+    std::vector<float> glo, ghi;
+    uint32_t g = 0;
+    for (uint32_t a = 0; a < sc.num_instances; ++a) {
+      const gsp_instance& I = instances[a];
+      const float* T = &inv_t[16ull * a];
+      for (uint32_t k = 0; k + 3 <= I.vertex_count; k += 3, ++g) {
+        const float* P = &positions[3ull * (I.first_vertex + k)];
+        const float* Nn = &normals[3ull * (I.first_vertex + k)];
+        f3 p0 = xform_point(I.transform, mk3(P[0], P[1], P[2]));
+        f3 p1 = xform_point(I.transform, mk3(P[3], P[4], P[5]));
+        f3 p2 = xform_point(I.transform, mk3(P[6], P[7], P[8]));
+        f3 n0 = xform_dir(T, mk3(Nn[0], Nn[1], Nn[2]));
+        f3 n1 = xform_dir(T, mk3(Nn[3], Nn[4], Nn[5]));
+        f3 n2 = xform_dir(T, mk3(Nn[6], Nn[7], Nn[8]));
+        f3 e1 = p1 - p0, e2 = p2 - p0;
+        f3 N = normalize(cross(e1, e2));
+        gi.push_back(mkq(p0.x, p0.y, p0.z, u2f(g)));
+        gi.push_back(mkq(e1.x, e1.y, e1.z, 0));
+        gi.push_back(mkq(e2.x, e2.y, e2.z, 0));
+        gs.push_back(mkq(N.x, N.y, N.z, u2f(a)));
+        gs.push_back(mkq(n0.x, n0.y, n0.z, 0));
+        gs.push_back(mkq(n1.x, n1.y, n1.z, 0));
+        gs.push_back(mkq(n2.x, n2.y, n2.z, 0));
+        const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
+        for (int c = 0; c < 3; ++c) {
+          float l = std::min(px[c], std::min(qx[c], rx[c])), h = std::max(px[c], std::max(qx[c], rx[c]));
+          float pad = 1e-5f * std::max(std::max(std::fabs(l), std::fabs(h)), 1e-3f) + 1e-6f * (h - l);
+          glo.push_back(l - pad);
+          ghi.push_back(h + pad);
+        }
+      }
+    }
+    const uint32_t n = g;
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    // median split, one triangle per leaf; emits nodes in the device format
+    nodes.clear();
+    struct Rec {
+      int32_t code;
+      float lo[3], hi[3];
+    };
+    std::vector<uint32_t> slots;  // final slot order
+    std::function<Rec(uint32_t, uint32_t)> build = [&](uint32_t first, uint32_t count) -> Rec {
+      Rec r;
+      if (count == 1) {
+        uint32_t slot = (uint32_t)slots.size();
+        slots.push_back(order[first]);
+        r.code = make_leaf(slot, 1);
+        for (int c = 0; c < 3; ++c) {
+          r.lo[c] = glo[3ull * order[first] + c];
+          r.hi[c] = ghi[3ull * order[first] + c];
+        }
+        return r;
+      }
+      float cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
+      for (uint32_t i = first; i < first + count; ++i)
+        for (int c = 0; c < 3; ++c) {
+          float m = 0.5f * (glo[3ull * order[i] + c] + ghi[3ull * order[i] + c]);
+          cl[c] = std::min(cl[c], m);
+          ch[c] = std::max(ch[c], m);
+        }
+      int ax = 0;
+      if (ch[1] - cl[1] > ch[ax] - cl[ax]) ax = 1;
+      if (ch[2] - cl[2] > ch[ax] - cl[ax]) ax = 2;
+      uint32_t mid = first + count / 2;
+      std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                       [&](uint32_t a, uint32_t b) {
+                         return glo[3ull * a + ax] + ghi[3ull * a + ax] < glo[3ull * b + ax] + ghi[3ull * b + ax];
+                       });
+      int32_t me = (int32_t)(nodes.size() / 4);
+      nodes.resize(nodes.size() + 4);
+      Rec L = build(first, mid - first), R = build(mid, first + count - mid);
+      nodes[4ull * me + 0] = mkq(L.lo[0], L.lo[1], L.lo[2], L.hi[0]);
+      nodes[4ull * me + 1] = mkq(L.hi[1], L.hi[2], R.lo[0], R.lo[1]);
+      nodes[4ull * me + 2] = mkq(R.lo[2], R.hi[0], R.hi[1], R.hi[2]);
+      nodes[4ull * me + 3] = mkq(u2f((uint32_t)L.code), u2f((uint32_t)R.code), 0, 0);
+      r.code = me;
+      for (int c = 0; c < 3; ++c) {
+        r.lo[c] = std::min(L.lo[c], R.lo[c]);
+        r.hi[c] = std::max(L.hi[c], R.hi[c]);
+      }
+      return r;
+    };
+    if (n == 0) {
+      isect.assign(3, mkq(0, 0, 0, 0));
+      shade.assign(4, mkq(0, 0, 0, 0));
+      slot_to_global.assign(1, 0);
+      nodes.assign(4, mkq(0, 0, 0, 0));
+      root = make_leaf(0, 1);
+    } else {
+      Rec r = build(0, n);
+      root = r.code;
+      isect.resize(3ull * n);
+      shade.resize(4ull * n);
+      slot_to_global.resize(n);
+      for (uint32_t s = 0; s < n; ++s) {
+        uint32_t gg = slots[s];
+        slot_to_global[s] = gg;
+        for (int k = 0; k < 3; ++k) isect[3ull * s + k] = gi[3ull * gg + k];
+        for (int k = 0; k < 4; ++k) shade[4ull * s + k] = gs[4ull * gg + k];
+      }
+      if (nodes.empty()) nodes.assign(4, mkq(0, 0, 0, 0));
+    }
+    view.nodes = nodes.data();
+    view.tri_isect = isect.data();
+    view.tri_shade = shade.data();
+    view.instances = recs.data();
+    view.bsdf.diffuse = b0.data();
+    view.bsdf.smooth_dielectric = b1.data();
+    view.bsdf.smooth_conductor = b2.data();
+    view.bsdf.smooth_plastic = b3.data();
+    view.bsdf.rough_conductor = b4.data();
+    view.bsdf.smooth_floor = b5.data();
+    view.bsdf.rough_floor = b6.data();
+    view.bsdf.rough_plastic = b7.data();
+    view.lights = lights.data();
+    view.num_lights = sc.num_lights;
+    view.root = root;
+  }
+};
+
+template <class T>
+void copyv(std::vector<T>& d, const T* s, size_t n) {
+  d.assign(s, s + (s ? n : 0));
+}
+
+}  // namespace
+
+extern "C" {
+
+// transformInvT is computed with the product's own host routine (pt_hostmath.h),
+// exactly as gsp_upload_scene does.
+void* emu_create(const gsp_scene_desc* sc) {
+  Emu* e = new Emu();
+  e->sc = *sc;
+  copyv(e->instances, sc->instances, sc->num_instances);
+  copyv(e->positions, sc->positions, 3 * (size_t)sc->num_vertices);
+  copyv(e->normals, sc->normals, 3 * (size_t)sc->num_vertices);
+  copyv(e->b0, sc->diffuse_bsdfs, sc->num_bsdfs[0]);
+  copyv(e->b1, sc->smooth_dielectric_bsdfs, sc->num_bsdfs[1]);
+  copyv(e->b2, sc->smooth_conductor_bsdfs, sc->num_bsdfs[2]);
+  copyv(e->b3, sc->smooth_plastic_bsdfs, sc->num_bsdfs[3]);
+  copyv(e->b4, sc->rough_conductor_bsdfs, sc->num_bsdfs[4]);
+  copyv(e->b5, sc->smooth_floor_bsdfs, sc->num_bsdfs[5]);
+  copyv(e->b6, sc->rough_floor_bsdfs, sc->num_bsdfs[6]);
+  copyv(e->b7, sc->rough_plastic_bsdfs, sc->num_bsdfs[7]);
+  copyv(e->lights, sc->lights, sc->num_lights);
+  e->inv_t.resize(16ull * sc->num_instances);
+  e->recs.resize(sc->num_instances);
+  for (uint32_t i = 0; i < sc->num_instances; ++i) {
+    float tr[16];
+    transpose4(e->instances[i].transform, tr);
+    inverse4(tr, &e->inv_t[16ull * i]);
+    InstanceRec& r = e->recs[i];
+    std::memset(&r, 0, sizeof(r));
+    for (int k = 0; k < 3; ++k) r.emission[k] = e->instances[i].emission[k];
+    r.bsdf = e->instances[i].bsdf;
+    r.twofaced = e->instances[i].twofaced;
+  }
+  e->bake();
+  return e;
+}
+void emu_destroy(void* h) { delete (Emu*)h; }
+
+// same contract as oracle_render / gsp_render + gsp_download_compact
+int emu_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixel_ids, uint64_t num_pixels,
+               const gsp_render_params* rp, float* accum) {
+  Emu* e = (Emu*)h;
+  RenderConsts rc;
+  rc.width = width;
+  rc.height = height;
+  rc.max_depth = rp->max_depth;
+  rc.rr_start_depth = rp->rr_start_depth;
+  rc.clamp = rp->clamp;
+  rc.zplane = (std::max((float)width, (float)height) / 2.0f) / tanf(e->sc.camera.fov / 2.0f);
+  for (int i = 0; i < 16; ++i) rc.cam_to_world[i] = e->sc.camera.to_world[i];
+  for (int i = 0; i < 3; ++i) rc.cam_origin[i] = e->sc.camera.to_world[12 + i];
+  const uint64_t npix = pixel_ids ? num_pixels : (uint64_t)width * height;
+  const SceneView& S = e->view;
+  for (uint64_t lp = 0; lp < npix; ++lp) {
+    const uint32_t gid = pixel_ids ? pixel_ids[lp] : (uint32_t)lp;
+    q4 acc = mkq(accum[4 * lp], accum[4 * lp + 1], accum[4 * lp + 2], accum[4 * lp + 3]);
+    for (uint32_t s = 0; s < rp->spp; ++s) {
+      const uint32_t ts = rp->first_timestamp + s;
+      PathState p;
+      generate_path(rc, gid, ts, 0, p);
+      q4 result = mkq(0, 0, 0, 0);
+      bool alive = true;
+      while (alive) {
+        VecStack stk;
+        HitRec hit;
+        TraceCounters cnt{0, 0};
+        traverse<false, false>(S.nodes, S.tri_isect, S.root, p.o, p.d, 0.0f, 1e10f, stk, hit, cnt);
+        if (hit.slot < 0 || e->sc.num_vertices == 0) break;  // miss
+        ShadeOut out;
+        shade_vertex(S, rc, p, hit, out);
+        if (out.has_shadow) {
+          VecStack st2;
+          HitRec sh;
+          bool occ = traverse<true, false>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f,
+                                           out.shadow.tmax, st2, sh, cnt);
+          bool nee_done;
+          connect_vertex(rc.clamp, out.shadow, occ, result, nee_done);
+          if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;
+        } else {
+          add_emitted(rc.clamp, out.emitted, result);
+        }
+        alive = out.alive;
+        p = out.next;
+      }
+      resolve_sample(ts, result, acc);
+    }
+    accum[4 * lp] = acc.x;
+    accum[4 * lp + 1] = acc.y;
+    accum[4 * lp + 2] = acc.z;
+    accum[4 * lp + 3] = acc.w;
+  }
+  return 0;
+}
+
+int emu_trace(void* h, const float* rays, uint64_t n, int any_hit, void* hits_out) {
+  Emu* e = (Emu*)h;
+  struct HR {
+    float t, u, v;
+    int32_t prim;
+  };
+  HR* out = (HR*)hits_out;
+  const SceneView& S = e->view;
+  const bool empty = e->sc.num_vertices == 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const float* r = rays + 8 * i;
+    VecStack stk;
+    HitRec hh;
+    TraceCounters cnt{0, 0};
+    bool hit;
+    if (any_hit)
+      hit = traverse<true, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7],
+                                  stk, hh, cnt);
+    else
+      hit = traverse<false, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3],
+                                   r[7], stk, hh, cnt);
+    if (empty) hit = false;
+    if (any_hit) out[i] = HR{0, 0, 0, hit ? 0 : -1};
+    else out[i] = hit ? HR{hh.t, hh.u, hh.v, (int32_t)e->slot_to_global[hh.slot]} : HR{0, 0, 0, -1};
+  }
+  return 0;
+}
+
+void emu_bsdf_sample(void* h, uint32_t handle, const float* wo, uint32_t seed, float* out9) {
+  Emu* e = (Emu*)h;
+  uint32_t rng = seed;
+  f3 wi;
+  BsdfResult r;
+  bsdf_sample(e->view.bsdf, handle, rng, mk3(wo[0], wo[1], wo[2]), wi, r);
+  out9[0] = wi.x;
+  out9[1] = wi.y;
+  out9[2] = wi.z;
+  out9[3] = r.f.x;
+  out9[4] = r.f.y;
+  out9[5] = r.f.z;
+  out9[6] = r.pdf;
+  out9[7] = r.delta ? 1.0f : 0.0f;
+  out9[8] = u2f(rng);
+}
+void emu_bsdf_eval(void* h, uint32_t handle, const float* wo, const float* wi, float* out5) {
+  Emu* e = (Emu*)h;
+  BsdfResult r;
+  bsdf_eval(e->view.bsdf, handle, mk3(wo[0], wo[1], wo[2]), mk3(wi[0], wi[1], wi[2]), r);
+  out5[0] = r.f.x;
+  out5[1] = r.f.y;
+  out5[2] = r.f.z;
+  out5[3] = r.pdf;
+  out5[4] = r.delta ? 1.0f : 0.0f;
+}
+void emu_sample_light(void* h, const float* pos, uint32_t seed, float* out8) {
+  Emu* e = (Emu*)h;
+  uint32_t rng = seed;
+  LightSample r = sample_light(e->view.lights, e->view.num_lights, rng, mk3(pos[0], pos[1], pos[2]));
+  out8[0] = r.position.x;
+  out8[1] = r.position.y;
+  out8[2] = r.position.z;
+  out8[3] = r.emission.x;
+  out8[4] = r.emission.y;
+  out8[5] = r.emission.z;
+  out8[6] = r.pdf;
+  out8[7] = u2f(rng);
+}
+void emu_det_math(const float* x, uint64_t n, float* s, float* c, float* lg, float* ex) {
+  for (uint64_t i = 0; i < n; ++i) {
+    det_sincosf(x[i], s[i], c[i]);
+    lg[i] = det_logf(x[i]);
+    ex[i] = det_expf(x[i]);
+  }
+}
+void emu_transform_inv_t(const float* m, float* out) {
+  float tr[16];
+  transpose4(m, tr);
+  inverse4(tr, out);
+}
+uint32_t emu_seed(uint32_t width, uint32_t px, uint32_t py, uint32_t timestamp) {
+  return pcg_hash(tea(width * py + px, timestamp));
+}
+}

@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Arithmetic is float32 end to end; both sides use the same operation order and
+the same deterministic transcendentals, so images are expected to agree bit for
+bit.  The contract (BASELINE.json north_star) is per-pixel RMSE < 1e-3 at equal
+spp; the tests assert that bound and report exactness separately.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_rays, rmse
+
+pytestmark = pytest.mark.gpu
+
+TOL_RMSE = 1e-3  # BASELINE.json: "per-pixel RMSE vs reference < 1e-3"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import gpuspectral_amd as g
+
+    c = g.Context(0)
+    yield c
+    c.close()
+
+
+def primary_rays(orc_scene, W, H):
+    rays = np.zeros((W * H, 8), np.float32)
+    for y in range(H):
+        for x in range(W):
+            r = orc_scene.primary_ray(W, H, x, y)
+            rays[y * W + x, 0:3] = r[0:3]
+            rays[y * W + x, 4:7] = r[3:6]
+    rays[:, 3] = 0.0
+    rays[:, 7] = 1e10
+    return rays
+
+
+@pytest.mark.parametrize("which", ["cornell", "materials"])
+def test_trace_closest_hit_matches_oracle(ctx, oracle_mod, cornell, materials_scene, which):
+    sc = cornell if which == "cornell" else materials_scene
+    o = oracle_mod.Oracle(sc)
+    ctx.upload_scene(sc)
+    rays = np.concatenate([primary_rays(o, 64, 64), random_rays(20000, 3)])
+    got = ctx.trace(rays)
+    ref = o.trace(rays)
+    assert (got["prim"] == ref["prim"]).all(), "hit triangle differs on %d rays" % (got["prim"] != ref["prim"]).sum()
+    hit = ref["prim"] >= 0
+    assert hit.sum() > 1000
+    for k in ("t", "u", "v"):
+        assert (got[k][hit] == ref[k][hit]).all(), k  # same arithmetic -> same bits
+
+
+@pytest.mark.parametrize("which", ["cornell", "materials"])
+def test_trace_any_hit_matches_oracle(ctx, oracle_mod, cornell, materials_scene, which):
+    sc = cornell if which == "cornell" else materials_scene
+    o = oracle_mod.Oracle(sc)
+    ctx.upload_scene(sc)
+    rays = random_rays(20000, 5)
+    rays[:, 3] = 0.01
+    rays[:, 7] = np.random.RandomState(1).uniform(0.05, 3.0, len(rays))
+    got = ctx.trace(rays, any_hit=True)
+    ref = o.trace(rays, any_hit=True)
+    assert (got["prim"] == ref["prim"]).all()
+    assert 0 < (ref["prim"] == 0).sum() < len(rays)
+
+
+def test_render_cornell_config1(ctx, oracle_mod, cornell):
+    """BASELINE config 1 (Cornell 128x128, 1 spp, timestamp 0) on the GPU vs the oracle."""
+    ctx.upload_scene(cornell)
+    ctx.frame_begin(128, 128)
+    ctx.render(spp=1)
+    img = ctx.download().reshape(-1, 4)
+    ref, st = oracle_mod.Oracle(cornell).render(128, 128, spp=1)
+    e = rmse(img, ref)
+    nbad = int((np.abs(img - ref).max(1) > 0).sum())
+    print("cornell 1spp rmse %.3e, %d pixels differ" % (e, nbad))
+    assert e < TOL_RMSE
+    gst = ctx.stats()
+    assert gst["extension_rays"] == st["extension_rays"]
+    assert gst["shaded_vertices"] == st["shaded_vertices"]
+
+
+def test_render_progressive_matches_single_call(ctx, oracle_mod, cornell):
+    """timestamp protocol (PathTracer.cpp:91-92): 3 calls of 1,2,5 spp == one call of 8 spp == oracle."""
+    ctx.upload_scene(cornell)
+    ctx.frame_begin(64, 64)
+    ctx.render(spp=1, first_timestamp=0)
+    ctx.render(spp=2, first_timestamp=1)
+    ctx.render(spp=5, first_timestamp=3, timestamps_in_flight=2)
+    a = ctx.download().copy()
+    ctx.frame_begin(64, 64)
+    ctx.render(spp=8, first_timestamp=0)
+    b = ctx.download()
+    assert np.array_equal(a, b)
+    ref, _ = oracle_mod.Oracle(cornell).render(64, 64, spp=8)
+    assert rmse(b, ref) < TOL_RMSE
+
+
+def test_render_materials_full_bsdf_set(ctx, oracle_mod, materials_scene):
+    """All eight BSDF types + NEE + deep dielectric paths, 16 spp."""
+    ctx.upload_scene(materials_scene)
+    ctx.frame_begin(96, 96)
+    ctx.render(spp=16)
+    img = ctx.download().reshape(-1, 4)
+    ref, st = oracle_mod.Oracle(materials_scene).render(96, 96, spp=16)
+    e = rmse(img, ref)
+    nbad = int((np.abs(img - ref).max(1) > 0).sum())
+    print("materials 16spp rmse %.3e, %d pixels differ" % (e, nbad))
+    assert e < TOL_RMSE
+    assert np.isfinite(img).all()
+
+
+def test_pixel_subset_reproduces_full_frame(ctx, cornell):
+    """Any partition of the frame gives the same pixels (seed = f(pixel, timestamp), raygen.rgen:37)."""
+    from gpuspectral_amd import scenes
+
+    W, H = 96, 64
+    ctx.upload_scene(cornell)
+    ctx.frame_begin(W, H)
+    ctx.render(spp=3)
+    full = ctx.download().reshape(-1, 4)
+    out = np.zeros_like(full)
+    for rank in range(3):
+        ids = scenes.tile_pixel_ids(W, H, rank, 3, tile=16)
+        ctx.frame_begin(W, H, ids)
+        ctx.render(spp=3)
+        out[ids] = ctx.download_compact()
+    assert np.array_equal(out, full)
+
+
+def test_edge_cases(ctx, oracle_mod):
+    """Empty scene, no lights, single triangle, max depth 0."""
+    from gpuspectral_amd import abi, scenes
+
+    empty = abi.SceneArrays()
+    ctx.upload_scene(empty)
+    ctx.frame_begin(16, 16)
+    ctx.render(spp=2)
+    img = ctx.download()
+    assert (img[..., :3] == 0).all()
+    assert (ctx.trace(random_rays(100, 1))["prim"] == -1).all()
+
+    b = scenes.SceneBuilder()
+    m = b.add_mesh(*scenes.rect_mesh())
+    b.add_object(m, scenes.trs((0, 1, 0)), b.diffuse((0.5, 0.5, 0.5)))  # no lights: numLights == 0
+    b.to_world = scenes.rowmajor(scenes._CORNELL["camera"])
+    sc = b.build()
+    ctx.upload_scene(sc)
+    ctx.frame_begin(32, 32)
+    ctx.render(spp=2)
+    img = ctx.download().reshape(-1, 4)
+    ref, _ = oracle_mod.Oracle(sc).render(32, 32, spp=2)
+    assert np.array_equal(img, ref)
+
+    cm = scenes.cornell_materials(8)
+    ctx.upload_scene(cm)
+    ctx.frame_begin(48, 48)
+    ctx.render(spp=2, max_depth=0, rr_start_depth=0)
+    p = abi.default_render_params()
+    p.max_depth, p.rr_start_depth = 0, 0
+    ref, _ = oracle_mod.Oracle(cm).render(48, 48, spp=2, params=p)
+    assert rmse(ctx.download(), ref) < TOL_RMSE
