@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X path-tracing integrator.
+
+Metric (BASELINE.json): Mrays/s (+ Msamples/s) on a ~1M-triangle Mitsuba-style
+scene at 1920x1080, on 1/2/4/8 MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+* One "step" = `--spp-per-step` samples per pixel over the whole 1920x1080
+  frame of the generated bathroom2 stand-in (gpuspectral_amd.scenes.interior,
+  ~1M triangles, seeded).  Throughput is linear in spp, so K steps of S spp is
+  a K*S-spp slice of the 4096-spp target render; the timestamps continue across
+  steps exactly as in one long render.
+* N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is
+  partitioned by interleaved 32x32 tiles, every rank holds the whole scene+BVH,
+  renders its own pixels and, after the K steps, ONE RCCL gather brings the HDR
+  tiles to rank 0 (inside the timed region).  Total work is fixed -> "strong".
+* Timed region: barrier + device sync on both sides, max over ranks.
+* Scene upload and BVH build are outside the timed region (reported separately).
+
+Rank 0 prints ONE JSON line.  `roofline` is the extend (BVH traversal) kernel:
+algorithmic bytes moved per second (formula in DESIGN.md) against the 8 TB/s
+HBM3E peak, with the kernel's time measured by HIP events on the tracer's own
+stream.  `cpu_baseline` times the scalar CPU oracle on this box's host cores on
+a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--scene", default="interior", choices=["interior", "materials", "caustics", "cornell"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--dump", default="", help="write the gathered frame as .npy (rank 0)")
+    return ap.parse_args()
+
+
+def make_scene(args):
+    from gpuspectral_amd import scenes
+
+    if args.scene == "interior":
+        return scenes.interior(args.tris, seed=7), "bathroom2 stand-in: scenes.interior(target_tris=%d, seed=7)" % args.tris
+    if args.scene == "materials":
+        return scenes.cornell_materials(96), "Cornell + full BSDF set: scenes.cornell_materials(96)"
+    if args.scene == "caustics":
+        return scenes.caustics(args.tris, seed=11), "dielectric caustics: scenes.caustics(%d, seed=11)" % args.tris
+    from oracle import mitsuba_loader as ml  # tiny fixture scene only
+
+    return ml.load_scene(os.path.join(ROOT, "tests", "golden", "cornell-box", "scene.xml")), "Cornell box (reference scene.xml)"
+
+
+def cpu_baseline(sc, args, scene_name):
+    """Scalar CPU oracle on a bounded, image-spread sample of the same workload."""
+    from gpuspectral_amd import scenes
+    from oracle import oracle as orc
+
+    threads = os.cpu_count() or 1
+    o = orc.Oracle(sc)
+    W, H = args.width, args.height
+    # probe 1/64 of the frame at 1 spp to size the sample for ~cpu_seconds
+    ids = scenes.tile_pixel_ids(W, H, 0, 64, tile=16)
+    _, st = o.render(W, H, spp=1, pixel_ids=ids, threads=threads)
+    rate = (st["extension_rays"] + st["shadow_rays"]) / max(st["seconds"], 1e-9)
+    per_px = (st["extension_rays"] + st["shadow_rays"]) / max(len(ids), 1)
+    want_px = int(min(W * H, max(len(ids), args.cpu_seconds * rate / max(per_px, 1e-9))))
+    parts = max(1, int(round(W * H / want_px)))
+    ids = scenes.tile_pixel_ids(W, H, 0, parts, tile=16)
+    _, st = o.render(W, H, spp=1, pixel_ids=ids, threads=threads)
+    rays = st["extension_rays"] + st["shadow_rays"]
+    return {
+        "value": rays / st["seconds"] / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "msamples_per_s": st["samples"] / st["seconds"] / 1e6,
+        "sample": "%s, %dx%d, 1 spp on %d pixels (every %d-th 16x16 tile), %.1f s, scalar C++ oracle with %d std::threads; BVH build %.2f s excluded"
+        % (scene_name, W, H, len(ids), parts, st["seconds"], threads, o.build_seconds),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import scenes
+
+    sc, scene_name = make_scene(args)
+    W, H = args.width, args.height
+    ids = scenes.tile_pixel_ids(W, H, rank, world, tile=32) if world > 1 else None
+
+    ctx = g.Context(local_rank)
+    t0 = time.time()
+    ctx.upload_scene(sc)
+    upload_s = time.time() - t0
+    ctx.frame_begin(W, H, ids)
+    npix_local = ctx.num_pixels
+    S = args.spp_per_step
+
+    def barrier():
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    ts = 0
+    for _ in range(args.warmup):
+        ctx.render(spp=S, first_timestamp=ts)
+        ts += S
+    # untimed statistics pass: BVH node / triangle reads per extension ray (for the roofline)
+    ctx.reset_stats()
+    ctx.render(spp=1, first_timestamp=ts, collect_traversal_stats=1)
+    ts += 1
+    st = ctx.stats()
+    nodes_per_ray = st["nodes_visited"] / max(1, st["stat_rays"])
+    tris_per_ray = st["tris_tested"] / max(1, st["stat_rays"])
+    ctx.reset_stats()
+
+    gather_buf = gather_list = None
+    if dist is not None:
+        counts = [len(scenes.tile_pixel_ids(W, H, r, world, tile=32)) for r in range(world)]
+        maxn = max(counts)
+        gather_buf = torch.zeros((maxn, 4), dtype=torch.float32, device="cuda")
+        if rank == 0:
+            gather_list = [torch.empty_like(gather_buf) for _ in range(world)]
+
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.render(spp=S, first_timestamp=ts, collect_kernel_times=1)
+        ts += S
+    frame = None
+    if dist is not None:
+        # the single collective of the job: HDR tiles -> rank 0 over xGMI
+        ctx.copy_accum_to_device(gather_buf.data_ptr(), npix_local * 16)
+        dist.gather(gather_buf, gather_list, dst=0)
+        if rank == 0:
+            frame = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
+            for r in range(world):
+                rid = torch.from_numpy(scenes.tile_pixel_ids(W, H, r, world, tile=32).astype(np.int64)).cuda()
+                frame[rid] = gather_list[r][: counts[r]]
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+
+    st = ctx.stats()
+    local = np.array(
+        [elapsed, st["extension_rays"], st["shadow_rays"], st["samples"], st["extend_kernel_ms"], st["extend_launches"],
+         st["shade_kernel_ms"], st["connect_kernel_ms"], st["shaded_vertices"]],
+        np.float64,
+    )
+    if dist is not None:
+        t = torch.from_numpy(local).cuda()
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        tot = tsum.cpu().numpy()
+    else:
+        tot = local
+    if rank == 0 and args.dump:
+        if frame is not None:
+            np.save(args.dump, frame.cpu().numpy().reshape(H, W, 4))
+        else:
+            np.save(args.dump, ctx.download())
+
+    if rank == 0:
+        ext_rays, sh_rays, samples = tot[1], tot[2], tot[3]
+        rays = ext_rays + sh_rays
+        # extend-kernel roofline (rank 0's launches): algorithmic bytes / HIP-event time
+        b_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray
+        ext_ms = st["extend_kernel_ms"]
+        launches = max(1, st["extend_launches"])
+        alg_bytes = st["extension_rays"] * b_ray
+        achieved = alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        traffic = None
+        pm = os.path.join(ROOT, "profiles", "pmc_extend_latest.json")
+        if os.path.exists(pm):
+            try:
+                traffic = json.load(open(pm)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (extension + shadow rays), ~1M-tri Mitsuba-style scene at 1080p",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "msamples_per_s": samples / elapsed / 1e6,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": scene_name,
+                "triangles": int(st["num_triangles"]),
+                "resolution": "%dx%d" % (W, H),
+                "spp_per_step": S,
+                "spp_timed": S * args.steps,
+                "target_spp": 4096,
+                "max_depth": 50,
+                "parallelism": "tile%d" % world if world > 1 else "single",
+                "extension_rays": int(ext_rays),
+                "shadow_rays": int(sh_rays),
+                "bvh_build_ms": st["bvh_build_ms"],
+                "scene_upload_ms": upload_s * 1e3,
+            },
+            "roofline": {
+                "kernel": "k_extend (BVH2 closest-hit traversal)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_ray": b_ray,
+                "nodes_per_ray": nodes_per_ray,
+                "tris_per_ray": tris_per_ray,
+                "launches": int(launches),
+                "avg_launch_ms": ext_ms / launches,
+                "algorithmic_bytes_per_launch": alg_bytes / launches,
+                "extend_ms": ext_ms,
+                "shade_ms": st["shade_kernel_ms"],
+                "connect_ms": st["connect_kernel_ms"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, args, scene_name)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

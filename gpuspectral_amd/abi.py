@@ -139,6 +139,9 @@ class Stats(C.Structure):
         ("nodes_visited", C.c_uint64),
         ("tris_tested", C.c_uint64),
         ("stat_rays", C.c_uint64),
+        ("shadow_nodes_visited", C.c_uint64),
+        ("shadow_tris_tested", C.c_uint64),
+        ("shadow_stat_rays", C.c_uint64),
         ("render_seconds", C.c_double),
         ("extend_kernel_ms", C.c_double),
         ("extend_launches", C.c_uint64),

@@ -54,7 +54,7 @@ struct ShadowQueue {
 // device counters
 enum { C_NEXT = 0, C_SHADOW = 1, C_COUNT = 2 };
 struct DevStats {
-  unsigned long long shaded, nodes, tris, stat_rays;
+  unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays;
 };
 
 // ---- per-lane traversal stack: LDS first, HBM spill behind it -----------------
@@ -257,9 +257,9 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView S, float clampv, c
   if (STATS) {
     unsigned long long a = wave_sum(cnt.nodes), b = wave_sum(cnt.tris), c = wave_sum(rays);
     if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&stats->nodes, a);
-      atomicAdd(&stats->tris, b);
-      atomicAdd(&stats->stat_rays, c);
+      atomicAdd(&stats->sh_nodes, a);
+      atomicAdd(&stats->sh_tris, b);
+      atomicAdd(&stats->sh_rays, c);
     }
   }
 }
@@ -825,6 +825,9 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
     ctx->stats.nodes_visited = d.nodes;
     ctx->stats.tris_tested = d.tris;
     ctx->stats.stat_rays = d.stat_rays;
+    ctx->stats.shadow_nodes_visited = d.sh_nodes;
+    ctx->stats.shadow_tris_tested = d.sh_tris;
+    ctx->stats.shadow_stat_rays = d.sh_rays;
   }
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
   ctx->stats.num_triangles = ctx->bvh.num_tris;

@@ -191,9 +191,12 @@ typedef struct gsp_stats {
   uint64_t shadow_rays;
   uint64_t shaded_vertices;
   uint64_t samples;          /* pixels * spp completed                           */
-  uint64_t nodes_visited;    /* BVH nodes popped, both ray kinds (stats mode)    */
-  uint64_t tris_tested;      /* triangle tests, both ray kinds (stats mode)      */
-  uint64_t stat_rays;        /* rays over which the two counters above were taken*/
+  uint64_t nodes_visited;    /* extension rays: BVH node records read (stats mode) */
+  uint64_t tris_tested;      /* extension rays: triangle packets read (stats mode) */
+  uint64_t stat_rays;        /* extension rays the two counters above cover        */
+  uint64_t shadow_nodes_visited; /* same three for shadow rays                     */
+  uint64_t shadow_tris_tested;
+  uint64_t shadow_stat_rays;
   double render_seconds;     /* host wall time inside gsp_render.. sync          */
   double extend_kernel_ms;   /* sum of HIP-event durations of the extend kernel  */
   uint64_t extend_launches;
