@@ -115,11 +115,11 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     import gpuspectral_amd as g
-    from gpuspectral_amd import scenes
+    from gpuspectral_amd import multigpu, scenes  # noqa: F401
 
     sc, scene_name = make_scene(args)
     W, H = args.width, args.height
-    ids = scenes.tile_pixel_ids(W, H, rank, world, tile=32) if world > 1 else None
+    ids = multigpu.partition(W, H, rank, world)
 
     ctx = g.Context(local_rank)
     t0 = time.time()
@@ -149,13 +149,9 @@ def main():
     tris_per_ray = st["tris_tested"] / max(1, st["stat_rays"])
     ctx.reset_stats()
 
-    gather_buf = gather_list = None
+    local_t = None
     if dist is not None:
-        counts = [len(scenes.tile_pixel_ids(W, H, r, world, tile=32)) for r in range(world)]
-        maxn = max(counts)
-        gather_buf = torch.zeros((maxn, 4), dtype=torch.float32, device="cuda")
-        if rank == 0:
-            gather_list = [torch.empty_like(gather_buf) for _ in range(world)]
+        local_t = torch.zeros((npix_local, 4), dtype=torch.float32, device="cuda")
 
     barrier()
     t_begin = time.perf_counter()
@@ -165,13 +161,8 @@ def main():
     frame = None
     if dist is not None:
         # the single collective of the job: HDR tiles -> rank 0 over xGMI
-        ctx.copy_accum_to_device(gather_buf.data_ptr(), npix_local * 16)
-        dist.gather(gather_buf, gather_list, dst=0)
-        if rank == 0:
-            frame = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
-            for r in range(world):
-                rid = torch.from_numpy(scenes.tile_pixel_ids(W, H, r, world, tile=32).astype(np.int64)).cuda()
-                frame[rid] = gather_list[r][: counts[r]]
+        ctx.copy_accum_to_device(local_t.data_ptr(), npix_local * 16)
+        frame = multigpu.gather_frame(local_t, W, H, rank, world, dist)
     barrier()
     elapsed = time.perf_counter() - t_begin
 

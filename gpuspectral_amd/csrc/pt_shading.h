@@ -276,7 +276,9 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       float cosTho = wo.z;
       r.delta = true;
       // refractRay (:290-299) against n = faceforward(+z, -wo, +z)
-      float nz = (-wo.z < 0.0f) ? 1.0f : -1.0f;
+      // (GLSL's -N negates every component: the flipped normal is (-0, -0, -1), which decides
+      // the sign of zero components of wt)
+      const bool keep = -wo.z < 0.0f;
       float sinTho = gsqrt(gmax(wo.x * wo.x + wo.y * wo.y, 0.0f));
       float sqrtTerm = 1.0f - ((no * no) / (nt * nt)) * (sinTho * sinTho);
       if (sqrtTerm <= 0.0f) {  // total internal reflection
@@ -286,7 +288,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
         break;
       }
       float cosTht = gsqrt(sqrtTerm);
-      f3 n = mk3(0.0f, 0.0f, nz);
+      f3 n = keep ? mk3(0.0f, 0.0f, 1.0f) : mk3(-0.0f, -0.0f, -1.0f);
       f3 wt = (no / nt) * (-wo) + ((no / nt) * dot(wo, n) - cosTht) * n;
       float Fr = fresnel_polarized(no, gabs(cosTho), nt, gabs(wt.z));
       float u = rand_uniform(rng);

@@ -14,8 +14,8 @@
 //           child <  0 : leaf, c = ~child, first slot = c >> 2, count = (c & 3) + 1
 //   triangle packet (48 B, in BVH leaf order):
 //                  p0 = {v0.x, v0.y, v0.z, bits(global triangle id)}
-//                  p1 = {e1.x, e1.y, e1.z, -}     e1 = v1 - v0
-//                  p2 = {e2.x, e2.y, e2.z, -}     e2 = v2 - v0
+//                  p1 = {v1.x, v1.y, v1.z, -}
+//                  p2 = {v2.x, v2.y, v2.z, -}
 //   Closest hit = smallest t, ties broken by the smaller global triangle id, so
 //   the result does not depend on the BVH topology or traversal order.
 #pragma once
@@ -35,20 +35,60 @@ struct HitRec {
 constexpr int kLeafMaxTris = 4;
 GSP_HD int32_t make_leaf(uint32_t first_slot, uint32_t count) { return ~(int32_t)((first_slot << 2) | (count - 1u)); }
 
-// Moeller-Trumbore on precomputed edges; the operation order is part of the
-// parity contract with the oracle (oracle/oracle_pt.cpp intersectTri).
-GSP_HD bool intersect_tri(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float tmin, float tmax, float& t, float& u, float& v) {
-  f3 pvec = cross(d, e2);
-  float det = dot(e1, pvec);
+// Watertight ray/triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle
+// Intersection", JCGT 2013), no back-face culling: the ray is sheared so that it
+// runs along +z of a permuted frame; the three 2D edge functions of a shared edge
+// are exact negations of each other in the two triangles that share it, so a ray
+// can never slip between them (hardware traversal behind traceRayEXT is watertight
+// too).  Zero edge values are re-evaluated in double.  The operation order is part
+// of the parity contract with the oracle (oracle/oracle_pt.cpp intersectTri).
+struct RayShear {
+  int kx, ky, kz;
+  float Sx, Sy, Sz;
+};
+GSP_HD float comp(f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+GSP_HD RayShear make_shear(f3 d) {
+  RayShear r;
+  const float ax = gabs(d.x), ay = gabs(d.y), az = gabs(d.z);
+  r.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+  r.kx = r.kz == 2 ? 0 : r.kz + 1;
+  r.ky = r.kx == 2 ? 0 : r.kx + 1;
+  const float dz = comp(d, r.kz);
+  if (dz < 0.0f) {
+    const int t = r.kx;
+    r.kx = r.ky;
+    r.ky = t;
+  }
+  r.Sx = comp(d, r.kx) / dz;
+  r.Sy = comp(d, r.ky) / dz;
+  r.Sz = 1.0f / dz;
+  return r;
+}
+// u, v = barycentric weights of v1 and v2 (hitAttributeEXT attribs.xy, rayhit.rchit:690)
+GSP_HD bool intersect_tri(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float tmin, float tmax, float& t, float& u,
+                          float& v) {
+  const f3 A = v0 - o, B = v1 - o, C = v2 - o;
+  const float Akz = comp(A, rs.kz), Bkz = comp(B, rs.kz), Ckz = comp(C, rs.kz);
+  const float Ax = comp(A, rs.kx) - rs.Sx * Akz, Ay = comp(A, rs.ky) - rs.Sy * Akz;
+  const float Bx = comp(B, rs.kx) - rs.Sx * Bkz, By = comp(B, rs.ky) - rs.Sy * Bkz;
+  const float Cx = comp(C, rs.kx) - rs.Sx * Ckz, Cy = comp(C, rs.ky) - rs.Sy * Ckz;
+  float U = Cx * By - Cy * Bx;
+  float V = Ax * Cy - Ay * Cx;
+  float W = Bx * Ay - By * Ax;
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  const float det = (U + V) + W;
   if (det == 0.0f) return false;
-  float inv = 1.0f / det;
-  f3 tvec = o - v0;
-  u = dot(tvec, pvec) * inv;
-  if (!(u >= 0.0f && u <= 1.0f)) return false;
-  f3 qvec = cross(tvec, e1);
-  v = dot(d, qvec) * inv;
-  if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-  t = dot(e2, qvec) * inv;
+  const float Az = rs.Sz * Akz, Bz = rs.Sz * Bkz, Cz = rs.Sz * Ckz;
+  const float T = (U * Az + V * Bz) + W * Cz;
+  const float rcp = 1.0f / det;
+  t = T * rcp;
+  u = V * rcp;
+  v = W * rcp;
   return t > tmin && t < tmax;
 }
 
@@ -83,6 +123,7 @@ GSP_HD bool traverse(const q4* __restrict__ nodes, const q4* __restrict__ tris, 
   hit.slot = -1;
   uint32_t best_id = 0xffffffffu;
   const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const RayShear rs = make_shear(d);
   int32_t cur = root;
   bool found = false;
   for (;;) {
@@ -114,7 +155,7 @@ GSP_HD bool traverse(const q4* __restrict__ nodes, const q4* __restrict__ tris, 
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
         if (STATS) cnt.tris++;
         float t, u, v;
-        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, d, tmin, tmax, t, u,
+        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u,
                           v)) {
           if (ANY) {
             hit.t = t;

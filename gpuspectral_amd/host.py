@@ -1,0 +1,175 @@
+"""ctypes binding of libgpuspectral_host.so: the C++ host layer (Scene, loadScene, PathTracer).
+
+The classes here only forward to the C++ objects a C++ caller would use
+(gpuspectral_amd/host/*.h); see those headers for the reference citations.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .pt import GspError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libgpuspectral_host.so")
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise GspError("host library %s not found: build it with `make -C gpuspectral_amd/host`" % path)
+    L = C.CDLL(path)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.gsph_last_error.restype = C.c_char_p
+    L.gsph_load_scene.restype = vp
+    L.gsph_load_scene.argtypes = [C.c_char_p, C.c_char_p]
+    L.gsph_scene_free.argtypes = [vp]
+    L.gsph_scene_free.restype = None
+    L.gsph_scene_desc.restype = C.POINTER(abi.SceneDesc)
+    L.gsph_scene_desc.argtypes = [vp]
+    L.gsph_scene_num_warnings.restype = u32
+    L.gsph_scene_num_warnings.argtypes = [vp]
+    L.gsph_scene_warning.restype = C.c_char_p
+    L.gsph_scene_warning.argtypes = [vp, u32]
+    L.gsph_scene_num_materials.restype = u32
+    L.gsph_scene_num_materials.argtypes = [vp]
+    L.gsph_pathtracer_create.restype = vp
+    L.gsph_pathtracer_create.argtypes = [u32, u32, C.c_int, vp, u64]
+    L.gsph_pathtracer_free.argtypes = [vp]
+    L.gsph_pathtracer_free.restype = None
+    L.gsph_pathtracer_create_render_pass.argtypes = [vp, vp]
+    L.gsph_pathtracer_render.argtypes = [vp, vp, u32]
+    L.gsph_pathtracer_set_params.argtypes = [vp, C.POINTER(abi.RenderParams)]
+    L.gsph_pathtracer_timestamp.argtypes = [vp]
+    L.gsph_pathtracer_reset.argtypes = [vp]
+    L.gsph_pathtracer_download.argtypes = [vp, vp, u64]
+    L.gsph_pathtracer_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.gsph_write_pfm.argtypes = [C.c_char_p, vp, u32, u32]
+    _LIB = L
+    return L
+
+
+def _err(L):
+    return L.gsph_last_error().decode(errors="replace")
+
+
+def _view(ptr, count, dtype):
+    if not ptr or count == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+class Scene:
+    """A C++ GPUSpectral::Scene produced by loadScene (S/engine/Loader.cpp:253-349)."""
+
+    def __init__(self, path, asset_dir=None):
+        self._L = load()
+        self._h = self._L.gsph_load_scene(path.encode(), asset_dir.encode() if asset_dir else None)
+        if not self._h:
+            raise GspError("loadScene(%s): %s" % (path, _err(self._L)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsph_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def warnings(self):
+        return [self._L.gsph_scene_warning(self._h, i).decode() for i in range(self._L.gsph_scene_num_warnings(self._h))]
+
+    @property
+    def num_materials(self):
+        return self._L.gsph_scene_num_materials(self._h)
+
+    def arrays(self):
+        """Copy of the flattened scene (what crosses the C ABI) as abi.SceneArrays."""
+        d = self._L.gsph_scene_desc(self._h).contents
+        sc = abi.SceneArrays()
+        sc.instances = _view(d.instances, d.num_instances, abi.INSTANCE_DT)
+        sc.positions = _view(d.positions, d.num_vertices * 3, np.float32).reshape(-1, 3)
+        sc.normals = _view(d.normals, d.num_vertices * 3, np.float32).reshape(-1, 3)
+        sc.bsdfs = [
+            _view(getattr(d, name + "_bsdfs"), d.num_bsdfs[i], dt)
+            for i, (name, dt) in enumerate(zip(abi.BSDF_NAMES, abi.BSDF_DTYPES))
+        ]
+        sc.lights = _view(d.lights, d.num_lights, abi.LIGHT_DT)
+        sc.to_world = np.array(list(d.camera.to_world), np.float32)
+        sc.fov = np.float32(d.camera.fov)
+        return sc
+
+
+class PathTracer:
+    """C++ GPUSpectral::PathTracer (drop-in for S/renderer/PathTracer.h:48-68)."""
+
+    def __init__(self, width, height, device=0, pixel_ids=None):
+        self._L = load()
+        ids = np.ascontiguousarray(pixel_ids, np.uint32) if pixel_ids is not None else None
+        self._h = self._L.gsph_pathtracer_create(width, height, device, ids.ctypes.data if ids is not None else None,
+                                                 len(ids) if ids is not None else 0)
+        if not self._h:
+            raise GspError("PathTracer(): %s" % _err(self._L))
+        self.width, self.height = width, height
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise GspError("%s: %s" % (what, _err(self._L)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsph_pathtracer_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def create_render_pass(self, scene):
+        self._check(self._L.gsph_pathtracer_create_render_pass(self._h, scene._h), "createRenderPass")
+
+    def render(self, scene, spp):
+        self._check(self._L.gsph_pathtracer_render(self._h, scene._h, spp), "render")
+
+    def set_params(self, params):
+        self._check(self._L.gsph_pathtracer_set_params(self._h, C.byref(params)), "set_params")
+
+    @property
+    def timestamp(self):
+        return self._L.gsph_pathtracer_timestamp(self._h)
+
+    def reset(self):
+        self._check(self._L.gsph_pathtracer_reset(self._h), "reset")
+
+    def download(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._check(self._L.gsph_pathtracer_download(self._h, out.ctypes.data, out.size), "download")
+        return out
+
+    def stats(self):
+        s = abi.Stats()
+        self._check(self._L.gsph_pathtracer_stats(self._h, C.byref(s)), "stats")
+        return s.as_dict()
+
+
+def write_pfm(path, rgba):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[0], rgba.shape[1]
+    L = load()
+    if L.gsph_write_pfm(path.encode(), rgba.ctypes.data, w, h) != 0:
+        raise GspError("write_pfm: %s" % _err(L))

@@ -1,0 +1,664 @@
+// Loader.cpp -- Mitsuba 0.5 XML + Wavefront OBJ -> Scene.
+//
+// Behaviour follows the reference loader S/engine/Loader.cpp:
+//   loadMesh        :19-64    de-index pos/normal/uv, concatenate all shapes
+//   loadMaterial    :145-234  twosided / diffuse / roughplastic / dielectric /
+//                             conductor / plastic / roughconductor, recursing into child bsdfs
+//   loadScene       :253-349  shapes (obj, rectangle, cube, disk), to_world, center,
+//                             area emitters -> one TriangleLight per triangle, sensor
+// The two parsing libraries it calls (TinyParser-Mitsuba, tinyobjloader) are absent
+// from the reference tree; the subset of their behaviour the call sites rely on
+//  is implemented here: camelCase -> snake_case property names,
+// <ref id> resolution into anonymous children, typed property getters with defaults
+// (number 0, colour 0, bool default), fan triangulation, relative OBJ indices.
+#include "Loader.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace GPUSpectral {
+
+namespace {
+
+std::string g_defaultAssetDir;
+
+// ---------------------------------------------------------------------------
+// minimal XML reader (elements, attributes, comments, <?...?>, self-closing tags)
+// ---------------------------------------------------------------------------
+struct XmlNode {
+  std::string tag;
+  std::vector<std::pair<std::string, std::string>> attrs;
+  std::vector<std::unique_ptr<XmlNode>> children;
+  const std::string* attr(const char* name) const {
+    for (auto& a : attrs)
+      if (a.first == name) return &a.second;
+    return nullptr;
+  }
+  std::string get(const char* name, const std::string& def = "") const {
+    auto* a = attr(name);
+    return a ? *a : def;
+  }
+};
+
+class XmlParser {
+ public:
+  explicit XmlParser(const std::string& text) : s(text) {}
+  std::unique_ptr<XmlNode> parseDocument() {
+    skipMisc();
+    auto root = parseElement();
+    if (!root) throw std::runtime_error("XML: no root element");
+    return root;
+  }
+
+ private:
+  const std::string& s;
+  size_t p = 0;
+  void skipWs() {
+    while (p < s.size() && std::isspace((unsigned char)s[p])) ++p;
+  }
+  bool starts(const char* lit) const { return s.compare(p, std::strlen(lit), lit) == 0; }
+  void skipMisc() {
+    for (;;) {
+      skipWs();
+      if (starts("<?")) {
+        size_t e = s.find("?>", p);
+        if (e == std::string::npos) throw std::runtime_error("XML: unterminated <?");
+        p = e + 2;
+      } else if (starts("<!--")) {
+        size_t e = s.find("-->", p);
+        if (e == std::string::npos) throw std::runtime_error("XML: unterminated comment");
+        p = e + 3;
+      } else if (starts("<!")) {
+        size_t e = s.find('>', p);
+        if (e == std::string::npos) throw std::runtime_error("XML: unterminated <!");
+        p = e + 1;
+      } else {
+        return;
+      }
+    }
+  }
+  static std::string unescape(const std::string& v) {
+    std::string o;
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (v[i] == '&') {
+        if (v.compare(i, 4, "&lt;") == 0) { o += '<'; i += 3; continue; }
+        if (v.compare(i, 4, "&gt;") == 0) { o += '>'; i += 3; continue; }
+        if (v.compare(i, 5, "&amp;") == 0) { o += '&'; i += 4; continue; }
+        if (v.compare(i, 6, "&quot;") == 0) { o += '"'; i += 5; continue; }
+        if (v.compare(i, 6, "&apos;") == 0) { o += '\''; i += 5; continue; }
+      }
+      o += v[i];
+    }
+    return o;
+  }
+  std::string name() {
+    size_t b = p;
+    while (p < s.size() && (std::isalnum((unsigned char)s[p]) || s[p] == '_' || s[p] == '-' || s[p] == ':' || s[p] == '.'))
+      ++p;
+    return s.substr(b, p - b);
+  }
+  std::unique_ptr<XmlNode> parseElement() {
+    skipMisc();
+    if (p >= s.size() || s[p] != '<') return nullptr;
+    ++p;
+    auto n = std::make_unique<XmlNode>();
+    n->tag = name();
+    if (n->tag.empty()) throw std::runtime_error("XML: bad tag near offset " + std::to_string(p));
+    for (;;) {
+      skipWs();
+      if (p >= s.size()) throw std::runtime_error("XML: unexpected end in <" + n->tag + ">");
+      if (starts("/>")) {
+        p += 2;
+        return n;
+      }
+      if (s[p] == '>') {
+        ++p;
+        break;
+      }
+      std::string an = name();
+      skipWs();
+      if (an.empty() || p >= s.size() || s[p] != '=') throw std::runtime_error("XML: bad attribute in <" + n->tag + ">");
+      ++p;
+      skipWs();
+      char q = s[p];
+      if (q != '"' && q != '\'') throw std::runtime_error("XML: unquoted attribute in <" + n->tag + ">");
+      size_t e = s.find(q, p + 1);
+      if (e == std::string::npos) throw std::runtime_error("XML: unterminated attribute value");
+      n->attrs.emplace_back(an, unescape(s.substr(p + 1, e - p - 1)));
+      p = e + 1;
+    }
+    for (;;) {
+      // text content is irrelevant for Mitsuba scenes: skip to the next tag
+      size_t lt = s.find('<', p);
+      if (lt == std::string::npos) throw std::runtime_error("XML: missing </" + n->tag + ">");
+      p = lt;
+      if (starts("</")) {
+        p += 2;
+        std::string cn = name();
+        skipWs();
+        if (p < s.size() && s[p] == '>') ++p;
+        if (cn != n->tag) throw std::runtime_error("XML: </" + cn + "> closes <" + n->tag + ">");
+        return n;
+      }
+      if (starts("<!--") || starts("<?") || starts("<!")) {
+        skipMisc();
+        continue;
+      }
+      n->children.push_back(parseElement());
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// stand-in for tinyparser_mitsuba::Object
+// ---------------------------------------------------------------------------
+enum PropType { PT_NUMBER, PT_BOOL, PT_STRING, PT_COLOR, PT_VECTOR, PT_TRANSFORM };
+struct Prop {
+  PropType type;
+  double number = 0;
+  bool flag = false;
+  std::string str;
+  float v[3] = {0, 0, 0};
+  float matrix[16];  // row-major, as written in the file
+};
+struct Object {
+  std::string kind;    // tag: shape, bsdf, sensor, emitter, texture, ...
+  std::string plugin;  // type attribute
+  std::map<std::string, Prop> props;
+  std::vector<std::shared_ptr<Object>> children;                        // anonymousChildren()
+  std::vector<std::pair<std::string, std::shared_ptr<Object>>> named;   // namedChildren()
+
+  bool has(const std::string& n) const { return props.count(n) != 0; }
+  float number(const std::string& n, float def = 0.0f) const {
+    auto it = props.find(n);
+    return it != props.end() && it->second.type == PT_NUMBER ? (float)it->second.number : def;
+  }
+  vec3 color(const std::string& n) const {
+    auto it = props.find(n);
+    if (it != props.end() && it->second.type == PT_COLOR) return vec3{it->second.v[0], it->second.v[1], it->second.v[2]};
+    return vec3{};
+  }
+  std::string string(const std::string& n) const {
+    auto it = props.find(n);
+    return it != props.end() && it->second.type == PT_STRING ? it->second.str : std::string();
+  }
+  bool boolean(const std::string& n, bool def) const {
+    auto it = props.find(n);
+    return it != props.end() && it->second.type == PT_BOOL ? it->second.flag : def;
+  }
+};
+
+// toWorld -> to_world, intIOR -> int_ior, diffuseReflectance -> diffuse_reflectance
+std::string snake(const std::string& s) {
+  std::string o;
+  for (size_t i = 0; i < s.size(); ++i) {
+    unsigned char c = s[i];
+    if (std::isupper(c) && i > 0 && (std::islower((unsigned char)s[i - 1]) || std::isdigit((unsigned char)s[i - 1]))) o += '_';
+    o += (char)std::tolower(c);
+  }
+  return o;
+}
+
+std::vector<double> numbers(const std::string& text) {
+  std::vector<double> out;
+  const char* c = text.c_str();
+  while (*c) {
+    while (*c && (std::isspace((unsigned char)*c) || *c == ',')) ++c;
+    if (!*c) break;
+    char* e = nullptr;
+    double v = std::strtod(c, &e);
+    if (e == c) break;
+    out.push_back(v);
+    c = e;
+  }
+  return out;
+}
+
+bool isObjectTag(const std::string& t) {
+  static const char* tags[] = {"shape", "bsdf", "sensor", "emitter", "texture", "medium", "integrator", "sampler", "film", "rfilter"};
+  for (auto* k : tags)
+    if (t == k) return true;
+  return false;
+}
+
+std::shared_ptr<Object> parseObject(const XmlNode& el, std::unordered_map<std::string, std::shared_ptr<Object>>& ids) {
+  auto o = std::make_shared<Object>();
+  o->kind = el.tag;
+  o->plugin = el.get("type");
+  for (auto& chp : el.children) {
+    const XmlNode& ch = *chp;
+    const std::string nm = snake(ch.get("name"));
+    Prop pr;
+    if (ch.tag == "float" || ch.tag == "integer") {
+      pr.type = PT_NUMBER;
+      pr.number = std::strtod(ch.get("value", "0").c_str(), nullptr);
+      o->props[nm] = pr;
+    } else if (ch.tag == "boolean") {
+      pr.type = PT_BOOL;
+      std::string v = ch.get("value");
+      for (auto& c : v) c = (char)std::tolower((unsigned char)c);
+      pr.flag = v.find("true") != std::string::npos;
+      o->props[nm] = pr;
+    } else if (ch.tag == "string") {
+      pr.type = PT_STRING;
+      pr.str = ch.get("value");
+      o->props[nm] = pr;
+    } else if (ch.tag == "rgb" || ch.tag == "srgb") {
+      pr.type = PT_COLOR;
+      auto v = numbers(ch.get("value"));
+      if (v.size() == 1) v = {v[0], v[0], v[0]};
+      for (size_t k = 0; k < 3 && k < v.size(); ++k) pr.v[k] = (float)v[k];
+      o->props[nm] = pr;
+    } else if (ch.tag == "point" || ch.tag == "vector") {
+      pr.type = PT_VECTOR;
+      if (ch.attr("value")) {
+        auto v = numbers(ch.get("value"));
+        for (size_t k = 0; k < 3 && k < v.size(); ++k) pr.v[k] = (float)v[k];
+      } else {
+        pr.v[0] = (float)std::strtod(ch.get("x", "0").c_str(), nullptr);
+        pr.v[1] = (float)std::strtod(ch.get("y", "0").c_str(), nullptr);
+        pr.v[2] = (float)std::strtod(ch.get("z", "0").c_str(), nullptr);
+      }
+      o->props[nm] = pr;
+    } else if (ch.tag == "transform") {
+      pr.type = PT_TRANSFORM;
+      for (int k = 0; k < 16; ++k) pr.matrix[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+      for (auto& t : ch.children)
+        if (t->tag == "matrix") {
+          auto v = numbers(t->get("value"));
+          for (size_t k = 0; k < 16 && k < v.size(); ++k) pr.matrix[k] = (float)v[k];
+        }
+      o->props[nm] = pr;
+    } else if (ch.tag == "ref") {
+      auto it = ids.find(ch.get("id"));
+      if (it != ids.end()) o->children.push_back(it->second);
+    } else if (isObjectTag(ch.tag)) {
+      auto child = parseObject(ch, ids);
+      if (ch.attr("id")) ids[ch.get("id")] = child;
+      if (ch.attr("name")) o->named.emplace_back(nm, child);
+      else o->children.push_back(child);
+    }
+  }
+  return o;
+}
+
+std::string dirOf(const std::string& path) {
+  size_t s = path.find_last_of("/\\");
+  return s == std::string::npos ? std::string(".") : path.substr(0, s);
+}
+std::string joinPath(const std::string& a, const std::string& b) {
+  if (a.empty()) return b;
+  if (!b.empty() && b[0] == '/') return b;
+  return a + "/" + b;
+}
+bool fileExists(const std::string& p) {
+  std::ifstream f(p);
+  return f.good();
+}
+
+// S/assets/rect.obj / box.obj restated from their definition: used when
+// the asset directory does not hold the files.
+MeshPtr builtinQuadMesh(uint32_t id, bool box) {
+  struct Face {
+    float n[3];
+    float c[4][3];
+  };
+  static const Face rect[] = {{{0, 0, 1}, {{-1, 1, 0}, {1, 1, 0}, {-1, -1, 0}, {1, -1, 0}}}};
+  static const Face cube[] = {
+      {{1, 0, 0}, {{1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}}},
+      {{-1, 0, 0}, {{-1, 1, -1}, {-1, 1, 1}, {-1, -1, -1}, {-1, -1, 1}}},
+      {{0, 1, 0}, {{-1, 1, -1}, {1, 1, -1}, {-1, 1, 1}, {1, 1, 1}}},
+      {{0, -1, 0}, {{-1, -1, 1}, {1, -1, 1}, {-1, -1, -1}, {1, -1, -1}}},
+      {{0, 0, 1}, {{-1, 1, 1}, {1, 1, 1}, {-1, -1, 1}, {1, -1, 1}}},
+      {{0, 0, -1}, {{1, 1, -1}, {-1, 1, -1}, {1, -1, -1}, {-1, -1, -1}}},
+  };
+  static const float uv[4][2] = {{0, 1}, {1, 1}, {0, 0}, {1, 0}};
+  static const int order[6] = {0, 2, 1, 2, 3, 1};  // f 1 3 2 / f 3 4 2
+  const Face* faces = box ? cube : rect;
+  const int nf = box ? 6 : 1;
+  std::vector<Mesh::Vertex> v;
+  for (int f = 0; f < nf; ++f)
+    for (int k : order) {
+      Mesh::Vertex x;
+      x.pos = vec3{faces[f].c[k][0], faces[f].c[k][1], faces[f].c[k][2]};
+      x.normal = vec3{faces[f].n[0], faces[f].n[1], faces[f].n[2]};
+      x.uv = vec2{uv[k][0], uv[k][1]};
+      v.push_back(x);
+    }
+  return std::make_shared<Mesh>(id, std::move(v));
+}
+
+// Loader.cpp:145-234
+void loadMaterial(Scene& scene, Material* material, const Object& obj) {
+  const std::string& type = obj.plugin;
+  if (type == "twosided") material->twofaced = true;
+  if (type == "diffuse") {
+    vec3 rgb = obj.color("reflectance");
+    for (auto& nc : obj.named)
+      if (nc.first == "reflectance") scene.warnings.push_back("diffuse: textured reflectance unsupported (Loader.cpp:122-143), colour default used");
+    material->bsdf = scene.addDiffuseBSDF(DiffuseBSDF{{rgb.x, rgb.y, rgb.z}, 0});
+  } else if (type == "roughplastic") {
+    vec3 rgb = obj.color("diffuse_reflectance");
+    float alpha = obj.number("alpha");
+    if (obj.has("ext_ior") && std::fabs(obj.number("ext_ior") - 1.0f) > 0.001f) scene.warnings.push_back("unsupported ext ior of plastic");
+    float ior = obj.has("int_ior") ? obj.number("int_ior") : 1.3f;
+    float R0 = (ior - 1.0f) / (ior + 1.0f);
+    R0 *= R0;
+    RoughPlasticBSDF b{};
+    b.diffuse[0] = rgb.x;
+    b.diffuse[1] = rgb.y;
+    b.diffuse[2] = rgb.z;
+    b.ior_in = ior;
+    b.ior_out = 1.0f;
+    b.r0 = R0;
+    b.alpha = (float)std::sqrt(2.0f) * alpha;
+    for (auto& nc : obj.named)
+      if (nc.first == "diffuse_reflectance") scene.warnings.push_back("roughplastic: textured diffuse_reflectance unsupported, colour default used");
+    material->bsdf = scene.addRoughPlasticBSDF(b);
+  } else if (type == "dielectric") {
+    float intIOR = obj.number("int_ior");
+    float extIOR = obj.number("ext_ior");
+    if (!obj.has("int_ior") || !obj.has("ext_ior")) scene.warnings.push_back("dielectric without numeric int_ior/ext_ior: the reference reads 0");
+    material->bsdf = scene.addSmoothDielectricBSDF(SmoothDielectricBSDF{intIOR, extIOR});
+  } else if (type == "conductor") {
+    float ior = obj.has("eta") ? obj.number("eta") : 0.0f;
+    material->bsdf = scene.addSmoothConductorBSDF(SmoothConductorBSDF{ior, 1.0f});
+  } else if (type == "plastic") {
+    vec3 rgb = obj.color("diffuse_reflectance");
+    if (obj.has("ext_ior") && std::fabs(obj.number("ext_ior") - 1.0f) > 0.001f) scene.warnings.push_back("unsupported ext ior of plastic");
+    float ior = obj.has("int_ior") ? obj.number("int_ior") : 1.3f;
+    float R0 = (ior - 1.0f) / (ior + 1.0f);
+    R0 *= R0;
+    SmoothPlasticBSDF b{};
+    b.diffuse[0] = rgb.x;
+    b.diffuse[1] = rgb.y;
+    b.diffuse[2] = rgb.z;
+    b.ior_in = ior;
+    b.ior_out = 1.0f;
+    b.r0 = R0;
+    material->bsdf = scene.addSmoothPlasticBSDF(b);
+  } else if (type == "roughconductor") {
+    vec3 eta = obj.color("eta"), k = obj.color("k"), refl = obj.color("specular_reflectance");
+    float alpha = obj.number("alpha");
+    RoughConductorBSDF b{};
+    b.eta[0] = eta.x; b.eta[1] = eta.y; b.eta[2] = eta.z;
+    b.k[0] = k.x; b.k[1] = k.y; b.k[2] = k.z;
+    b.reflectance[0] = refl.x; b.reflectance[1] = refl.y; b.reflectance[2] = refl.z;
+    b.alpha = (float)std::sqrt(2) * alpha;
+    material->bsdf = scene.addRoughConductorBSDF(b);
+  }
+  for (auto& child : obj.children)
+    if (child->kind == "bsdf") loadMaterial(scene, material, *child);
+}
+
+}  // namespace
+
+void setDefaultAssetDir(const std::string& dir) { g_defaultAssetDir = dir; }
+
+// Loader.cpp:19-64
+MeshPtr loadMesh(const std::string& path, uint32_t id) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("cannot open OBJ file: " + path);
+  std::vector<float> v, vt, vn;
+  std::vector<Mesh::Vertex> out;
+  std::string line;
+  bool missingNormals = false;
+  struct Corner {
+    int v, t, n;
+  };
+  std::vector<Corner> corners;
+  while (std::getline(in, line)) {
+    const char* c = line.c_str();
+    while (*c == ' ' || *c == '\t') ++c;
+    if (c[0] == 'v' && (c[1] == ' ' || c[1] == '\t')) {
+      char* e;
+      c += 2;
+      for (int k = 0; k < 3; ++k) {
+        v.push_back((float)std::strtod(c, &e));
+        c = e;
+      }
+    } else if (c[0] == 'v' && c[1] == 'n') {
+      char* e;
+      c += 3;
+      for (int k = 0; k < 3; ++k) {
+        vn.push_back((float)std::strtod(c, &e));
+        c = e;
+      }
+    } else if (c[0] == 'v' && c[1] == 't') {
+      char* e;
+      c += 3;
+      for (int k = 0; k < 2; ++k) {
+        vt.push_back((float)std::strtod(c, &e));
+        c = e;
+      }
+    } else if (c[0] == 'f' && (c[1] == ' ' || c[1] == '\t')) {
+      corners.clear();
+      c += 2;
+      for (;;) {
+        while (*c == ' ' || *c == '\t') ++c;
+        if (!*c || *c == '\r' || *c == '\n') break;
+        Corner k{0, 0, 0};
+        char* e;
+        long a = std::strtol(c, &e, 10);
+        if (e == c) break;
+        c = e;
+        k.v = a > 0 ? (int)a - 1 : (int)(v.size() / 3) + (int)a;
+        k.t = k.n = -1;
+        if (*c == '/') {
+          ++c;
+          if (*c != '/') {
+            long t = std::strtol(c, &e, 10);
+            if (e != c) k.t = t > 0 ? (int)t - 1 : (int)(vt.size() / 2) + (int)t;
+            c = e;
+          }
+          if (*c == '/') {
+            ++c;
+            long n = std::strtol(c, &e, 10);
+            if (e != c) k.n = n > 0 ? (int)n - 1 : (int)(vn.size() / 3) + (int)n;
+            c = e;
+          }
+        }
+        corners.push_back(k);
+      }
+      for (size_t k = 2; k < corners.size(); ++k) {  // fan triangulation
+        const Corner tri[3] = {corners[0], corners[k - 1], corners[k]};
+        for (const Corner& q : tri) {
+          Mesh::Vertex x;
+          if (q.v < 0 || (size_t)q.v * 3 + 2 >= v.size()) throw std::runtime_error("OBJ index out of range in " + path);
+          x.pos = vec3{v[3 * q.v], v[3 * q.v + 1], v[3 * q.v + 2]};
+          if (q.t >= 0 && (size_t)q.t * 2 + 1 < vt.size()) x.uv = vec2{vt[2 * q.t], vt[2 * q.t + 1]};
+          if (q.n >= 0 && (size_t)q.n * 3 + 2 < vn.size()) x.normal = vec3{vn[3 * q.n], vn[3 * q.n + 1], vn[3 * q.n + 2]};
+          else missingNormals = true;
+          out.push_back(x);
+        }
+      }
+    }
+  }
+  if (missingNormals) {
+    // outside the reference's contract (it indexes attrib.normals unchecked, Loader.cpp:56-59):
+    // substitute flat face normals so the mesh is still renderable
+    for (size_t i = 0; i + 2 < out.size(); i += 3) {
+      vec3 a = out[i].pos, b = out[i + 1].pos, c = out[i + 2].pos;
+      float e1[3] = {b.x - a.x, b.y - a.y, b.z - a.z}, e2[3] = {c.x - a.x, c.y - a.y, c.z - a.z};
+      float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      vec3 fn = l > 0 ? vec3{n[0] / l, n[1] / l, n[2] / l} : vec3{};
+      out[i].normal = out[i + 1].normal = out[i + 2].normal = fn;
+    }
+  }
+  return std::make_shared<Mesh>(id, std::move(out));
+}
+
+// Loader.cpp:253-349
+Scene loadScene(const std::string& path, const std::string& assetDirArg) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open scene file: " + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string text = ss.str();
+  auto root = XmlParser(text).parseDocument();
+  const std::string parentPath = dirOf(path);
+  const std::string assetDir = !assetDirArg.empty() ? assetDirArg : (!g_defaultAssetDir.empty() ? g_defaultAssetDir : parentPath);
+
+  std::unordered_map<std::string, std::shared_ptr<Object>> ids;
+  auto top = parseObject(*root, ids);
+
+  std::unordered_map<std::string, MeshPtr> meshCache;
+  uint32_t nextMeshId = 1;
+  Scene outScene;
+  auto loadOrGetMesh = [&](const std::string& objPath, int builtin) -> MeshPtr {
+    auto it = meshCache.find(objPath);
+    if (it != meshCache.end()) return it->second;
+    MeshPtr m;
+    if (builtin && !fileExists(objPath)) m = builtinQuadMesh(nextMeshId++, builtin == 2);
+    else m = loadMesh(objPath, nextMeshId++);
+    meshCache.emplace(objPath, m);
+    return m;
+  };
+
+  for (auto& obj : top->children) {
+    if (obj->kind == "shape") {
+      std::string filename;
+      int builtin = 0;
+      const std::string& pt = obj->plugin;
+      if (pt == "obj") filename = joinPath(parentPath, obj->string("filename"));
+      else if (pt == "rectangle") { filename = joinPath(assetDir, "rect.obj"); builtin = 1; }
+      else if (pt == "cube") { filename = joinPath(assetDir, "box.obj"); builtin = 2; }
+      else if (pt == "disk") filename = joinPath(assetDir, "disk.obj");
+      else {
+        outScene.warnings.push_back("unsupported shape type '" + pt + "' skipped");
+        continue;
+      }
+      if (!builtin && !fileExists(filename)) {
+        outScene.warnings.push_back("missing mesh '" + filename + "' skipped");
+        continue;
+      }
+      MeshPtr mesh = loadOrGetMesh(filename, builtin);
+      float rowMajor[16];
+      for (int k = 0; k < 16; ++k) rowMajor[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+      auto tw = obj->props.find("to_world");
+      if (tw != obj->props.end() && tw->second.type == PT_TRANSFORM) std::memcpy(rowMajor, tw->second.matrix, sizeof(rowMajor));
+      bool faceNormals = obj->boolean("face_normals", false);
+      mat4 matrix = transpose(make_mat4(rowMajor));  // Loader.cpp:286
+      auto ce = obj->props.find("center");
+      if (ce != obj->props.end() && ce->second.type == PT_VECTOR) {  // Loader.cpp:287-293
+        matrix[3][0] = ce->second.v[0];
+        matrix[3][1] = ce->second.v[1];
+        matrix[3][2] = ce->second.v[2];
+        matrix[3][3] = 1.0f;
+      }
+      bool emitting = false;
+      RenderObject renderObject;
+      Material material;
+      for (auto& child : obj->children) {
+        if (child->kind == "bsdf") {
+          loadMaterial(outScene, &material, *child);
+        } else if (child->kind == "emitter" && child->plugin == "area") {
+          material.emission = child->color("radiance");
+          emitting = true;
+        }
+      }
+      renderObject.mesh = mesh;
+      renderObject.transform = matrix;
+      renderObject.material = outScene.addMaterial(material);
+      outScene.getMaterial(renderObject.material).facenormals = faceNormals;
+      outScene.addRenderObject(renderObject);
+      if (emitting) {  // Loader.cpp:316-330
+        const auto& vertices = mesh->getVertices();
+        for (size_t i = 0; i + 2 < vertices.size(); i += 3) {
+          TriangleLight light{};
+          for (int k = 0; k < 3; ++k) {
+            const vec3& p = vertices[i + k].pos;
+            vec4 w = renderObject.transform * vec4{p.x, p.y, p.z, 1.0f};
+            light.positions[k][0] = w.x;
+            light.positions[k][1] = w.y;
+            light.positions[k][2] = w.z;
+            light.positions[k][3] = w.w;
+          }
+          light.radiance[0] = material.emission.x;
+          light.radiance[1] = material.emission.y;
+          light.radiance[2] = material.emission.z;
+          light.radiance[3] = 1.0f;
+          outScene.addTriangleLight(light);
+        }
+      }
+    } else if (obj->kind == "sensor") {  // Loader.cpp:331-337
+      float rowMajor[16];
+      for (int k = 0; k < 16; ++k) rowMajor[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+      auto tw = obj->props.find("to_world");
+      if (tw != obj->props.end() && tw->second.type == PT_TRANSFORM) std::memcpy(rowMajor, tw->second.matrix, sizeof(rowMajor));
+      float fov = obj->number("fov");
+      outScene.camera.setFov((float)(fov * M_PI / 180.f));
+      outScene.camera.setToWorld(transpose(make_mat4(rowMajor)));
+    } else if (obj->kind == "emitter") {
+      outScene.warnings.push_back("top-level emitter (envmap) ignored, as in the reference (Loader.cpp:338-346)");
+    }
+  }
+  return outScene;
+}
+
+void flattenScene(const Scene& scene, FlatScene& out) {
+  out = FlatScene{};
+  std::unordered_map<const Mesh*, std::pair<uint32_t, uint32_t>> placed;
+  for (const RenderObject& obj : scene.renderObjects) {
+    const Mesh* m = obj.mesh.get();
+    auto it = placed.find(m);
+    if (it == placed.end()) {
+      const auto& vs = m->getVertices();
+      uint32_t first = (uint32_t)(out.positions.size() / 3);
+      uint32_t count = (uint32_t)(vs.size() / 3 * 3);
+      for (uint32_t i = 0; i < count; ++i) {
+        out.positions.insert(out.positions.end(), {vs[i].pos.x, vs[i].pos.y, vs[i].pos.z});
+        out.normals.insert(out.normals.end(), {vs[i].normal.x, vs[i].normal.y, vs[i].normal.z});
+      }
+      it = placed.emplace(m, std::make_pair(first, count)).first;
+    }
+    const Material& material = scene.getMaterial(obj.material);
+    gsp_instance in{};
+    std::memcpy(in.transform, obj.transform.data(), sizeof(in.transform));
+    in.emission[0] = material.emission.x;
+    in.emission[1] = material.emission.y;
+    in.emission[2] = material.emission.z;
+    in.bsdf = material.bsdf.handle;
+    in.twofaced = material.twofaced ? 1u : 0u;
+    in.first_vertex = it->second.first;
+    in.vertex_count = it->second.second;
+    out.instances.push_back(in);
+  }
+  gsp_scene_desc& d = out.desc;
+  d.instances = out.instances.data();
+  d.num_instances = (uint32_t)out.instances.size();
+  d.positions = out.positions.data();
+  d.normals = out.normals.data();
+  d.num_vertices = out.positions.size() / 3;
+  d.diffuse_bsdfs = scene.diffuseBSDFs.data();
+  d.smooth_dielectric_bsdfs = scene.smoothDielectricBSDFs.data();
+  d.smooth_conductor_bsdfs = scene.smoothConductorBSDFs.data();
+  d.smooth_plastic_bsdfs = scene.smoothPlasticBSDFs.data();
+  d.rough_conductor_bsdfs = scene.roughConductorBSDFs.data();
+  d.smooth_floor_bsdfs = scene.smoothFloorBSDFs.data();
+  d.rough_floor_bsdfs = scene.roughFloorBSDFs.data();
+  d.rough_plastic_bsdfs = scene.roughPlasticBSDFs.data();
+  d.num_bsdfs[GSP_BSDF_DIFFUSE] = (uint32_t)scene.diffuseBSDFs.size();
+  d.num_bsdfs[GSP_BSDF_SMOOTH_DIELECTRIC] = (uint32_t)scene.smoothDielectricBSDFs.size();
+  d.num_bsdfs[GSP_BSDF_SMOOTH_CONDUCTOR] = (uint32_t)scene.smoothConductorBSDFs.size();
+  d.num_bsdfs[GSP_BSDF_SMOOTH_PLASTIC] = (uint32_t)scene.smoothPlasticBSDFs.size();
+  d.num_bsdfs[GSP_BSDF_ROUGH_CONDUCTOR] = (uint32_t)scene.roughConductorBSDFs.size();
+  d.num_bsdfs[GSP_BSDF_SMOOTH_FLOOR] = (uint32_t)scene.smoothFloorBSDFs.size();
+  d.num_bsdfs[GSP_BSDF_ROUGH_FLOOR] = (uint32_t)scene.roughFloorBSDFs.size();
+  d.num_bsdfs[GSP_BSDF_ROUGH_PLASTIC] = (uint32_t)scene.roughPlasticBSDFs.size();
+  d.lights = scene.triangleLights.data();
+  d.num_lights = (uint32_t)scene.triangleLights.size();
+  std::memcpy(d.camera.to_world, scene.camera.getToWorld().data(), sizeof(d.camera.to_world));
+  d.camera.fov = scene.camera.getFov();
+}
+
+}  // namespace GPUSpectral

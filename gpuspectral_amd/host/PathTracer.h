@@ -1,0 +1,65 @@
+// PathTracer.h -- host half of the path-tracing pass, the drop-in for the reference's
+// `class PathTracer : public RenderPassCreator` (S/renderer/PathTracer.h:48-68,
+// S/renderer/Renderer.h:22-25).
+//
+// Same two-phase shape as the reference:
+//   construction  = setup(): allocate the frame-sized RGBA32F accumulate buffer
+//                   (PathTracer.cpp:5-7)
+//   createRenderPass(scene) = one call per presented frame: prepareScene + traceRays
+//                   -> ONE more sample per pixel folded into the running mean, with the
+//                   internal `timestamp` counter advanced (PathTracer.cpp:9-56,91-92)
+// plus `render(scene, spp)` for offline use.  Instead of recording Vulkan passes into a
+// FrameGraph it drives the HIP wavefront tracer through the C ABI
+// (include/gpuspectral_pt.h).  Errors are C++ exceptions (std::runtime_error), as in the
+// reference.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "Scene.h"
+
+namespace GPUSpectral {
+
+// The plugin interface of the reference (Renderer.h:22-25) without the Vulkan FrameGraph.
+class RenderPassCreator {
+ public:
+  virtual ~RenderPassCreator() = default;
+  virtual void createRenderPass(const Scene& scene) = 0;
+};
+
+class PathTracer : public RenderPassCreator {
+ public:
+  // `pixelIds` optionally restricts this tracer to a subset of the frame (multi-GPU tiles).
+  PathTracer(uint32_t width, uint32_t height, int device = 0, const std::vector<uint32_t>& pixelIds = {});
+  ~PathTracer() override;
+  PathTracer(const PathTracer&) = delete;
+  PathTracer& operator=(const PathTracer&) = delete;
+
+  void setup();
+  void createRenderPass(const Scene& scene) override;  // +1 spp
+  void render(const Scene& scene, uint32_t spp);       // +spp samples
+  void prepareScene(const Scene& scene);               // flatten + upload + BVH build (cached per Scene object)
+
+  // RGBA32F, row-major, width*height*4 floats (running mean, alpha 1)
+  std::vector<float> download();
+  void reset();  // timestamp = 0, accumulate buffer cleared
+  int getTimestamp() const { return timestamp; }
+  gsp_stats stats();
+  gsp_render_params params;  // reference literals by default (MAX_DEPTH 50, RR > 10, clamp 20)
+
+ private:
+  void check(int rc, const char* what);
+  gsp_context* ctx = nullptr;
+  uint32_t width, height;
+  int device;
+  std::vector<uint32_t> pixelIds;
+  const Scene* uploaded = nullptr;
+  size_t uploadedObjects = 0;
+  int timestamp{0};
+};
+
+// Headless output step: little-endian PFM ("PF", bottom-to-top rows) of the RGB channels.
+void writePfm(const std::string& path, const float* rgba, uint32_t width, uint32_t height);
+
+}  // namespace GPUSpectral

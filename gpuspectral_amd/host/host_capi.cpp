@@ -1,0 +1,92 @@
+// host_capi.cpp -- C wrappers over the C++ host layer (Scene / loadScene / PathTracer) so
+// that the Python tests can drive exactly the classes a C++ caller would use.
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <string>
+
+#include "Loader.h"
+#include "PathTracer.h"
+
+using namespace GPUSpectral;
+
+namespace {
+thread_local std::string g_err;
+struct SceneBox {
+  Scene scene;
+  FlatScene flat;
+};
+template <class F>
+int guard(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* gsph_last_error(void) { return g_err.c_str(); }
+
+void* gsph_load_scene(const char* path, const char* asset_dir) {
+  SceneBox* b = nullptr;
+  int rc = guard([&] {
+    b = new SceneBox();
+    b->scene = loadScene(path, asset_dir ? asset_dir : "");
+    flattenScene(b->scene, b->flat);
+  });
+  if (rc) {
+    delete b;
+    return nullptr;
+  }
+  return b;
+}
+void gsph_scene_free(void* s) { delete (SceneBox*)s; }
+// The flattened scene (pointers stay valid until gsph_scene_free).
+const gsp_scene_desc* gsph_scene_desc(void* s) { return &((SceneBox*)s)->flat.desc; }
+uint32_t gsph_scene_num_warnings(void* s) { return (uint32_t)((SceneBox*)s)->scene.warnings.size(); }
+const char* gsph_scene_warning(void* s, uint32_t i) { return ((SceneBox*)s)->scene.warnings[i].c_str(); }
+uint32_t gsph_scene_num_materials(void* s) { return (uint32_t)((SceneBox*)s)->scene.materials.size(); }
+
+void* gsph_pathtracer_create(uint32_t width, uint32_t height, int device, const uint32_t* pixel_ids, uint64_t n) {
+  PathTracer* pt = nullptr;
+  int rc = guard([&] {
+    std::vector<uint32_t> ids;
+    if (pixel_ids) ids.assign(pixel_ids, pixel_ids + n);
+    pt = new PathTracer(width, height, device, ids);
+  });
+  return rc ? nullptr : pt;
+}
+void gsph_pathtracer_free(void* pt) { delete (PathTracer*)pt; }
+int gsph_pathtracer_create_render_pass(void* pt, void* scene) {
+  return guard([&] { ((PathTracer*)pt)->createRenderPass(((SceneBox*)scene)->scene); });
+}
+int gsph_pathtracer_render(void* pt, void* scene, uint32_t spp) {
+  return guard([&] { ((PathTracer*)pt)->render(((SceneBox*)scene)->scene, spp); });
+}
+int gsph_pathtracer_set_params(void* pt, const gsp_render_params* p) {
+  return guard([&] { ((PathTracer*)pt)->params = *p; });
+}
+int gsph_pathtracer_timestamp(void* pt) { return ((PathTracer*)pt)->getTimestamp(); }
+int gsph_pathtracer_reset(void* pt) {
+  return guard([&] { ((PathTracer*)pt)->reset(); });
+}
+int gsph_pathtracer_download(void* pt, float* out, uint64_t count) {
+  return guard([&] {
+    auto img = ((PathTracer*)pt)->download();
+    if (count < img.size()) throw std::runtime_error("output buffer too small");
+    std::memcpy(out, img.data(), img.size() * sizeof(float));
+  });
+}
+int gsph_pathtracer_stats(void* pt, gsp_stats* out) {
+  return guard([&] { *out = ((PathTracer*)pt)->stats(); });
+}
+int gsph_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
+  return guard([&] { writePfm(path, rgba, width, height); });
+}
+
+}  // extern "C"

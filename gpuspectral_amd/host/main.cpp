@@ -1,0 +1,42 @@
+// main.cpp -- headless counterpart of the reference's S/main.cpp:15-30:
+//   Engine + PathTracer + loadScene + Window::run(frame loop)
+// becomes: load the Mitsuba XML, render N samples per pixel, write the HDR framebuffer.
+//   gsp_render <scene.xml> <out.pfm> [width height spp [device]]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <exception>
+
+#include "Loader.h"
+#include "PathTracer.h"
+
+using namespace GPUSpectral;
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s scene.xml out.pfm [width height spp [device]]\n", argv[0]);
+    return 2;
+  }
+  const uint32_t width = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 500;  // S/main.cpp:17: 500x500 window
+  const uint32_t height = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 500;
+  const uint32_t spp = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 64;
+  const int device = argc > 6 ? std::atoi(argv[6]) : 0;
+  try {
+    Scene scene = loadScene(argv[1]);
+    for (auto& w : scene.warnings) std::fprintf(stderr, "WARN: %s\n", w.c_str());
+    PathTracer pt(width, height, device);
+    auto t0 = std::chrono::steady_clock::now();
+    pt.render(scene, spp);
+    auto img = pt.download();
+    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    gsp_stats st = pt.stats();
+    writePfm(argv[2], img.data(), width, height);
+    std::printf("%llu triangles, %ux%u x %u spp in %.3f s: %.1f Mrays/s, %.2f Msamples/s (BVH build %.1f ms)\n",
+                (unsigned long long)st.num_triangles, width, height, spp, s,
+                (st.extension_rays + st.shadow_rays) / s / 1e6, st.samples / s / 1e6, st.bvh_build_ms);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -28,7 +28,7 @@ namespace orc {
 // Triangle soup in world space + binned-SAH BVH2 (stand-in for BLAS/TLAS).
 // ---------------------------------------------------------------------------
 struct Tri {
-  vec3 v0, e1, e2;
+  vec3 v0, v1, v2;
 };
 
 struct Node {
@@ -53,21 +53,52 @@ struct Accel {
   std::vector<uint32_t> tri_instance;  // global triangle id -> instance
 };
 
-// Ray/triangle test (Moeller-Trumbore on precomputed edges).  The arithmetic
-// below IS the oracle's definition of the intersection the Vulkan driver
-// performs opaquely; the product kernel states the same sequence.
-static inline bool intersectTri(const Tri& tr, vec3 o, vec3 d, float tmin, float tmax, float& t, float& u, float& v) {
-  vec3 pvec = cross(d, tr.e2);
-  float det = dot(tr.e1, pvec);
+// Ray/triangle test: watertight algorithm of Woop, Benthin, Wald (JCGT 2013), no culling.
+// The Vulkan driver's intersector is opaque (PARITY UNPINNED, README.md); hardware
+// traversal is watertight, so the oracle uses the published watertight test.  The
+// arithmetic below IS the oracle's definition; the product kernel states the same sequence.
+struct Shear {
+  int kx, ky, kz;
+  float Sx, Sy, Sz;
+};
+static inline float comp(vec3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+static inline Shear makeShear(vec3 d) {
+  Shear r;
+  const float ax = gabs(d.x), ay = gabs(d.y), az = gabs(d.z);
+  r.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+  r.kx = r.kz == 2 ? 0 : r.kz + 1;
+  r.ky = r.kx == 2 ? 0 : r.kx + 1;
+  const float dz = comp(d, r.kz);
+  if (dz < 0.0f) std::swap(r.kx, r.ky);
+  r.Sx = comp(d, r.kx) / dz;
+  r.Sy = comp(d, r.ky) / dz;
+  r.Sz = 1.0f / dz;
+  return r;
+}
+static inline bool intersectTri(const Tri& tr, vec3 o, const Shear& rs, float tmin, float tmax, float& t, float& u,
+                                float& v) {
+  const vec3 A = tr.v0 - o, B = tr.v1 - o, C = tr.v2 - o;
+  const float Akz = comp(A, rs.kz), Bkz = comp(B, rs.kz), Ckz = comp(C, rs.kz);
+  const float Ax = comp(A, rs.kx) - rs.Sx * Akz, Ay = comp(A, rs.ky) - rs.Sy * Akz;
+  const float Bx = comp(B, rs.kx) - rs.Sx * Bkz, By = comp(B, rs.ky) - rs.Sy * Bkz;
+  const float Cx = comp(C, rs.kx) - rs.Sx * Ckz, Cy = comp(C, rs.ky) - rs.Sy * Ckz;
+  float U = Cx * By - Cy * Bx;
+  float V = Ax * Cy - Ay * Cx;
+  float W = Bx * Ay - By * Ax;
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  const float det = (U + V) + W;
   if (det == 0.0f) return false;
-  float inv = 1.0f / det;
-  vec3 tvec = o - tr.v0;
-  u = dot(tvec, pvec) * inv;
-  if (!(u >= 0.0f && u <= 1.0f)) return false;
-  vec3 qvec = cross(tvec, tr.e1);
-  v = dot(d, qvec) * inv;
-  if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-  t = dot(tr.e2, qvec) * inv;
+  const float Az = rs.Sz * Akz, Bz = rs.Sz * Bkz, Cz = rs.Sz * Ckz;
+  const float T = (U * Az + V * Bz) + W * Cz;
+  const float rcp = 1.0f / det;
+  t = T * rcp;
+  u = V * rcp;  // weight of v1
+  v = W * rcp;  // weight of v2
   return t > tmin && t < tmax;
 }
 
@@ -80,7 +111,7 @@ static void buildAccel(const gsp_scene_desc& sc, Accel& A) {
       vec3 p0 = xform_point(in.transform, V(p[0], p[1], p[2]));
       vec3 p1 = xform_point(in.transform, V(p[3], p[4], p[5]));
       vec3 p2 = xform_point(in.transform, V(p[6], p[7], p[8]));
-      A.tris.push_back(Tri{p0, p1 - p0, p2 - p0});
+      A.tris.push_back(Tri{p0, p1, p2});
       A.tri_instance.push_back(i);
     }
   }
@@ -90,7 +121,7 @@ static void buildAccel(const gsp_scene_desc& sc, Accel& A) {
   for (uint32_t i = 0; i < n; ++i) {
     A.order[i] = i;
     const Tri& t = A.tris[i];
-    vec3 a = t.v0, b = t.v0 + t.e1, c = t.v0 + t.e2;
+    vec3 a = t.v0, b = t.v1, c = t.v2;
     float lo[3] = {std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z))};
     float hi[3] = {std::max(a.x, std::max(b.x, c.x)), std::max(a.y, std::max(b.y, c.y)), std::max(a.z, std::max(b.z, c.z))};
     for (int k = 0; k < 3; ++k) {
@@ -256,6 +287,7 @@ static inline bool slab(const Node& n, vec3 o, vec3 inv, float tmin, float tmax,
 static Hit closestHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, TravStats* st) {
   Hit best{tmax, 0.0f, 0.0f, -1};
   vec3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const Shear rs = makeShear(d);
   uint32_t stack[128];
   int sp = 0;
   stack[sp++] = 0;
@@ -270,7 +302,7 @@ static Hit closestHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, Tr
         uint32_t id = A.order[n.left + i];
         float t, u, v;
         ++nt;
-        if (intersectTri(A.tris[id], o, d, tmin, tmax, t, u, v)) {
+        if (intersectTri(A.tris[id], o, rs, tmin, tmax, t, u, v)) {
           if (t < best.t || (t == best.t && (int32_t)id < best.prim)) best = Hit{t, u, v, (int32_t)id};
         }
       }
@@ -304,6 +336,7 @@ static Hit closestHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, Tr
 // any hit in (tmin, tmax): TerminateOnFirstHit | SkipClosestHitShader   rayhit.rchit:738-748
 static bool anyHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, TravStats* st) {
   vec3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const Shear rs = makeShear(d);
   uint32_t stack[128];
   int sp = 0;
   stack[sp++] = 0;
@@ -318,7 +351,7 @@ static bool anyHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, TravS
       for (uint32_t i = 0; i < n.count; ++i) {
         float t, u, v;
         ++nt;
-        if (intersectTri(A.tris[A.order[n.left + i]], o, d, tmin, tmax, t, u, v)) {
+        if (intersectTri(A.tris[A.order[n.left + i]], o, rs, tmin, tmax, t, u, v)) {
           found = true;
           break;
         }

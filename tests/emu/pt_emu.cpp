@@ -80,8 +80,8 @@ struct Emu {
         f3 e1 = p1 - p0, e2 = p2 - p0;
         f3 N = normalize(cross(e1, e2));
         gi.push_back(mkq(p0.x, p0.y, p0.z, u2f(g)));
-        gi.push_back(mkq(e1.x, e1.y, e1.z, 0));
-        gi.push_back(mkq(e2.x, e2.y, e2.z, 0));
+        gi.push_back(mkq(p1.x, p1.y, p1.z, 0));
+        gi.push_back(mkq(p2.x, p2.y, p2.z, 0));
         gs.push_back(mkq(N.x, N.y, N.z, u2f(a)));
         gs.push_back(mkq(n0.x, n0.y, n0.z, 0));
         gs.push_back(mkq(n1.x, n1.y, n1.z, 0));

@@ -161,3 +161,52 @@ def test_edge_cases(ctx, oracle_mod):
     p.max_depth, p.rr_start_depth = 0, 0
     ref, _ = oracle_mod.Oracle(cm).render(48, 48, spp=2, params=p)
     assert rmse(ctx.download(), ref) < TOL_RMSE
+
+
+def test_cpp_host_pathtracer_frame_protocol(oracle_mod, cornell):
+    """C++ host layer end to end: loadScene(XML) -> PathTracer::createRenderPass x N == oracle,
+    with the reference's per-frame timestamp protocol (PathTracer.cpp:91-92)."""
+    from conftest import CORNELL_XML
+    from gpuspectral_amd import host
+
+    scene = host.Scene(CORNELL_XML)
+    pt = host.PathTracer(64, 64)
+    for i in range(3):
+        assert pt.timestamp == i
+        pt.create_render_pass(scene)  # one traceRays(W,H) = +1 spp
+    pt.render(scene, 5)
+    assert pt.timestamp == 8
+    img = pt.download().reshape(-1, 4)
+    ref, _ = oracle_mod.Oracle(cornell).render(64, 64, spp=8)
+    assert rmse(img, ref) < TOL_RMSE
+    assert np.array_equal(img, ref)
+    st = pt.stats()
+    assert st["num_triangles"] == 36 and st["samples"] == 64 * 64 * 8
+    pt.reset()
+    assert pt.timestamp == 0 and (pt.download() == 0).all()
+    pt.close()
+
+
+def test_size_independent_properties_at_scale(ctx):
+    """Properties that need no oracle, at a size the oracle would take minutes for:
+    determinism, split-invariance of the running mean, energy bounds, stats consistency."""
+    from gpuspectral_amd import scenes
+
+    sc = scenes.interior(120_000)
+    ctx.upload_scene(sc)
+    ctx.reset_stats()
+    ctx.frame_begin(480, 270)
+    ctx.render(spp=6)
+    a = ctx.download().copy()
+    st = ctx.stats()
+    ctx.frame_begin(480, 270)
+    ctx.render(spp=2, timestamps_in_flight=1)
+    ctx.render(spp=4, first_timestamp=2, timestamps_in_flight=3)
+    b = ctx.download()
+    assert np.array_equal(a, b)  # same image whatever the batching
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[..., 3] == 1).all()
+    assert a[..., :3].max() < 20.0 * 52  # firefly clamp bounds every bounce's contribution
+    assert st["samples"] == 480 * 270 * 6
+    assert st["extension_rays"] >= st["samples"] and st["shaded_vertices"] <= st["extension_rays"]
+    assert st["shadow_rays"] <= st["shaded_vertices"]
+    assert st["num_triangles"] == sc.num_triangles and st["num_bvh_nodes"] == sc.num_triangles - 1
