@@ -30,13 +30,13 @@
 
 #include "pt_hostmath.h"
 #include "pt_internal.h"
+#include "pt_wavetrace.h"
 
 namespace gsp {
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kLdsStack = 24;  // stack entries per lane kept in LDS; deeper levels spill to HBM
 
 struct PathQueue {
   q4* P0;
@@ -52,27 +52,12 @@ struct ShadowQueue {
 };
 
 // device counters
-enum { C_NEXT = 0, C_SHADOW = 1, C_COUNT = 2 };
+// device counters: [0] next-queue size, [1] shadow-queue size, then the ray hand-out counters of
+// the extend and connect launches (kWorkShards words each, on separate 128-B lines)
+enum { C_NEXT = 0, C_SHADOW = 1, C_WORK_EXT = 32, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
+       C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
 struct DevStats {
   unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays;
-};
-
-// ---- per-lane traversal stack: LDS first, HBM spill behind it -----------------
-struct LaneStack {
-  int32_t* lds;    // &lds_stack[threadIdx.x], stride kBlock
-  int32_t* spill;  // &spill[global thread], stride spill_stride
-  uint32_t spill_stride;
-  int sp;
-  __device__ __forceinline__ void push(int32_t v) {
-    if (sp < kLdsStack) lds[sp * kBlock] = v;
-    else spill[(size_t)(sp - kLdsStack) * spill_stride] = v;
-    ++sp;
-  }
-  __device__ __forceinline__ int32_t pop() {
-    --sp;
-    return sp < kLdsStack ? lds[sp * kBlock] : spill[(size_t)(sp - kLdsStack) * spill_stride];
-  }
-  __device__ __forceinline__ bool empty() const { return sp == 0; }
 };
 
 __device__ __forceinline__ q4 mkq(float x, float y, float z, float w) {
@@ -111,39 +96,68 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
   }
 }
 
-// ---- extend ---------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_extend(SceneView S, uint32_t n, PathQueue q, q4* __restrict__ hits,
-                                                    int32_t* __restrict__ spill, uint32_t spill_stride,
-                                                    DevStats* __restrict__ stats) {
-  __shared__ int32_t lds_stack[kLdsStack * kBlock];
-  const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-  LaneStack stk;
-  stk.lds = lds_stack + threadIdx.x;
-  stk.spill = spill + gtid;
-  stk.spill_stride = spill_stride;
-  TraceCounters cnt;
-  cnt.nodes = 0;
-  cnt.tris = 0;
-  uint32_t rays = 0;
-  for (uint32_t i = gtid; i < n; i += gridDim.x * kBlock) {
+// ---- extend / connect / test hook: ray sources and result sinks of k_trace -----------------
+struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
+  PathQueue q;
+  q4* hits;
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
     const q4 p0 = q.P0[i], p1 = q.P1[i];
-    HitRec h;
-    stk.sp = 0;
-    traverse<false, STATS>(S.nodes, S.tri_isect, S.root, mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), 0.0f, 1e10f, stk,
-                           h, cnt);
+    o = mk3(p0.x, p0.y, p0.z);
+    d = mk3(p0.w, p1.x, p1.y);
+    tmin = 0.0f;
+    tmax = 1e10f;
+  }
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h) const {
     hits[i] = mkq(h.t, h.u, h.v, ub((uint32_t)h.slot));
-    ++rays;
   }
-  if (STATS) {
-    unsigned long long a = wave_sum(cnt.nodes), b = wave_sum(cnt.tris), c = wave_sum(rays);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&stats->nodes, a);
-      atomicAdd(&stats->tris, b);
-      atomicAdd(&stats->stat_rays, c);
-    }
+};
+
+struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any hit
+  ShadowQueue sq;
+  q4* next_P2;
+  q4* result;
+  float clampv;
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
+    const q4 s0 = sq.S0[i], s1 = sq.S1[i];
+    o = mk3(s0.x, s0.y, s0.z);
+    d = mk3(s1.x, s1.y, s1.z);
+    tmin = 0.01f;
+    tmax = s0.w;
   }
-}
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h) const {
+    const q4 s1 = sq.S1[i], s2 = sq.S2[i], s3 = sq.S3[i];
+    ShadowRay r;
+    r.nee = mk3(s2.x, s2.y, s2.z);
+    r.emis = mk3(s3.x, s3.y, s3.z);
+    const uint32_t sid = fb(s1.w);
+    q4 res = result[sid];
+    bool nee_done;
+    connect_vertex(clampv, r, h.slot >= 0, res, nee_done);
+    result[sid] = res;
+    const uint32_t nx = fb(s3.w);
+    if (nee_done && nx != 0xffffffffu) next_P2[nx].w = s2.w;  // rayhit.rchit:785-787
+  }
+};
+
+struct TestIO {  // gsp_trace
+  const float* rays;
+  q4* hits;
+  const uint32_t* slot_to_global;
+  int any_hit;
+  uint32_t num_tris;
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
+    const float* r = rays + 8ull * i;
+    o = mk3(r[0], r[1], r[2]);
+    d = mk3(r[4], r[5], r[6]);
+    tmin = r[3];
+    tmax = r[7];
+  }
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h) const {
+    const bool hit = h.slot >= 0 && num_tris != 0;
+    if (any_hit) hits[i] = mkq(0.0f, 0.0f, 0.0f, ub(hit ? 0u : 0xffffffffu));
+    else hits[i] = hit ? mkq(h.t, h.u, h.v, ub(slot_to_global[h.slot])) : mkq(0.0f, 0.0f, 0.0f, ub(0xffffffffu));
+  }
+};
 
 // ---- shade ----------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
@@ -218,52 +232,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, 
   if (lane == 0 && shaded) atomicAdd(&stats->shaded, shaded);
 }
 
-// ---- connect --------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_connect(SceneView S, float clampv, const uint32_t* __restrict__ counters,
-                                                     ShadowQueue sq, q4* __restrict__ next_P2,
-                                                     q4* __restrict__ result, int32_t* __restrict__ spill,
-                                                     uint32_t spill_stride, DevStats* __restrict__ stats) {
-  __shared__ int32_t lds_stack[kLdsStack * kBlock];
-  const uint32_t n = counters[C_SHADOW];
-  const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-  LaneStack stk;
-  stk.lds = lds_stack + threadIdx.x;
-  stk.spill = spill + gtid;
-  stk.spill_stride = spill_stride;
-  TraceCounters cnt;
-  cnt.nodes = 0;
-  cnt.tris = 0;
-  uint32_t rays = 0;
-  for (uint32_t i = gtid; i < n; i += gridDim.x * kBlock) {
-    const q4 s0 = sq.S0[i], s1 = sq.S1[i];
-    HitRec h;
-    stk.sp = 0;
-    const bool occluded = traverse<true, STATS>(S.nodes, S.tri_isect, S.root, mk3(s0.x, s0.y, s0.z),
-                                                mk3(s1.x, s1.y, s1.z), 0.01f, s0.w, stk, h, cnt);
-    const q4 s2 = sq.S2[i], s3 = sq.S3[i];
-    ShadowRay r;
-    r.nee = mk3(s2.x, s2.y, s2.z);
-    r.emis = mk3(s3.x, s3.y, s3.z);
-    const uint32_t sid = fb(s1.w);
-    q4 res = result[sid];
-    bool nee_done;
-    connect_vertex(clampv, r, occluded, res, nee_done);
-    result[sid] = res;
-    const uint32_t nx = fb(s3.w);
-    if (nee_done && nx != 0xffffffffu) next_P2[nx].w = s2.w;  // rayhit.rchit:785-787
-    ++rays;
-  }
-  if (STATS) {
-    unsigned long long a = wave_sum(cnt.nodes), b = wave_sum(cnt.tris), c = wave_sum(rays);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&stats->sh_nodes, a);
-      atomicAdd(&stats->sh_tris, b);
-      atomicAdd(&stats->sh_rays, c);
-    }
-  }
-}
-
 // ---- resolve ----------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_t K, uint32_t first_timestamp,
                                                      const q4* __restrict__ result, q4* __restrict__ accum) {
@@ -271,35 +239,6 @@ __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_
     q4 a = accum[lp];
     for (uint32_t k = 0; k < K; ++k) resolve_sample(first_timestamp + k, result[(uint64_t)k * num_pixels + lp], a);
     accum[lp] = a;
-  }
-}
-
-// ---- test hook: arbitrary rays ------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_trace_rays(SceneView S, uint32_t n, const float* __restrict__ rays,
-                                                        int any_hit, const uint32_t* __restrict__ slot_to_global,
-                                                        uint32_t num_tris, q4* __restrict__ hits,
-                                                        int32_t* __restrict__ spill, uint32_t spill_stride) {
-  __shared__ int32_t lds_stack[kLdsStack * kBlock];
-  const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-  LaneStack stk;
-  stk.lds = lds_stack + threadIdx.x;
-  stk.spill = spill + gtid;
-  stk.spill_stride = spill_stride;
-  TraceCounters cnt;
-  for (uint32_t i = gtid; i < n; i += gridDim.x * kBlock) {
-    const float* r = rays + 8ull * i;
-    HitRec h;
-    stk.sp = 0;
-    bool hit;
-    if (any_hit)
-      hit = traverse<true, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7],
-                                  stk, h, cnt);
-    else
-      hit = traverse<false, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3],
-                                   r[7], stk, h, cnt);
-    if (num_tris == 0) hit = false;
-    if (any_hit) hits[i] = mkq(0.0f, 0.0f, 0.0f, ub(hit ? 0u : 0xffffffffu));
-    else hits[i] = hit ? mkq(h.t, h.u, h.v, ub(slot_to_global[h.slot])) : mkq(0.0f, 0.0f, 0.0f, ub(0xffffffffu));
   }
 }
 
@@ -406,14 +345,14 @@ struct gsp_context {
     v.root = bvh.root;
     return v;
   }
-  uint32_t max_blocks() const { return (uint32_t)num_cus * 6u; }
+  uint32_t max_blocks() const { return (uint32_t)num_cus * 6u; }  // 6 x 256 threads: what 24 KB of LDS per block admits
   uint32_t grid_for(uint64_t n) const {
     uint64_t b = (n + kBlock - 1) / kBlock;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, max_blocks()));
   }
   int ensure_spill() {
     // one stack level per internal node on the deepest path (+ slack)
-    const uint32_t need = bvh.depth + 2 > (uint32_t)kLdsStack ? bvh.depth + 2 - kLdsStack : 1;
+    const uint32_t need = bvh.depth + 3 > (uint32_t)kLdsStackDepth ? bvh.depth + 3 - kLdsStackDepth : 1;
     spill_stride = max_blocks() * kBlock;
     GSP_HIP_TRY(spill.ensure((size_t)need * spill_stride, &bytes));
     return GSP_OK;
@@ -648,7 +587,7 @@ static int ensure_pool(gsp_context* ctx, uint64_t cap) {
   CTX_TRY(ctx, ctx->S1.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, ctx->S2.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, ctx->S3.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, ctx->counters.ensure(16, &ctx->bytes));
+  CTX_TRY(ctx, ctx->counters.ensure(C_COUNT, &ctx->bytes));
   if (!ctx->dstats.p) {
     CTX_TRY(ctx, ctx->dstats.ensure(1, &ctx->bytes));
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
@@ -707,6 +646,8 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   for (int k = 0; k < 2; ++k) Q[k] = PathQueue{ctx->P0[k].p, ctx->P1[k].p, ctx->P2[k].p, ctx->FL[k].p};
   ShadowQueue SQ{ctx->S0.p, ctx->S1.p, ctx->S2.p, ctx->S3.p};
 
+  const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
+  const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
   uint32_t done = 0;
   while (done < rp->spp) {
     const uint32_t Kp = (uint32_t)std::min<uint64_t>(K, rp->spp - done);
@@ -719,24 +660,36 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       const uint32_t grid = ctx->grid_for(n);
       CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, C_COUNT * sizeof(uint32_t), st));
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-      if (stats_mode)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, st, view, (uint32_t)n, Q[cur], ctx->hits.p,
-                           ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
-      else
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, st, view, (uint32_t)n, Q[cur], ctx->hits.p,
-                           ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
+      {
+        const ExtendIO io{Q[cur], ctx->hits.p};
+        uint32_t* work = ctx->counters.p + C_WORK_EXT;
+        if (stats_mode)
+          hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
+                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, work, ctx->spill.p,
+                             ctx->spill_stride, so_ext);
+        else
+          hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
+                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, work, ctx->spill.p,
+                             ctx->spill_stride, so_ext);
+      }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
       hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
                          Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, ctx->dstats.p);
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-      if (stats_mode)
-        hipLaunchKernelGGL(k_connect<true>, dim3(grid), dim3(kBlock), 0, st, view, rcst.clamp, ctx->counters.p, SQ,
-                           Q[cur ^ 1].P2, ctx->result.p, ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
-      else
-        hipLaunchKernelGGL(k_connect<false>, dim3(grid), dim3(kBlock), 0, st, view, rcst.clamp, ctx->counters.p, SQ,
-                           Q[cur ^ 1].P2, ctx->result.p, ctx->spill.p, ctx->spill_stride, ctx->dstats.p);
+      {
+        const ConnectIO io{SQ, Q[cur ^ 1].P2, ctx->result.p, rcst.clamp};
+        uint32_t* work = ctx->counters.p + C_WORK_SH;
+        if (stats_mode)
+          hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
+                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, io, work,
+                             ctx->spill.p, ctx->spill_stride, so_sh);
+        else
+          hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
+                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, io, work,
+                             ctx->spill.p, ctx->spill_stride, so_sh);
+      }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-      CTX_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, C_COUNT * sizeof(uint32_t),
+      CTX_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, 2 * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, st));
       CTX_TRY(ctx, hipStreamSynchronize(st));
       CTX_TRY(ctx, hipGetLastError());
@@ -861,9 +814,20 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   DevBuf<q4> d_hits;
   CTX_TRY(ctx, d_rays.upload(rays, 8 * n, ctx->stream, nullptr));
   CTX_TRY(ctx, d_hits.ensure(n, nullptr));
-  hipLaunchKernelGGL(k_trace_rays, dim3(ctx->grid_for(n)), dim3(kBlock), 0, ctx->stream, ctx->view(), (uint32_t)n,
-                     d_rays.p, any_hit, ctx->bvh.slot_to_global, ctx->bvh.num_tris, d_hits.p, ctx->spill.p,
-                     ctx->spill_stride);
+  DevBuf<uint32_t> d_work;
+  CTX_TRY(ctx, d_work.ensure(kWorkShards * kWorkStride, nullptr));
+  CTX_TRY(ctx, hipMemsetAsync(d_work.p, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
+  const SceneView view = ctx->view();
+  const TestIO io{d_rays.p, d_hits.p, ctx->bvh.slot_to_global, any_hit, ctx->bvh.num_tris};
+  const TraceStatsOut none{nullptr, nullptr, nullptr};
+  if (any_hit)
+    hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->grid_for(n)), dim3(kTraceBlock), 0, ctx->stream,
+                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, d_work.p,
+                       ctx->spill.p, ctx->spill_stride, none);
+  else
+    hipLaunchKernelGGL((k_trace<false, false, TestIO>), dim3(ctx->grid_for(n)), dim3(kTraceBlock), 0, ctx->stream,
+                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, d_work.p,
+                       ctx->spill.p, ctx->spill_stride, none);
   CTX_TRY(ctx, hipGetLastError());
   CTX_TRY(ctx, hipMemcpyAsync(hits, d_hits.p, n * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,247 @@
+// pt_wavetrace.h -- persistent wave64 BVH traversal kernel (device only).
+//
+// The extend (closest hit), connect (any hit) and test-hook kernels are all this
+// one loop with a different ray source / result sink (`IO`).
+//
+// Why it looks like this (rocprofv3 PMC, profiles/r01_a_pmc_summary.txt and r01_b_*): the
+// first version (one ray per lane per grid-stride iteration) kept the VALU pipes ~85 % busy
+// with only ~17 % of the lanes enabled -- rays of very different length share a wave, and
+// lanes in a leaf wait for lanes in inner nodes.  The kernel is VALU-issue bound, so the
+// lever is lanes doing useful work per issued instruction.  Hence a flat, wave-uniform
+// state machine (every decision is a ballot + scalar branch, no divergent loops):
+//   * each lane owns a ray state {cur node, postponed leaf, stack}; per loop iteration the
+//     wave runs ONE node step for all lanes that sit on an inner node, and a leaf step
+//     (triangle tests) only when kLeafBatch lanes have a leaf pending or nothing else can
+//     run -- triangle tests execute with many lanes enabled instead of one at a time
+//     (leaf postponing after Aila & Laine 2009, re-tuned for 64 lanes);
+//   * lanes whose ray finished commit their result and are refilled from a wave-local pool
+//     as soon as kRefillLanes of them are idle; the pool takes 256-ray chunks from 8
+//     hand-out counters (one per blockIdx % 8 label = per XCD under round-robin placement;
+//     speed only), i.e. one atomic per 256 rays on a line no other XCD touches;
+//   * per-lane stack in LDS ([level][lane]: conflict-free) with an HBM spill region behind
+//     it; a sentinel at the bottom removes the empty-stack test.
+#pragma once
+#include "pt_trace.h"
+
+namespace gsp {
+
+constexpr int kTraceBlock = 256;
+constexpr int kLdsStackDepth = 24;          // LDS levels per lane (24 KB per block)
+constexpr int kRefillLanes = 16;            // idle lanes that trigger a refill
+constexpr int kLeafBatch = 20;              // pending leaves that trigger a leaf step
+constexpr uint32_t kChunk = 256;            // rays per hand-out
+constexpr int kWorkShards = 8;
+constexpr int kWorkStride = 32;             // counters sit on separate 128-B lines
+constexpr int32_t kSentinel = 0x7fffffff;
+
+// Explicit address spaces: a generic pointer that may be LDS or HBM compiles to flat_load /
+// flat_store on every push and pop; with typed pointers the LDS levels are ds_read/ds_write.
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+typedef __attribute__((address_space(1))) int32_t glb_i32;
+
+struct WaveStack {
+  lds_i32* lds;    // &lds_stack[threadIdx.x], stride kTraceBlock
+  glb_i32* spill;  // &spill[global thread], stride spill_stride
+  uint32_t spill_stride;
+  int sp;
+  __device__ __forceinline__ void push(int32_t v) {
+    if (sp < kLdsStackDepth) lds[sp * kTraceBlock] = v;
+    else spill[(size_t)(sp - kLdsStackDepth) * spill_stride] = v;
+    ++sp;
+  }
+  __device__ __forceinline__ int32_t pop() {
+    --sp;
+    int32_t v;
+    if (sp < kLdsStackDepth) v = lds[sp * kTraceBlock];
+    else v = spill[(size_t)(sp - kLdsStackDepth) * spill_stride];
+    return v;
+  }
+};
+
+struct TraceStatsOut {
+  unsigned long long* nodes;
+  unsigned long long* tris;
+  unsigned long long* rays;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// IO contract:
+//   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const;
+//   __device__ void store(uint32_t i, const HitRec& h) const;   // h.slot < 0: miss / unoccluded
+template <bool ANY, bool STATS, class IO>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
+                                                        int32_t root, const uint32_t* __restrict__ n_ptr,
+                                                        uint32_t n_imm, IO io, uint32_t* __restrict__ work,
+                                                        int32_t* __restrict__ spill, uint32_t spill_stride,
+                                                        TraceStatsOut so) {
+  __shared__ int32_t lds_stack[kLdsStackDepth * kTraceBlock];
+  const uint32_t n = n_ptr ? *n_ptr : n_imm;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t shard = blockIdx.x % kWorkShards;
+  uint32_t* my_work = work + shard * kWorkStride;
+
+  WaveStack stk;
+  stk.lds = (lds_i32*)lds_stack + threadIdx.x;
+  stk.spill = (glb_i32*)spill + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
+  stk.spill_stride = spill_stride;
+  stk.sp = 0;
+
+  // wave-uniform hand-out state
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+
+  // per-lane ray state
+  int32_t cur = kSentinel, leaf = 0;
+  uint32_t ri = 0xffffffffu, best_id = 0xffffffffu;
+  f3 o = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+  RayShear rs;
+  rs.kx = rs.ky = rs.kz = 0;
+  rs.Sx = rs.Sy = rs.Sz = 0.0f;
+  float tmin = 0.0f, tmax = 0.0f;
+  HitRec h;
+  h.t = 0.0f;
+  h.u = h.v = 0.0f;
+  h.slot = -1;
+  uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
+
+  for (;;) {
+    // ---- commit finished rays ------------------------------------------------------------
+    if (ri != 0xffffffffu && cur == kSentinel && leaf == 0) {
+      io.store(ri, h);
+      ri = 0xffffffffu;
+    }
+    // ---- refill idle lanes from the wave-local pool -----------------------------------------
+    uint64_t idle_m = __ballot(ri == 0xffffffffu);
+    if (!exhausted && __popcll(idle_m) >= kRefillLanes) {
+      while (idle_m) {  // wave-uniform
+        if (pool_next >= pool_end) {
+          uint32_t k = 0;
+          if (lane == 0) k = atomicAdd(my_work, 1u);
+          k = __shfl(k, 0);
+          const uint64_t start = ((uint64_t)k * kWorkShards + shard) * kChunk;
+          if (start >= n) {
+            exhausted = true;
+            break;
+          }
+          pool_next = (uint32_t)start;
+          pool_end = (uint32_t)(start + kChunk < n ? start + kChunk : n);
+        }
+        const uint32_t rank = (uint32_t)__popcll(idle_m & lt_mask);
+        const uint32_t avail = pool_end - pool_next;
+        if (((idle_m >> lane) & 1ull) && rank < avail) {
+          ri = pool_next + rank;
+          f3 d;
+          io.load(ri, o, d, tmin, tmax);
+          inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          rs = make_shear(d);
+          h.t = tmax;
+          h.u = h.v = 0.0f;
+          h.slot = -1;
+          best_id = 0xffffffffu;
+          stk.sp = 0;
+          stk.push(kSentinel);
+          cur = root;
+          leaf = 0;
+          if (cur < 0) {  // the root itself is a leaf (single-triangle or empty scene)
+            leaf = cur;
+            cur = kSentinel;
+            stk.sp = 0;
+          }
+          if (STATS) ++c_rays;
+        }
+        const uint32_t want = (uint32_t)__popcll(idle_m);
+        pool_next += want < avail ? want : avail;
+        idle_m = __ballot(ri == 0xffffffffu);
+      }
+    }
+    // ---- what can run? -------------------------------------------------------------------------
+    const bool on_node = (uint32_t)cur < (uint32_t)kSentinel;
+    const uint64_t node_m = __ballot(on_node);
+    const uint64_t leaf_m = __ballot(leaf < 0);
+    if ((node_m | leaf_m) == 0) {
+      if (exhausted || idle_m == 0) break;  // nothing in flight and nothing left to hand out
+      continue;                             // (all lanes idle: the refill above runs next)
+    }
+    // ---- one inner-node step for every lane that sits on an inner node ---------------------------
+    const bool leaf_step = __popcll(leaf_m) >= kLeafBatch || node_m == 0;
+    if (node_m != 0 && !leaf_step) {
+      if (on_node) {
+        const q4* nd = nodes + 4ll * cur;
+        const q4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        if (STATS) ++c_nodes;
+        float tl, tr;
+        const bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, h.t, tl);
+        const bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, h.t, tr);
+        const int32_t cl = (int32_t)__float_as_uint(q3.x), cr = (int32_t)__float_as_uint(q3.y);
+        if (hl && hr) {
+          const bool left_first = tl <= tr;
+          stk.push(left_first ? cr : cl);
+          cur = left_first ? cl : cr;
+        } else if (hl) {
+          cur = cl;
+        } else if (hr) {
+          cur = cr;
+        } else {
+          cur = stk.pop();
+        }
+        if (cur < 0 && leaf == 0) {  // first leaf: postpone it and keep descending
+          leaf = cur;
+          cur = stk.pop();
+        }
+      }
+      continue;
+    }
+    // ---- leaf step: triangle tests for every lane with a postponed leaf -----------------------------
+    if (leaf < 0) {
+      const uint32_t c = (uint32_t)~leaf;
+      const uint32_t first = c >> 2, count = (c & 3u) + 1u;
+      bool stop = false;
+      for (uint32_t k = 0; k < count; ++k) {
+        const q4* p = tris + 3ll * (first + k);
+        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
+        if (STATS) ++c_tris;
+        float t, u, v;
+        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u,
+                          v)) {
+          if (ANY) {
+            h.t = t;
+            h.slot = (int32_t)(first + k);
+            stop = true;
+            break;
+          }
+          const uint32_t id = __float_as_uint(p0.w);
+          if (t < h.t || (t == h.t && id < best_id)) {
+            h.t = t;
+            h.u = u;
+            h.v = v;
+            h.slot = (int32_t)(first + k);
+            best_id = id;
+          }
+        }
+      }
+      leaf = 0;
+      if (ANY && stop) {
+        cur = kSentinel;
+      } else if (cur < 0) {  // a second leaf was waiting in `cur`
+        leaf = cur;
+        cur = stk.pop();
+      }
+    }
+  }
+  if (STATS) {
+    const unsigned long long a = wave_sum_u64(c_nodes), b = wave_sum_u64(c_tris), c = wave_sum_u64(c_rays);
+    if (lane == 0) {
+      atomicAdd(so.nodes, a);
+      atomicAdd(so.tris, b);
+      atomicAdd(so.rays, c);
+    }
+  }
+}
+
+}  // namespace gsp

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 0 --no-cpu-baseline $*"
 run() { # name, counters
-  rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python3 $ROOT/bench.py $ARGS > $OUT/$1.log 2>&1 || echo "pass $1 failed"
+  timeout 180 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python3 $ROOT/bench.py $ARGS > $OUT/$1.log 2>&1 || echo "pass $1 failed"
 }
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
