@@ -15,13 +15,17 @@
 //   sort      rocPRIM radix sort of (code, triangle) pairs
 //   scatter   packets into leaf (Morton) order -> coherent rays touch adjacent HBM lines
 //   hierarchy Karras 2012 binary radix tree over the sorted codes
-//   fit       bottom-up boxes; each 64-B node stores BOTH child boxes, so a
-//             traversal step reads exactly one node record
+//   fit       bottom-up boxes of the binary tree (each binary node holds both child boxes)
+//   collapse  binary tree -> 4-wide BVH: every binary node at even depth becomes one 128-B
+//             node whose children are its grandchildren (leaf children stay as they are), so
+//             a ray makes half as many dependent node fetches; node index = exclusive scan of
+//             the even-depth flags (rocPRIM), which keeps the Morton locality of the LBVH
 #include <cstring>
 #include <algorithm>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "pt_internal.h"
 
@@ -294,6 +298,71 @@ __global__ __launch_bounds__(kBlock) void k_depth(int n, const int32_t* __restri
   if ((threadIdx.x & 63) == 0 && depth) atomicMax(max_depth, depth);
 }
 
+// flag[i] = 1 when binary node i sits at even depth (root = depth 0)
+__global__ __launch_bounds__(kBlock) void k_flag_even(int n_int, const int32_t* __restrict__ parent_int,
+                                                      uint32_t* __restrict__ flag) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_int) return;
+  uint32_t depth = 0;
+  for (int node = parent_int[i]; node >= 0; node = parent_int[node]) ++depth;
+  flag[i] = (depth & 1u) ? 0u : 1u;
+}
+
+struct Entry4 {
+  q4 lo, hi;
+  int32_t code;
+};
+
+// 4-wide node (128 B = 8 quads, SoA over the children):
+//   {minx0..3} {miny0..3} {minz0..3} {maxx0..3} {maxy0..3} {maxz0..3} {child0..3} {-}
+__global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restrict__ nodes2,
+                                                  const uint32_t* __restrict__ flag,
+                                                  const uint32_t* __restrict__ idx4, q4* __restrict__ nodes4) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_int || !flag[i]) return;
+  Entry4 e[4];
+  int cnt = 0;
+  auto conv = [&](int32_t g) { return g < 0 ? g : (int32_t)idx4[g]; };
+  auto expand = [&](int32_t c, q4 lo, q4 hi) {
+    if (c < 0) {
+      e[cnt].lo = lo;
+      e[cnt].hi = hi;
+      e[cnt].code = c;
+      ++cnt;
+    } else {  // odd-depth inner node: absorb it, adopt its two children
+      const q4* m = nodes2 + 4ll * c;
+      const q4 a = m[0], b = m[1], d = m[2], k = m[3];
+      e[cnt].lo = mkq(a.x, a.y, a.z, 0.0f);
+      e[cnt].hi = mkq(a.w, b.x, b.y, 0.0f);
+      e[cnt].code = conv((int32_t)__float_as_uint(k.x));
+      ++cnt;
+      e[cnt].lo = mkq(b.z, b.w, d.x, 0.0f);
+      e[cnt].hi = mkq(d.y, d.z, d.w, 0.0f);
+      e[cnt].code = conv((int32_t)__float_as_uint(k.y));
+      ++cnt;
+    }
+  };
+  const q4* me = nodes2 + 4ll * i;
+  const q4 a = me[0], b = me[1], d = me[2], k = me[3];
+  expand((int32_t)__float_as_uint(k.x), mkq(a.x, a.y, a.z, 0.0f), mkq(a.w, b.x, b.y, 0.0f));
+  expand((int32_t)__float_as_uint(k.y), mkq(b.z, b.w, d.x, 0.0f), mkq(d.y, d.z, d.w, 0.0f));
+  for (; cnt < 4; ++cnt) {  // empty slot: far-away point box, never followed (code checked in the kernel)
+    e[cnt].lo = mkq(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);
+    e[cnt].hi = e[cnt].lo;
+    e[cnt].code = kEmptyChild;
+  }
+  q4* o = nodes4 + 8ll * idx4[i];
+  o[0] = mkq(e[0].lo.x, e[1].lo.x, e[2].lo.x, e[3].lo.x);
+  o[1] = mkq(e[0].lo.y, e[1].lo.y, e[2].lo.y, e[3].lo.y);
+  o[2] = mkq(e[0].lo.z, e[1].lo.z, e[2].lo.z, e[3].lo.z);
+  o[3] = mkq(e[0].hi.x, e[1].hi.x, e[2].hi.x, e[3].hi.x);
+  o[4] = mkq(e[0].hi.y, e[1].hi.y, e[2].hi.y, e[3].hi.y);
+  o[5] = mkq(e[0].hi.z, e[1].hi.z, e[2].hi.z, e[3].hi.z);
+  o[6] = mkq(__uint_as_float((uint32_t)e[0].code), __uint_as_float((uint32_t)e[1].code),
+             __uint_as_float((uint32_t)e[2].code), __uint_as_float((uint32_t)e[3].code));
+  o[7] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 struct Scratch {
   std::vector<void*> ptrs;
   size_t bytes = 0;
@@ -329,28 +398,30 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   const uint32_t n = in.num_tris;
   const uint32_t slots = n ? n : 1;  // an empty scene keeps one degenerate triangle (det == 0: never hit)
   out.num_tris = n;
-  out.num_nodes = n >= 2 ? n - 1 : 0;
-  size_t b_nodes = (size_t)std::max<uint32_t>(out.num_nodes, 1) * 64, b_is = (size_t)slots * 48,
-         b_sh = (size_t)slots * 64, b_map = (size_t)slots * 4;
-  GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
+  out.num_nodes = 0;
+  size_t b_is = (size_t)slots * 48, b_sh = (size_t)slots * 64, b_map = (size_t)slots * 4;
   GSP_HIP_TRY(hipMalloc((void**)&out.tri_isect, b_is));
   GSP_HIP_TRY(hipMalloc((void**)&out.tri_shade, b_sh));
   GSP_HIP_TRY(hipMalloc((void**)&out.slot_to_global, b_map));
-  out.bytes = b_nodes + b_is + b_sh + b_map;
-  GSP_HIP_TRY(hipMemsetAsync(out.nodes, 0, b_nodes, stream));
+  out.bytes = b_is + b_sh + b_map;
   GSP_HIP_TRY(hipMemsetAsync(out.tri_isect, 0, b_is, stream));
   GSP_HIP_TRY(hipMemsetAsync(out.tri_shade, 0, b_sh, stream));
   GSP_HIP_TRY(hipMemsetAsync(out.slot_to_global, 0, b_map, stream));
   out.root = make_leaf(0, 1);
   out.depth = 0;
+  if (n < 2) {  // no inner node: the root is the single (or dummy) triangle's leaf
+    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, 128));
+    GSP_HIP_TRY(hipMemsetAsync(out.nodes, 0, 128, stream));
+    out.bytes += 128;
+  }
   if (n == 0) {
     GSP_HIP_TRY(hipStreamSynchronize(stream));
     return GSP_OK;
   }
 
   Scratch S;
-  q4 *isect_g, *shade_g, *lo_g, *hi_g, *leaf_lo, *leaf_hi, *int_lo, *int_hi;
-  uint32_t *bounds, *vals_in, *vals_out, *arrive, *d_depth;
+  q4 *isect_g, *shade_g, *lo_g, *hi_g, *leaf_lo, *leaf_hi, *int_lo, *int_hi, *nodes2;
+  uint32_t *bounds, *vals_in, *vals_out, *arrive, *d_depth, *flag, *idx4;
   uint64_t *keys_in, *keys_out;
   int32_t *child_l, *child_r, *parent_int, *parent_leaf;
   GSP_HIP_TRY(S.alloc(&isect_g, 3ull * n));
@@ -372,6 +443,9 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(S.alloc(&child_r, n));
   GSP_HIP_TRY(S.alloc(&parent_int, n));
   GSP_HIP_TRY(S.alloc(&parent_leaf, n));
+  GSP_HIP_TRY(S.alloc(&nodes2, 4ull * n));
+  GSP_HIP_TRY(S.alloc(&flag, n + 1ull));
+  GSP_HIP_TRY(S.alloc(&idx4, n + 1ull));
 
   const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
   GSP_HIP_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
@@ -394,15 +468,32 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(n - 1)), dim3(kBlock), 0, stream, (int)n, keys_out, child_l, child_r,
                        parent_int, parent_leaf);
     hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, child_l, child_r, parent_int,
-                       parent_leaf, leaf_lo, leaf_hi, int_lo, int_hi, arrive, out.nodes, d_depth);
+                       parent_leaf, leaf_lo, leaf_hi, int_lo, int_hi, arrive, nodes2, d_depth);
     hipLaunchKernelGGL(k_depth, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, parent_int, parent_leaf, d_depth);
+    // ---- collapse to the 4-wide tree ----
+    const int n_int = (int)n - 1;
+    GSP_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t) * (n + 1ull), stream));
+    hipLaunchKernelGGL(k_flag_even, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, parent_int, flag);
+    size_t scan_bytes = 0;
+    GSP_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
+    void* scan_tmp = nullptr;
+    GSP_HIP_TRY(S.alloc((char**)&scan_tmp, scan_bytes));
+    GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
+    uint32_t n4 = 0;
+    GSP_HIP_TRY(hipMemcpyAsync(&n4, idx4 + n_int, sizeof(n4), hipMemcpyDeviceToHost, stream));
+    GSP_HIP_TRY(hipStreamSynchronize(stream));
+    out.num_nodes = n4;
+    const size_t b_nodes = (size_t)std::max<uint32_t>(n4, 1) * 128;
+    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
+    out.bytes += b_nodes;
+    hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes);
     out.root = 0;
   }
   GSP_HIP_TRY(hipGetLastError());
   uint32_t depth = 0;
   GSP_HIP_TRY(hipMemcpyAsync(&depth, d_depth, sizeof(depth), hipMemcpyDeviceToHost, stream));
   GSP_HIP_TRY(hipStreamSynchronize(stream));
-  out.depth = depth;
+  out.depth = depth / 2 + 1;  // levels of the 4-wide tree
   return GSP_OK;
 }
 

@@ -24,7 +24,10 @@
 //   S0 = {o.xyz, tmax}  S1 = {d.xyz, bits(sid)}  S2 = {nee.rgb, dw_nee}  S3 = {emis.rgb, bits(next)}
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -52,10 +55,13 @@ struct ShadowQueue {
 };
 
 // device counters
-// device counters: [0] next-queue size, [1] shadow-queue size, then the ray hand-out counters of
-// the extend and connect launches (kWorkShards words each, on separate 128-B lines)
-enum { C_NEXT = 0, C_SHADOW = 1, C_WORK_EXT = 32, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
+// device counter words: [0] next-queue size, [1] shadow-queue size, [2, 2+kMaxSlots) live paths per
+// sample slot, then the ray hand-out counters of the extend and connect launches (kWorkShards
+// words each, on separate 128-B lines)
+constexpr int kMaxSlots = 64;
+enum { C_NEXT = 0, C_SHADOW = 1, C_LIVE = 2, C_WORK_EXT = 96, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
        C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
+static_assert(C_LIVE + kMaxSlots <= C_WORK_EXT, "counter layout");
 struct DevStats {
   unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays;
 };
@@ -78,21 +84,25 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 
 // ---- generate ------------------------------------------------------------------
+// Appends K timestamps x num_pixels new paths to the queue at `offset`; their sample slots start
+// at `sid_base` in the result ring.
 __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t num_pixels, uint32_t K,
                                                       uint32_t first_timestamp,
                                                       const uint32_t* __restrict__ pixel_ids, PathQueue q,
-                                                      q4* __restrict__ result) {
+                                                      uint32_t offset, uint32_t sid_base, q4* __restrict__ result) {
   const uint64_t total = (uint64_t)num_pixels * K;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
     const uint32_t k = (uint32_t)(i / num_pixels), lp = (uint32_t)(i % num_pixels);
     const uint32_t gid = pixel_ids ? pixel_ids[lp] : lp;
+    const uint32_t sid = sid_base + (uint32_t)i;
     PathState p;
-    generate_path(rc, gid, first_timestamp + k, (uint32_t)i, p);
-    q.P0[i] = mkq(p.o.x, p.o.y, p.o.z, p.d.x);
-    q.P1[i] = mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid));
-    q.P2[i] = mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight);
-    q.FL[i] = p.flags;
-    result[i] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+    generate_path(rc, gid, first_timestamp + k, sid, p);
+    const uint64_t j = offset + i;
+    q.P0[j] = mkq(p.o.x, p.o.y, p.o.z, p.d.x);
+    q.P1[j] = mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid));
+    q.P2[j] = mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight);
+    q.FL[j] = p.flags;
+    result[sid] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
   }
 }
 
@@ -163,7 +173,10 @@ struct TestIO {  // gsp_trace
 __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
                                                    const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
                                                    q4* __restrict__ result, uint32_t* __restrict__ counters,
-                                                   DevStats* __restrict__ stats) {
+                                                   uint32_t slot_paths, DevStats* __restrict__ stats) {
+  __shared__ uint32_t s_dead[kMaxSlots];
+  if (threadIdx.x < kMaxSlots) s_dead[threadIdx.x] = 0;
+  __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   // every lane of a wave runs the same number of iterations (ballots need the full wave)
@@ -173,8 +186,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, 
   for (uint32_t it = 0; it < iters; ++it) {
     const uint32_t i = it * stride + blockIdx.x * kBlock + threadIdx.x;
     bool alive = false, has_shadow = false;
+    uint32_t my_sid = 0;
     ShadeOut out;
     if (i < n) {
+      my_sid = fb(cur.P1[i].w);
       const q4 hq = hits[i];
       HitRec h;
       h.t = hq.x;
@@ -200,6 +215,21 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, 
           add_emitted(rc.clamp, out.emitted, r);
           result[in.sid] = r;
         }
+      }
+    }
+    // paths that ended here leave their sample slot's live count (a slot is resolved when it
+    // reaches 0).  Deaths are summed per block in LDS and flushed once at the end of the kernel:
+    // a global atomic per wave per iteration serialises on the few live-counter addresses.
+    {
+      const bool died = (i < n) && !alive;
+      uint64_t dm = __ballot(died);
+      const uint32_t slot = my_sid / slot_paths;
+      while (dm) {  // wave-uniform; lanes of a wave almost always share a slot
+        const int first = __ffsll((unsigned long long)dm) - 1;
+        const uint32_t s0 = (uint32_t)__shfl((int)slot, first);
+        const uint64_t same = __ballot(died && slot == s0) & dm;
+        if ((int)lane == first) atomicAdd(&s_dead[s0], (uint32_t)__popcll(same));
+        dm &= ~same;
       }
     }
     // wave64 compaction of the survivors: ballot + prefix popcount, one atomic per wave
@@ -228,6 +258,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, 
       sq.S3[s] = mkq(r.emis.x, r.emis.y, r.emis.z, ub(alive ? j : 0xffffffffu));
     }
   }
+  __syncthreads();
+  if (threadIdx.x < kMaxSlots && s_dead[threadIdx.x]) atomicSub(&counters[C_LIVE + threadIdx.x], s_dead[threadIdx.x]);
   shaded = wave_sum(shaded);
   if (lane == 0 && shaded) atomicAdd(&stats->shaded, shaded);
 }
@@ -314,7 +346,7 @@ struct gsp_context {
   DevBuf<q4> accum;
 
   // pool
-  uint64_t pool_cap = 0;
+  uint64_t pool_cap = 0, result_cap = 0;
   DevBuf<q4> P0[2], P1[2], P2[2], hits, result, S0, S1, S2, S3;
   DevBuf<uint32_t> FL[2];
   DevBuf<uint32_t> counters;
@@ -351,8 +383,9 @@ struct gsp_context {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, max_blocks()));
   }
   int ensure_spill() {
-    // one stack level per internal node on the deepest path (+ slack)
-    const uint32_t need = bvh.depth + 3 > (uint32_t)kLdsStackDepth ? bvh.depth + 3 - kLdsStackDepth : 1;
+    // ordered descent pushes at most 3 siblings per level of the 4-wide tree (+ sentinel, slack)
+    const uint32_t bound = 3 * bvh.depth + 4;
+    const uint32_t need = bound > (uint32_t)kLdsStackDepth ? bound - kLdsStackDepth : 1;
     spill_stride = max_blocks() * kBlock;
     GSP_HIP_TRY(spill.ensure((size_t)need * spill_stride, &bytes));
     return GSP_OK;
@@ -425,12 +458,13 @@ int gsp_ctx_create(int device, gsp_context** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_counters, 64, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_counters, 1024, hipHostMallocDefault);
   if (e != hipSuccess) {
     set_create_error(std::string("context setup: ") + hipGetErrorString(e));
     delete c;
     return GSP_ERR_DEVICE;
   }
+  std::memset(c->h_counters, 0, 1024);
   *out = c;
   return GSP_OK;
 }
@@ -573,7 +607,19 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uin
   return GSP_OK;
 }
 
-static int ensure_pool(gsp_context* ctx, uint64_t cap) {
+static int ensure_pool(gsp_context* ctx, uint64_t cap, uint64_t result_entries) {
+  if (result_entries > ctx->result_cap) {
+    CTX_TRY(ctx, ctx->result.ensure(result_entries, &ctx->bytes));
+    ctx->result_cap = result_entries;
+  }
+  if (!ctx->counters.p) {
+    CTX_TRY(ctx, ctx->counters.ensure(C_COUNT, &ctx->bytes));
+    CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, C_COUNT * sizeof(uint32_t), ctx->stream));
+  }
+  if (!ctx->dstats.p) {
+    CTX_TRY(ctx, ctx->dstats.ensure(1, &ctx->bytes));
+    CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
+  }
   if (cap <= ctx->pool_cap) return GSP_OK;
   for (int k = 0; k < 2; ++k) {
     CTX_TRY(ctx, ctx->P0[k].ensure(cap, &ctx->bytes));
@@ -582,16 +628,10 @@ static int ensure_pool(gsp_context* ctx, uint64_t cap) {
     CTX_TRY(ctx, ctx->FL[k].ensure(cap, &ctx->bytes));
   }
   CTX_TRY(ctx, ctx->hits.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, ctx->result.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, ctx->S0.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, ctx->S1.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, ctx->S2.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, ctx->S3.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, ctx->counters.ensure(C_COUNT, &ctx->bytes));
-  if (!ctx->dstats.p) {
-    CTX_TRY(ctx, ctx->dstats.ensure(1, &ctx->bytes));
-    CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
-  }
   ctx->pool_cap = cap;
   return GSP_OK;
 }
@@ -611,12 +651,25 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   const auto t_begin = std::chrono::steady_clock::now();
   hipStream_t st = ctx->stream;
   const uint64_t npix = ctx->num_pixels;
-  // samples traced concurrently: fill ~8M paths so the late, sparse bounces still occupy the chip
-  uint64_t K = rp->timestamps_in_flight;
-  if (K == 0) K = std::max<uint64_t>(1, (8ull << 20) / npix);
-  K = std::min<uint64_t>(K, rp->spp);
-  while (K > 1 && K * npix >= (1ull << 31)) --K;
-  int rc = ensure_pool(ctx, K * npix);
+  // Streaming path pool.  Samples enter in batches of Kb timestamps (>= ~1M paths); a new batch is
+  // injected whenever the pool has room, so every launch works on ~8M paths even though 95 % of a
+  // batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
+  // owns a slot of the sample-result ring and is folded into the accumulate buffer, in timestamp
+  // order, once its live count has dropped to zero.
+  uint64_t Kb = rp->timestamps_in_flight;
+  if (Kb == 0) Kb = std::max<uint64_t>(1, (1ull << 20) / npix);
+  Kb = std::min<uint64_t>(Kb, rp->spp);
+  while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
+  const uint64_t batch_paths = Kb * npix;
+  const uint64_t pool_target = std::max<uint64_t>(8ull << 20, 2 * batch_paths);
+  const uint64_t cap = pool_target + batch_paths;
+  const uint32_t num_slots =
+      (uint32_t)std::min<uint64_t>(kMaxSlots, std::max<uint64_t>(4, 8 * ((pool_target + batch_paths - 1) / batch_paths)));
+  if (cap >= (1ull << 32) || (uint64_t)num_slots * batch_paths >= (1ull << 32)) {
+    ctx->err = "frame too large for 32-bit path indices";
+    return GSP_ERR_INVALID;
+  }
+  int rc = ensure_pool(ctx, cap, (uint64_t)num_slots * batch_paths);
   if (rc != GSP_OK) return rc;
 
   RenderConsts rcst;
@@ -648,17 +701,42 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
 
   const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
-  uint32_t done = 0;
-  while (done < rp->spp) {
-    const uint32_t Kp = (uint32_t)std::min<uint64_t>(K, rp->spp - done);
-    const uint32_t t0 = rp->first_timestamp + done;
-    uint64_t n = (uint64_t)Kp * npix;
-    int cur = 0;
-    hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(n)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, Kp, t0,
-                       ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur], ctx->result.p);
-    for (uint32_t bounce = 0; bounce <= rp->max_depth + 1 && n > 0; ++bounce) {
+  struct Batch {
+    uint32_t t0, kb, slot;
+  };
+  std::deque<Batch> inflight;
+  std::vector<char> slot_used(num_slots, 0);
+  uint32_t next_ts = rp->first_timestamp, remaining = rp->spp;
+  uint64_t n = 0;
+  int cur = 0;
+  uint32_t iteration = 0;
+  while (remaining > 0 || n > 0 || !inflight.empty()) {
+    // ---- inject new batches while there is room ----
+    while (remaining > 0 && n < pool_target) {
+      const uint32_t kb = (uint32_t)std::min<uint64_t>(Kb, remaining);
+      uint32_t slot = num_slots;
+      for (uint32_t s2 = 0; s2 < num_slots; ++s2)
+        if (!slot_used[s2]) {
+          slot = s2;
+          break;
+        }
+      if (slot == num_slots || n + (uint64_t)kb * npix > cap) break;
+      const uint64_t paths = (uint64_t)kb * npix;
+      hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, next_ts,
+                         ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur], (uint32_t)n,
+                         (uint32_t)(slot * batch_paths), ctx->result.p);
+      CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->counters.p + C_LIVE + slot), (int)paths, 1, st));
+      slot_used[slot] = 1;
+      inflight.push_back(Batch{next_ts, kb, slot});
+      n += paths;
+      next_ts += kb;
+      remaining -= kb;
+    }
+    if (n > 0) {
+      const uint32_t bounce = iteration++;
       const uint32_t grid = ctx->grid_for(n);
-      CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, C_COUNT * sizeof(uint32_t), st));
+      CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 2 * sizeof(uint32_t), st));
+      CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p + C_WORK_EXT, 0, (C_COUNT - C_WORK_EXT) * sizeof(uint32_t), st));
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[0], st));
       {
         const ExtendIO io{Q[cur], ctx->hits.p};
@@ -674,7 +752,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
       hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
-                         Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, ctx->dstats.p);
+                         Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, (uint32_t)batch_paths, ctx->dstats.p);
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[2], st));
       {
         const ConnectIO io{SQ, Q[cur ^ 1].P2, ctx->result.p, rcst.clamp};
@@ -689,30 +767,42 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
                              ctx->spill.p, ctx->spill_stride, so_sh);
       }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-      CTX_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, 2 * sizeof(uint32_t),
+      CTX_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, (C_LIVE + kMaxSlots) * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, st));
       CTX_TRY(ctx, hipStreamSynchronize(st));
       CTX_TRY(ctx, hipGetLastError());
       ctx->stats.extension_rays += n;
       ctx->stats.shadow_rays += ctx->h_counters[C_SHADOW];
       if (timing) {
-        float ms = 0.0f;
-        CTX_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        ctx->stats.extend_kernel_ms += ms;
+        float ms = 0.0f, e_ms = 0.0f, s_ms = 0.0f;
+        CTX_TRY(ctx, hipEventElapsedTime(&e_ms, ctx->ev[0], ctx->ev[1]));
+        ctx->stats.extend_kernel_ms += e_ms;
         ctx->stats.extend_launches += 1;
-        CTX_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
-        ctx->stats.shade_kernel_ms += ms;
+        CTX_TRY(ctx, hipEventElapsedTime(&s_ms, ctx->ev[1], ctx->ev[2]));
+        ctx->stats.shade_kernel_ms += s_ms;
         CTX_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
         ctx->stats.connect_kernel_ms += ms;
+        if (getenv("GSP_TRACE_BOUNCES"))
+          fprintf(stderr, "iter %3u: n %9llu shadow %9u inflight %2zu | extend %8.3f ms shade %8.3f ms connect %8.3f ms\n",
+                  bounce, (unsigned long long)n, ctx->h_counters[C_SHADOW], inflight.size(), e_ms, s_ms, ms);
       }
       n = ctx->h_counters[C_NEXT];
       cur ^= 1;
     }
-    hipLaunchKernelGGL(k_resolve, dim3(ctx->grid_for(npix)), dim3(kBlock), 0, st, (uint32_t)npix, Kp, t0,
-                       ctx->result.p, ctx->accum.p);
-    CTX_TRY(ctx, hipGetLastError());
-    done += Kp;
-    ctx->stats.samples += (uint64_t)Kp * npix;
+    // ---- fold finished batches into the accumulate buffer, strictly in timestamp order ----
+    while (!inflight.empty() && ctx->h_counters[C_LIVE + inflight.front().slot] == 0) {
+      const Batch b = inflight.front();
+      inflight.pop_front();
+      hipLaunchKernelGGL(k_resolve, dim3(ctx->grid_for(npix)), dim3(kBlock), 0, st, (uint32_t)npix, b.kb, b.t0,
+                         ctx->result.p + (uint64_t)b.slot * batch_paths, ctx->accum.p);
+      CTX_TRY(ctx, hipGetLastError());
+      slot_used[b.slot] = 0;
+      ctx->stats.samples += (uint64_t)b.kb * npix;
+    }
+    if (n == 0 && remaining == 0 && !inflight.empty()) {
+      ctx->err = "internal error: paths exhausted with unresolved sample batches";
+      return GSP_ERR_DEVICE;
+    }
   }
   CTX_TRY(ctx, hipStreamSynchronize(st));
   ctx->stats.render_seconds +=

@@ -33,6 +33,7 @@ struct HitRec {
 };
 
 constexpr int kLeafMaxTris = 4;
+constexpr int32_t kEmptyChild = 0x7ffffffe;  // unused slot of a 4-wide node
 GSP_HD int32_t make_leaf(uint32_t first_slot, uint32_t count) { return ~(int32_t)((first_slot << 2) | (count - 1u)); }
 
 // Watertight ray/triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle

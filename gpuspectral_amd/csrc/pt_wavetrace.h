@@ -172,24 +172,38 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
     const bool leaf_step = __popcll(leaf_m) >= kLeafBatch || node_m == 0;
     if (node_m != 0 && !leaf_step) {
       if (on_node) {
-        const q4* nd = nodes + 4ll * cur;
-        const q4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        // 4-wide node: 7 quads SoA over the children (pt_bvh.hip k_emit4)
+        const q4* nd = nodes + 8ll * cur;
+        const q4 mnx = nd[0], mny = nd[1], mnz = nd[2], mxx = nd[3], mxy = nd[4], mxz = nd[5], cc = nd[6];
         if (STATS) ++c_nodes;
-        float tl, tr;
-        const bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, h.t, tl);
-        const bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, h.t, tr);
-        const int32_t cl = (int32_t)__float_as_uint(q3.x), cr = (int32_t)__float_as_uint(q3.y);
-        if (hl && hr) {
-          const bool left_first = tl <= tr;
-          stk.push(left_first ? cr : cl);
-          cur = left_first ? cl : cr;
-        } else if (hl) {
-          cur = cl;
-        } else if (hr) {
-          cur = cr;
-        } else {
-          cur = stk.pop();
-        }
+        const int32_t c0 = (int32_t)__float_as_uint(cc.x), c1 = (int32_t)__float_as_uint(cc.y),
+                      c2 = (int32_t)__float_as_uint(cc.z), c3 = (int32_t)__float_as_uint(cc.w);
+        float l0, l1, l2, l3;
+        const bool h0 = slab(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, o, inv, tmin, h.t, l0) && c0 != kEmptyChild;
+        const bool h1 = slab(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, o, inv, tmin, h.t, l1) && c1 != kEmptyChild;
+        const bool h2 = slab(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, o, inv, tmin, h.t, l2) && c2 != kEmptyChild;
+        const bool h3 = slab(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, o, inv, tmin, h.t, l3) && c3 != kEmptyChild;
+        // order the hit children by entry distance: sort 4 keys = {distance bits | child slot}
+        uint32_t k0 = h0 ? ((__float_as_uint(l0) & 0x7ffffffcu) | 0u) : 0xffffffffu;
+        uint32_t k1 = h1 ? ((__float_as_uint(l1) & 0x7ffffffcu) | 1u) : 0xffffffffu;
+        uint32_t k2 = h2 ? ((__float_as_uint(l2) & 0x7ffffffcu) | 2u) : 0xffffffffu;
+        uint32_t k3 = h3 ? ((__float_as_uint(l3) & 0x7ffffffcu) | 3u) : 0xffffffffu;
+        uint32_t t;
+#define GSP_CSWAP(a, b) t = min(a, b); b = max(a, b); a = t;
+        GSP_CSWAP(k0, k1)
+        GSP_CSWAP(k2, k3)
+        GSP_CSWAP(k0, k2)
+        GSP_CSWAP(k1, k3)
+        GSP_CSWAP(k1, k2)
+#undef GSP_CSWAP
+        const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+#define GSP_CODE(k) (((k) & 2u) ? (((k) & 1u) ? c3 : c2) : (((k) & 1u) ? c1 : c0))
+        if (nh > 3) stk.push(GSP_CODE(k3));
+        if (nh > 2) stk.push(GSP_CODE(k2));
+        if (nh > 1) stk.push(GSP_CODE(k1));
+        if (nh > 0) cur = GSP_CODE(k0);
+        else cur = stk.pop();
+#undef GSP_CODE
         if (cur < 0 && leaf == 0) {  // first leaf: postpone it and keep descending
           leaf = cur;
           cur = stk.pop();

@@ -209,4 +209,5 @@ def test_size_independent_properties_at_scale(ctx):
     assert st["samples"] == 480 * 270 * 6
     assert st["extension_rays"] >= st["samples"] and st["shaded_vertices"] <= st["extension_rays"]
     assert st["shadow_rays"] <= st["shaded_vertices"]
-    assert st["num_triangles"] == sc.num_triangles and st["num_bvh_nodes"] == sc.num_triangles - 1
+    assert st["num_triangles"] == sc.num_triangles
+    assert sc.num_triangles / 3 < st["num_bvh_nodes"] < sc.num_triangles  # 4-wide nodes: 2..4 children each
