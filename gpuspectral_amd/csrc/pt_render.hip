@@ -170,42 +170,54 @@ struct TestIO {  // gsp_trace
 };
 
 // ---- shade ----------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
-                                                   const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
-                                                   q4* __restrict__ result, uint32_t* __restrict__ counters,
-                                                   uint32_t slot_paths, DevStats* __restrict__ stats) {
+// Block of 1024 threads = 16 waves (4 per SIMD, <= 128 VGPRs).  The two queue tails (next queue,
+// shadow queue) are single words: with one atomic pair per WAVE the ~130k same-address atomics of
+// an 8M-path launch serialise at the ~88/us a single address sustains (MI355X_MICROARCH.md,
+// "dequeue" row) and cost half the kernel.  So survivors are counted per block through LDS and the
+// block reserves its ranges with ONE atomic pair per 1024 paths.
+constexpr int kShadeBlock = 1024;
+constexpr int kShadeWaves = kShadeBlock / 64;
+__global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
+                                                        const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
+                                                        q4* __restrict__ result, uint32_t* __restrict__ counters,
+                                                        uint32_t slot_paths, DevStats* __restrict__ stats) {
   __shared__ uint32_t s_dead[kMaxSlots];
+  __shared__ uint32_t s_cnt[2][kShadeWaves];   // per-wave survivor / shadow counts of this iteration
+  __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave start in the global queues
   if (threadIdx.x < kMaxSlots) s_dead[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  // every lane of a wave runs the same number of iterations (ballots need the full wave)
-  const uint32_t stride = gridDim.x * kBlock;
+  // every thread of the block runs the same number of iterations (barriers inside the loop)
+  const uint32_t stride = gridDim.x * kShadeBlock;
   const uint32_t iters = (n + stride - 1) / stride;
   unsigned long long shaded = 0;
   for (uint32_t it = 0; it < iters; ++it) {
-    const uint32_t i = it * stride + blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = it * stride + blockIdx.x * kShadeBlock + threadIdx.x;
     bool alive = false, has_shadow = false;
     uint32_t my_sid = 0;
     ShadeOut out;
     if (i < n) {
-      my_sid = fb(cur.P1[i].w);
+      // everything that does not depend on the hit is requested up front (one latency, not two)
       const q4 hq = hits[i];
+      const q4 p0 = cur.P0[i], p1 = cur.P1[i], p2 = cur.P2[i];
+      const uint32_t fl = cur.FL[i];
+      my_sid = fb(p1.w);
       HitRec h;
       h.t = hq.x;
       h.u = hq.y;
       h.v = hq.z;
       h.slot = (int32_t)fb(hq.w);
       if (h.slot >= 0) {  // miss: miss.rmiss:15-18, the path ends and adds nothing
-        const q4 p0 = cur.P0[i], p1 = cur.P1[i], p2 = cur.P2[i];
         PathState in;
         in.o = mk3(p0.x, p0.y, p0.z);
         in.d = mk3(p0.w, p1.x, p1.y);
         in.seed = fb(p1.z);
-        in.sid = fb(p1.w);
+        in.sid = my_sid;
         in.weight = mk3(p2.x, p2.y, p2.z);
         in.directWeight = p2.w;
-        in.flags = cur.FL[i];
+        in.flags = fl;
         shade_vertex(S, rc, in, h, out);
         alive = out.alive;
         has_shadow = out.has_shadow;
@@ -218,8 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, 
       }
     }
     // paths that ended here leave their sample slot's live count (a slot is resolved when it
-    // reaches 0).  Deaths are summed per block in LDS and flushed once at the end of the kernel:
-    // a global atomic per wave per iteration serialises on the few live-counter addresses.
+    // reaches 0): summed per block in LDS, flushed once at the end of the kernel
     {
       const bool died = (i < n) && !alive;
       uint64_t dm = __ballot(died);
@@ -232,12 +243,27 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, 
         dm &= ~same;
       }
     }
-    // wave64 compaction of the survivors: ballot + prefix popcount, one atomic per wave
+    // compaction: wave64 ballot + prefix popcount inside the wave, LDS scan over the 16 waves,
+    // one atomic per queue per block
     const uint64_t am = __ballot(alive);
-    uint32_t base = 0;
-    if (lane == 0 && am) base = atomicAdd(&counters[C_NEXT], (uint32_t)__popcll(am));
-    base = __shfl(base, 0);
-    const uint32_t j = base + (uint32_t)__popcll(am & lt_mask);
+    const uint64_t sm = __ballot(has_shadow);
+    if (lane == 0) {
+      s_cnt[0][wave] = (uint32_t)__popcll(am);
+      s_cnt[1][wave] = (uint32_t)__popcll(sm);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const int q = threadIdx.x;
+      uint32_t tot = 0;
+      for (int w = 0; w < kShadeWaves; ++w) tot += s_cnt[q][w];
+      uint32_t base = tot ? atomicAdd(&counters[q == 0 ? C_NEXT : C_SHADOW], tot) : 0u;
+      for (int w = 0; w < kShadeWaves; ++w) {
+        s_base[q][w] = base;
+        base += s_cnt[q][w];
+      }
+    }
+    __syncthreads();
+    const uint32_t j = s_base[0][wave] + (uint32_t)__popcll(am & lt_mask);
     if (alive) {
       const PathState& p = out.next;
       nxt.P0[j] = mkq(p.o.x, p.o.y, p.o.z, p.d.x);
@@ -245,12 +271,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneView S, RenderConsts rc, 
       nxt.P2[j] = mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight);
       nxt.FL[j] = p.flags;
     }
-    const uint64_t sm = __ballot(has_shadow);
-    uint32_t sbase = 0;
-    if (lane == 0 && sm) sbase = atomicAdd(&counters[C_SHADOW], (uint32_t)__popcll(sm));
-    sbase = __shfl(sbase, 0);
     if (has_shadow) {
-      const uint32_t s = sbase + (uint32_t)__popcll(sm & lt_mask);
+      const uint32_t s = s_base[1][wave] + (uint32_t)__popcll(sm & lt_mask);
       const ShadowRay& r = out.shadow;
       sq.S0[s] = mkq(r.o.x, r.o.y, r.o.z, r.tmax);
       sq.S1[s] = mkq(r.d.x, r.d.y, r.d.z, ub(r.sid));
@@ -751,7 +773,9 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
                              ctx->spill_stride, so_ext);
       }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-      hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
+      const uint32_t shade_grid =
+          (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2));
+      hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
                          Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, (uint32_t)batch_paths, ctx->dstats.p);
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[2], st));
       {

@@ -40,7 +40,8 @@ class GspError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libgpuspectral_pt.so")
+    # GSP_LIB_PATH: developer override used to A/B kernel build variants
+    return os.environ.get("GSP_LIB_PATH") or os.path.join(_HERE, "lib", "libgpuspectral_pt.so")
 
 
 def load():
