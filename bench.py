@@ -6,7 +6,7 @@ scene at 1920x1080, on 1/2/4/8 MI355X.
 
   python bench.py --gpus N --steps K --warmup W
 
-* One "step" = `--spp-per-step` samples per pixel over the whole 1920x1080
+* One "step" = `--spp-per-step` (default 64) samples per pixel over the whole 1920x1080
   frame of the generated bathroom2 stand-in (gpuspectral_amd.scenes.interior,
   ~1M triangles, seeded).  Throughput is linear in spp, so K steps of S spp is
   a K*S-spp slice of the 4096-spp target render; the timestamps continue across
@@ -42,9 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tris", type=int, default=1_000_000)
@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--dump", default="", help="write the gathered frame as .npy (rank 0)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo = host tensors, for dry runs)")
     return ap.parse_args()
 
 
@@ -109,8 +111,11 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -121,7 +126,8 @@ def main():
     W, H = args.width, args.height
     ids = multigpu.partition(W, H, rank, world)
 
-    ctx = g.Context(local_rank)
+    # (gloo dry runs may put several ranks on one GPU; RCCL runs use one GPU per rank)
+    ctx = g.Context(local_rank if args.backend == "nccl" else local_rank % max(1, g.device_count()))
     t0 = time.time()
     ctx.upload_scene(sc)
     upload_s = time.time() - t0
@@ -129,11 +135,16 @@ def main():
     npix_local = ctx.num_pixels
     S = args.spp_per_step
 
+    on_gpu = args.backend == "nccl"
+    tdev = "cuda" if on_gpu else "cpu"
+
     def barrier():
         if dist is not None:
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
         ctx.sync()
 
     ts = 0
@@ -151,7 +162,7 @@ def main():
 
     local_t = None
     if dist is not None:
-        local_t = torch.zeros((npix_local, 4), dtype=torch.float32, device="cuda")
+        local_t = torch.zeros((npix_local, 4), dtype=torch.float32, device=tdev)
 
     barrier()
     t_begin = time.perf_counter()
@@ -161,7 +172,10 @@ def main():
     frame = None
     if dist is not None:
         # the single collective of the job: HDR tiles -> rank 0 over xGMI
-        ctx.copy_accum_to_device(local_t.data_ptr(), npix_local * 16)
+        if on_gpu:
+            ctx.copy_accum_to_device(local_t.data_ptr(), npix_local * 16)
+        else:
+            local_t.copy_(torch.from_numpy(ctx.download_compact()))
         frame = multigpu.gather_frame(local_t, W, H, rank, world, dist)
     barrier()
     elapsed = time.perf_counter() - t_begin
@@ -173,7 +187,7 @@ def main():
         np.float64,
     )
     if dist is not None:
-        t = torch.from_numpy(local).cuda()
+        t = torch.from_numpy(local).to(tdev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()

@@ -104,15 +104,21 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     shade[4ull * g + 2] = mkq(n1.x, n1.y, n1.z, 0.0f);
     shade[4ull * g + 3] = mkq(n2.x, n2.y, n2.z, 0.0f);
     const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
+    float l[3], h[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      float l = fminf(px[k], fminf(qx[k], rx[k]));
-      float h = fmaxf(px[k], fmaxf(qx[k], rx[k]));
-      // conservative padding: box culling must never reject a triangle the
-      // triangle test would accept
-      float pad = 1e-5f * fmaxf(fmaxf(fabsf(l), fabsf(h)), 1e-3f) + 1e-6f * (h - l);
-      lo[k] = l - pad;
-      hi[k] = h + pad;
+      l[k] = fminf(px[k], fminf(qx[k], rx[k]));
+      h[k] = fmaxf(px[k], fmaxf(qx[k], rx[k]));
+    }
+    // conservative padding: box culling must never reject a triangle the triangle test would
+    // accept.  It scales with the triangle's own extent as well as with its coordinates, so an
+    // axis-aligned (flat) box at coordinate 0 is still padded.
+    const float diag = fmaxf(h[0] - l[0], fmaxf(h[1] - l[1], h[2] - l[2]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float pad = 1e-5f * fmaxf(fmaxf(fabsf(l[k]), fabsf(h[k])), fmaxf(diag, 1e-3f));
+      lo[k] = l[k] - pad;
+      hi[k] = h[k] + pad;
     }
     box_lo[g] = mkq(lo[0], lo[1], lo[2], 0.0f);
     box_hi[g] = mkq(hi[0], hi[1], hi[2], 0.0f);

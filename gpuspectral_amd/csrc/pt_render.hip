@@ -404,6 +404,15 @@ struct gsp_context {
     uint64_t b = (n + kBlock - 1) / kBlock;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, max_blocks()));
   }
+  // Rays are handed out in `chunk`-sized pieces from kWorkShards counters; chunk c belongs to shard
+  // c % kWorkShards and only blocks with blockIdx % kWorkShards == shard serve it, so the grid must
+  // hold a block for every shard that owns a chunk.
+  uint32_t trace_grid(uint64_t n, uint32_t chunk) const {
+    const uint64_t chunks = (n + chunk - 1) / chunk;
+    const uint64_t by_threads = (n + kTraceBlock - 1) / kTraceBlock;
+    const uint64_t g = std::max<uint64_t>(by_threads, std::min<uint64_t>(chunks, kWorkShards));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, max_blocks()));
+  }
   int ensure_spill() {
     // ordered descent pushes at most 3 siblings per level of the 4-wide tree (+ sentinel, slack)
     const uint32_t bound = 3 * bvh.depth + 4;
@@ -756,7 +765,8 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     }
     if (n > 0) {
       const uint32_t bounce = iteration++;
-      const uint32_t grid = ctx->grid_for(n);
+      const uint32_t chunk = n >= (1u << 20) ? kChunkLarge : kChunkSmall;
+      const uint32_t grid = ctx->trace_grid(n, chunk);
       CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 2 * sizeof(uint32_t), st));
       CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p + C_WORK_EXT, 0, (C_COUNT - C_WORK_EXT) * sizeof(uint32_t), st));
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[0], st));
@@ -765,11 +775,11 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
         uint32_t* work = ctx->counters.p + C_WORK_EXT;
         if (stats_mode)
           hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, work, ctx->spill.p,
+                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, ctx->spill.p,
                              ctx->spill_stride, so_ext);
         else
           hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, work, ctx->spill.p,
+                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, ctx->spill.p,
                              ctx->spill_stride, so_ext);
       }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
@@ -783,11 +793,11 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
         uint32_t* work = ctx->counters.p + C_WORK_SH;
         if (stats_mode)
           hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, io, work,
+                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, chunk, io, work,
                              ctx->spill.p, ctx->spill_stride, so_sh);
         else
           hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, io, work,
+                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, chunk, io, work,
                              ctx->spill.p, ctx->spill_stride, so_sh);
       }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[3], st));
@@ -935,12 +945,12 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   const TestIO io{d_rays.p, d_hits.p, ctx->bvh.slot_to_global, any_hit, ctx->bvh.num_tris};
   const TraceStatsOut none{nullptr, nullptr, nullptr};
   if (any_hit)
-    hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->grid_for(n)), dim3(kTraceBlock), 0, ctx->stream,
-                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, d_work.p,
+    hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
+                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, kChunkSmall, io, d_work.p,
                        ctx->spill.p, ctx->spill_stride, none);
   else
-    hipLaunchKernelGGL((k_trace<false, false, TestIO>), dim3(ctx->grid_for(n)), dim3(kTraceBlock), 0, ctx->stream,
-                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, io, d_work.p,
+    hipLaunchKernelGGL((k_trace<false, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
+                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, kChunkSmall, io, d_work.p,
                        ctx->spill.p, ctx->spill_stride, none);
   CTX_TRY(ctx, hipGetLastError());
   CTX_TRY(ctx, hipMemcpyAsync(hits, d_hits.p, n * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));

@@ -95,7 +95,7 @@ GSP_HD bool intersect_tri(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t
 
 // Slab test.  min/max here are the NaN-dropping IEEE forms, so a NaN from
 // 0*inf (origin on a slab plane, zero direction component) leaves that slab
-// unconstrained: conservative.  The far bound is relaxed by 4 ulp.
+// unconstrained: conservative.  The far bound is relaxed by 8 ulp.
 GSP_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 GSP_HD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 GSP_HD bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv, float tmin,
@@ -106,7 +106,7 @@ GSP_HD bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz
   float lo = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));
   float hi = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), tmax));
   tnear = lo;
-  return lo <= hi * 1.0000004f + 1e-30f;
+  return lo <= hi * 1.000001f;  // 8 ulp of slack on top of the padded boxes
 }
 
 struct TraceCounters {

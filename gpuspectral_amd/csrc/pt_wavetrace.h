@@ -27,9 +27,16 @@ namespace gsp {
 
 constexpr int kTraceBlock = 256;
 constexpr int kLdsStackDepth = 24;          // LDS levels per lane (24 KB per block)
-constexpr int kRefillLanes = 16;            // idle lanes that trigger a refill
-constexpr int kLeafBatch = 20;              // pending leaves that trigger a leaf step
-constexpr uint32_t kChunk = 256;            // rays per hand-out
+#ifndef GSP_REFILL_LANES
+#define GSP_REFILL_LANES 16
+#endif
+#ifndef GSP_LEAF_BATCH
+#define GSP_LEAF_BATCH 20
+#endif
+constexpr int kRefillLanes = GSP_REFILL_LANES;  // idle lanes that trigger a refill
+constexpr int kLeafBatch = GSP_LEAF_BATCH;      // pending leaves that trigger a leaf step
+constexpr uint32_t kChunkLarge = 256;       // rays per hand-out (big queues)
+constexpr uint32_t kChunkSmall = 64;        // ... when the queue is small: one ray per lane, all waves busy
 constexpr int kWorkShards = 8;
 constexpr int kWorkStride = 32;             // counters sit on separate 128-B lines
 constexpr int32_t kSentinel = 0x7fffffff;
@@ -44,17 +51,43 @@ struct WaveStack {
   glb_i32* spill;  // &spill[global thread], stride spill_stride
   uint32_t spill_stride;
   int sp;
+  // Slow, per-lane form: LDS level or HBM spill level.
+  __device__ __forceinline__ void store_at(int level, int32_t v) {
+    if (level < kLdsStackDepth) lds[level * kTraceBlock] = v;
+    else spill[(size_t)(level - kLdsStackDepth) * spill_stride] = v;
+  }
+  __device__ __forceinline__ int32_t load_at(int level) {
+    int32_t v;
+    if (level < kLdsStackDepth) v = lds[level * kTraceBlock];
+    else v = spill[(size_t)(level - kLdsStackDepth) * spill_stride];
+    return v;
+  }
   __device__ __forceinline__ void push(int32_t v) {
-    if (sp < kLdsStackDepth) lds[sp * kTraceBlock] = v;
-    else spill[(size_t)(sp - kLdsStackDepth) * spill_stride] = v;
+    store_at(sp, v);
     ++sp;
   }
+  // Hot path: the LDS-or-spill decision is taken once per wave (a ballot and a scalar branch);
+  // almost always every lane is inside the LDS levels and the access is a bare ds_read/ds_write.
   __device__ __forceinline__ int32_t pop() {
     --sp;
-    int32_t v;
-    if (sp < kLdsStackDepth) v = lds[sp * kTraceBlock];
-    else v = spill[(size_t)(sp - kLdsStackDepth) * spill_stride];
-    return v;
+    if (__builtin_expect(__ballot(sp >= kLdsStackDepth) == 0, 1)) return lds[sp * kTraceBlock];
+    return load_at(sp);
+  }
+  // Pushes the `m` (0..3) entries e1 (nearest of the three) .. e3 (farthest), farthest first, without
+  // branches: an entry that does not exist is written to this lane's scratch level instead.
+  __device__ __forceinline__ void push_sorted(int m, int32_t e1, int32_t e2, int32_t e3) {
+    const int p1 = sp + m - 1, p2 = sp + m - 2, p3 = sp + m - 3;
+    if (__builtin_expect(__ballot(sp + 3 >= kLdsStackDepth - 1) == 0, 1)) {
+      const int scratch = kLdsStackDepth - 1;  // never a live level on this path (sp + 3 < scratch)
+      lds[(m > 0 ? p1 : scratch) * kTraceBlock] = e1;
+      lds[(m > 1 ? p2 : scratch) * kTraceBlock] = e2;
+      lds[(m > 2 ? p3 : scratch) * kTraceBlock] = e3;
+    } else {
+      if (m > 2) store_at(p3, e3);
+      if (m > 1) store_at(p2, e2);
+      if (m > 0) store_at(p1, e1);
+    }
+    sp += m;
   }
 };
 
@@ -76,7 +109,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 template <bool ANY, bool STATS, class IO>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
                                                         int32_t root, const uint32_t* __restrict__ n_ptr,
-                                                        uint32_t n_imm, IO io, uint32_t* __restrict__ work,
+                                                        uint32_t n_imm, uint32_t chunk, IO io,
+                                                        uint32_t* __restrict__ work,
                                                         int32_t* __restrict__ spill, uint32_t spill_stride,
                                                         TraceStatsOut so) {
   __shared__ int32_t lds_stack[kLdsStackDepth * kTraceBlock];
@@ -124,13 +158,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
           uint32_t k = 0;
           if (lane == 0) k = atomicAdd(my_work, 1u);
           k = __shfl(k, 0);
-          const uint64_t start = ((uint64_t)k * kWorkShards + shard) * kChunk;
+          const uint64_t start = ((uint64_t)k * kWorkShards + shard) * chunk;
           if (start >= n) {
             exhausted = true;
             break;
           }
           pool_next = (uint32_t)start;
-          pool_end = (uint32_t)(start + kChunk < n ? start + kChunk : n);
+          pool_end = (uint32_t)(start + chunk < n ? start + chunk : n);
         }
         const uint32_t rank = (uint32_t)__popcll(idle_m & lt_mask);
         const uint32_t avail = pool_end - pool_next;
@@ -198,9 +232,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
 #undef GSP_CSWAP
         const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
 #define GSP_CODE(k) (((k) & 2u) ? (((k) & 1u) ? c3 : c2) : (((k) & 1u) ? c1 : c0))
-        if (nh > 3) stk.push(GSP_CODE(k3));
-        if (nh > 2) stk.push(GSP_CODE(k2));
-        if (nh > 1) stk.push(GSP_CODE(k1));
+        stk.push_sorted(nh > 0 ? nh - 1 : 0, GSP_CODE(k1), GSP_CODE(k2), GSP_CODE(k3));
         if (nh > 0) cur = GSP_CODE(k0);
         else cur = stk.pop();
 #undef GSP_CODE

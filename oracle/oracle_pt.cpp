@@ -124,10 +124,12 @@ static void buildAccel(const gsp_scene_desc& sc, Accel& A) {
     vec3 a = t.v0, b = t.v1, c = t.v2;
     float lo[3] = {std::min(a.x, std::min(b.x, c.x)), std::min(a.y, std::min(b.y, c.y)), std::min(a.z, std::min(b.z, c.z))};
     float hi[3] = {std::max(a.x, std::max(b.x, c.x)), std::max(a.y, std::max(b.y, c.y)), std::max(a.z, std::max(b.z, c.z))};
+    // conservative padding so that box culling never rejects a triangle the triangle test would
+    // accept; it scales with the triangle's extent as well as with its coordinates (flat boxes at
+    // coordinate 0 are padded too)
+    const float diag = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
     for (int k = 0; k < 3; ++k) {
-      // conservative padding so that box culling never rejects a triangle the
-      // triangle test would accept
-      float pad = 1e-5f * std::max(std::max(std::fabs(lo[k]), std::fabs(hi[k])), 1e-3f) + 1e-6f * (hi[k] - lo[k]);
+      float pad = 1e-5f * std::max(std::max(std::fabs(lo[k]), std::fabs(hi[k])), std::max(diag, 1e-3f));
       cmin[3ull * i + k] = lo[k] - pad;
       cmax[3ull * i + k] = hi[k] + pad;
       cen[3ull * i + k] = 0.5f * (lo[k] + hi[k]);
@@ -279,7 +281,7 @@ static inline bool slab(const Node& n, vec3 o, vec3 inv, float tmin, float tmax,
   float lo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
   float hi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
   tnear = lo;
-  return lo <= hi * 1.0000004f + 1e-30f;
+  return lo <= hi * 1.000001f;
 }
 
 // closest hit: smallest t, ties -> smallest global triangle id (a rule that is

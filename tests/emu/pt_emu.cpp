@@ -87,11 +87,16 @@ struct Emu {
         gs.push_back(mkq(n1.x, n1.y, n1.z, 0));
         gs.push_back(mkq(n2.x, n2.y, n2.z, 0));
         const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
+        float l3[3], h3[3];
         for (int c = 0; c < 3; ++c) {
-          float l = std::min(px[c], std::min(qx[c], rx[c])), h = std::max(px[c], std::max(qx[c], rx[c]));
-          float pad = 1e-5f * std::max(std::max(std::fabs(l), std::fabs(h)), 1e-3f) + 1e-6f * (h - l);
-          glo.push_back(l - pad);
-          ghi.push_back(h + pad);
+          l3[c] = std::min(px[c], std::min(qx[c], rx[c]));
+          h3[c] = std::max(px[c], std::max(qx[c], rx[c]));
+        }
+        const float diag = std::max(h3[0] - l3[0], std::max(h3[1] - l3[1], h3[2] - l3[2]));
+        for (int c = 0; c < 3; ++c) {
+          float pad = 1e-5f * std::max(std::max(std::fabs(l3[c]), std::fabs(h3[c])), std::max(diag, 1e-3f));
+          glo.push_back(l3[c] - pad);
+          ghi.push_back(h3[c] + pad);
         }
       }
     }

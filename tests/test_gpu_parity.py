@@ -211,3 +211,44 @@ def test_size_independent_properties_at_scale(ctx):
     assert st["shadow_rays"] <= st["shaded_vertices"]
     assert st["num_triangles"] == sc.num_triangles
     assert sc.num_triangles / 3 < st["num_bvh_nodes"] < sc.num_triangles  # 4-wide nodes: 2..4 children each
+
+
+def test_render_interior_parity_with_oracle(ctx, oracle_mod):
+    """Larger scene (tens of thousands of triangles, 7 material kinds, deep LBVH): image vs oracle.
+    Guards the conservativeness of the GPU box tests (an over-eager cull would change a hit)."""
+    from gpuspectral_amd import scenes
+
+    sc = scenes.interior(40_000)
+    ctx.upload_scene(sc)
+    ctx.frame_begin(160, 90)
+    ctx.render(spp=3)
+    img = ctx.download().reshape(-1, 4)
+    o = oracle_mod.Oracle(sc)
+    ref, _ = o.render(160, 90, spp=3)
+    e = rmse(img, ref)
+    nbad = int((np.abs(img - ref).max(1) > 0).sum())
+    print("interior 3spp rmse %.3e, %d pixels differ" % (e, nbad))
+    assert e < TOL_RMSE
+    rays = random_rays(200000, 17, lo=(-4, 0, -5), hi=(4, 2.6, 5))
+    got, want = ctx.trace(rays), o.trace(rays)
+    assert (got["prim"] == want["prim"]).all()
+    hit = want["prim"] >= 0
+    assert (got["t"][hit] == want["t"][hit]).all()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (17, 5), (40, 23), (65, 31)])
+def test_tiny_frames_and_small_queues(ctx, oracle_mod, materials_scene, size):
+    """Queues of a handful to a few thousand rays: every hand-out shard of the persistent traversal
+    kernel must be served whatever the launch size (a missed chunk leaves stale hit records)."""
+    W, H = size
+    ctx.upload_scene(materials_scene)
+    ctx.frame_begin(W, H)
+    ctx.render(spp=5)
+    img = ctx.download().reshape(-1, 4)
+    ref, st = oracle_mod.Oracle(materials_scene).render(W, H, spp=5)
+    assert np.array_equal(img, ref)
+    ctx.frame_begin(W, H)
+    ctx.reset_stats()
+    ctx.render(spp=5)
+    assert np.array_equal(ctx.download().reshape(-1, 4), ref)
+    assert ctx.stats()["extension_rays"] == st["extension_rays"]
