@@ -212,11 +212,38 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
         if (STATS) ++c_nodes;
         const int32_t c0 = (int32_t)__float_as_uint(cc.x), c1 = (int32_t)__float_as_uint(cc.y),
                       c2 = (int32_t)__float_as_uint(cc.z), c3 = (int32_t)__float_as_uint(cc.w);
-        float l0, l1, l2, l3;
-        const bool h0 = slab(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, o, inv, tmin, h.t, l0) && c0 != kEmptyChild;
-        const bool h1 = slab(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, o, inv, tmin, h.t, l1) && c1 != kEmptyChild;
-        const bool h2 = slab(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, o, inv, tmin, h.t, l2) && c2 != kEmptyChild;
-        const bool h3 = slab(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, o, inv, tmin, h.t, l3) && c3 != kEmptyChild;
+        // four slab tests, two children per packed-f32 instruction (v_pk_add_f32 / v_pk_mul_f32:
+        // the kernel is VALU-issue bound, so halving the instruction count of the 48 subtract /
+        // multiply operations matters).  Same arithmetic as slab() in pt_trace.h.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+        const v2f tmn = {tmin, tmin}, tmx = {h.t, h.t};
+        float lo4[4];
+        bool hit4[4];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const v2f bx0 = pr ? v2f{mnx.z, mnx.w} : v2f{mnx.x, mnx.y}, bx1 = pr ? v2f{mxx.z, mxx.w} : v2f{mxx.x, mxx.y};
+          const v2f by0 = pr ? v2f{mny.z, mny.w} : v2f{mny.x, mny.y}, by1 = pr ? v2f{mxy.z, mxy.w} : v2f{mxy.x, mxy.y};
+          const v2f bz0 = pr ? v2f{mnz.z, mnz.w} : v2f{mnz.x, mnz.y}, bz1 = pr ? v2f{mxz.z, mxz.w} : v2f{mxz.x, mxz.y};
+          const v2f t0x = (bx0 - ox) * ix, t1x = (bx1 - ox) * ix;
+          const v2f t0y = (by0 - oy) * iy, t1y = (by1 - oy) * iy;
+          const v2f t0z = (bz0 - oz) * iz, t1z = (bz1 - oz) * iz;
+          const v2f lo = __builtin_elementwise_max(
+              __builtin_elementwise_max(__builtin_elementwise_min(t0x, t1x), __builtin_elementwise_min(t0y, t1y)),
+              __builtin_elementwise_max(__builtin_elementwise_min(t0z, t1z), tmn));
+          const v2f hi = __builtin_elementwise_min(
+              __builtin_elementwise_min(__builtin_elementwise_max(t0x, t1x), __builtin_elementwise_max(t0y, t1y)),
+              __builtin_elementwise_min(__builtin_elementwise_max(t0z, t1z), tmx));
+          const v2f hs = hi * v2f{1.000001f, 1.000001f};
+          lo4[2 * pr] = lo.x;
+          lo4[2 * pr + 1] = lo.y;
+          hit4[2 * pr] = lo.x <= hs.x;
+          hit4[2 * pr + 1] = lo.y <= hs.y;
+        }
+        const float l0 = lo4[0], l1 = lo4[1], l2 = lo4[2], l3 = lo4[3];
+        const bool h0 = hit4[0] && c0 != kEmptyChild, h1 = hit4[1] && c1 != kEmptyChild,
+                   h2 = hit4[2] && c2 != kEmptyChild, h3 = hit4[3] && c3 != kEmptyChild;
         // order the hit children by entry distance: sort 4 keys = {distance bits | child slot}
         uint32_t k0 = h0 ? ((__float_as_uint(l0) & 0x7ffffffcu) | 0u) : 0xffffffffu;
         uint32_t k1 = h1 ? ((__float_as_uint(l1) & 0x7ffffffcu) | 1u) : 0xffffffffu;

@@ -1,0 +1,14 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gpuspectral_amd as g
+from gpuspectral_amd import scenes
+sc = scenes.interior(1_000_000)
+with g.Context(0) as ctx:
+    ctx.upload_scene(sc); ctx.frame_begin(1920, 1080); ctx.render(spp=8); ts = 8
+    best = None
+    for rep in range(2):
+        ctx.reset_stats(); t = time.time(); ctx.render(spp=48, first_timestamp=ts, collect_kernel_times=1); dt = time.time() - t; ts += 48
+        st = ctx.stats()
+        r = ((st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, st["extend_kernel_ms"], st["shade_kernel_ms"], st["connect_kernel_ms"])
+        best = r if best is None or r[0] > best[0] else best
+    print("%.1f Mrays/s | extend %.1f shade %.1f connect %.1f ms" % best, flush=True)
