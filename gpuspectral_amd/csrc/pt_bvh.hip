@@ -14,14 +14,19 @@
 //   morton    63-bit Morton code of the box centre
 //   sort      rocPRIM radix sort of (code, triangle) pairs
 //   scatter   packets into leaf (Morton) order -> coherent rays touch adjacent HBM lines
-//   hierarchy Karras 2012 binary radix tree over the sorted codes
+//   hierarchy binary tree over the Morton-sorted leaves: PLOC (parallel locally-ordered clustering,
+//             Meister & Bittner 2018: repeatedly merge mutual nearest neighbours, by merged surface
+//             area, within a window of the cluster array) -- near-SAH quality; the Karras 2012 radix
+//             tree (LBVH) is kept behind GSP_BVH=lbvh for comparison
 //   fit       bottom-up boxes of the binary tree (each binary node holds both child boxes)
 //   collapse  binary tree -> 4-wide BVH: every binary node at even depth becomes one 128-B
 //             node whose children are its grandchildren (leaf children stay as they are), so
 //             a ray makes half as many dependent node fetches; node index = exclusive scan of
 //             the even-depth flags (rocPRIM), which keeps the Morton locality of the LBVH
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -304,6 +309,91 @@ __global__ __launch_bounds__(kBlock) void k_depth(int n, const int32_t* __restri
   if ((threadIdx.x & 63) == 0 && depth) atomicMax(max_depth, depth);
 }
 
+// ---- PLOC ------------------------------------------------------------------------------------
+#ifndef GSP_PLOC_RADIUS
+#define GSP_PLOC_RADIUS 32
+#endif
+constexpr int kPlocRadius = GSP_PLOC_RADIUS;
+
+__device__ __forceinline__ float half_area(const q4& lo, const q4& hi) {
+  const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+  return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ploc_init(int n, int32_t* __restrict__ code) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) code[i] = make_leaf((uint32_t)i, 1);
+}
+
+// nearest neighbour of every cluster inside the window [i - R, i + R]: smallest merged half-area
+__global__ __launch_bounds__(kBlock) void k_ploc_nn(int n, const q4* __restrict__ lo, const q4* __restrict__ hi,
+                                                    int32_t* __restrict__ nn) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const q4 a_lo = lo[i], a_hi = hi[i];
+  float best = 3.0e38f;
+  int best_j = i > 0 ? i - 1 : i + 1;
+  const int j0 = max(0, i - kPlocRadius), j1 = min(n - 1, i + kPlocRadius);
+  for (int j = j0; j <= j1; ++j) {
+    if (j == i) continue;
+    const q4 b_lo = lo[j], b_hi = hi[j];
+    const q4 m_lo = mkq(fminf(a_lo.x, b_lo.x), fminf(a_lo.y, b_lo.y), fminf(a_lo.z, b_lo.z), 0.0f);
+    const q4 m_hi = mkq(fmaxf(a_hi.x, b_hi.x), fmaxf(a_hi.y, b_hi.y), fmaxf(a_hi.z, b_hi.z), 0.0f);
+    const float a = half_area(m_lo, m_hi);
+    if (a < best) {
+      best = a;
+      best_j = j;
+    }
+  }
+  nn[i] = best_j;
+}
+
+// keep[i] = 0 for the right partner of a mutual pair (it disappears), isnew[i] = 1 for the left one
+__global__ __launch_bounds__(kBlock) void k_ploc_flags(int n, const int32_t* __restrict__ nn,
+                                                       uint32_t* __restrict__ keep, uint32_t* __restrict__ isnew) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int j = nn[i];
+  const bool mutual = nn[j] == i;
+  keep[i] = (mutual && i > j) ? 0u : 1u;
+  isnew[i] = (mutual && i < j) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ploc_apply(int n, const int32_t* __restrict__ nn,
+                                                       const uint32_t* __restrict__ keep,
+                                                       const uint32_t* __restrict__ isnew,
+                                                       const uint32_t* __restrict__ kpos,
+                                                       const uint32_t* __restrict__ npos, uint32_t node_base,
+                                                       const int32_t* __restrict__ code_in, const q4* __restrict__ lo_in,
+                                                       const q4* __restrict__ hi_in, int32_t* __restrict__ code_out,
+                                                       q4* __restrict__ lo_out, q4* __restrict__ hi_out,
+                                                       q4* __restrict__ nodes2, int32_t* __restrict__ parent_int,
+                                                       int32_t* __restrict__ parent_leaf) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || !keep[i]) return;
+  const uint32_t p = kpos[i];
+  if (!isnew[i]) {
+    code_out[p] = code_in[i];
+    lo_out[p] = lo_in[i];
+    hi_out[p] = hi_in[i];
+    return;
+  }
+  const int j = nn[i];
+  const int32_t id = (int32_t)(node_base + npos[i]);
+  const int32_t cl = code_in[i], cr = code_in[j];
+  const q4 llo = lo_in[i], lhi = hi_in[i], rlo = lo_in[j], rhi = hi_in[j];
+  q4* N = nodes2 + 4ll * id;
+  N[0] = mkq(llo.x, llo.y, llo.z, lhi.x);
+  N[1] = mkq(lhi.y, lhi.z, rlo.x, rlo.y);
+  N[2] = mkq(rlo.z, rhi.x, rhi.y, rhi.z);
+  N[3] = mkq(__uint_as_float((uint32_t)cl), __uint_as_float((uint32_t)cr), 0.0f, 0.0f);
+  if (cl < 0) parent_leaf[((uint32_t)~cl) >> 2] = id; else parent_int[cl] = id;
+  if (cr < 0) parent_leaf[((uint32_t)~cr) >> 2] = id; else parent_int[cr] = id;
+  code_out[p] = id;
+  lo_out[p] = mkq(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.0f);
+  hi_out[p] = mkq(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
+}
+
 // flag[i] = 1 when binary node i sits at even depth (root = depth 0)
 __global__ __launch_bounds__(kBlock) void k_flag_even(int n_int, const int32_t* __restrict__ parent_int,
                                                       uint32_t* __restrict__ flag) {
@@ -471,10 +561,55 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, vals_out, isect_g, shade_g, lo_g, hi_g,
                      out.tri_isect, out.tri_shade, leaf_lo, leaf_hi, out.slot_to_global);
   if (n >= 2) {
-    hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(n - 1)), dim3(kBlock), 0, stream, (int)n, keys_out, child_l, child_r,
-                       parent_int, parent_leaf);
-    hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, child_l, child_r, parent_int,
-                       parent_leaf, leaf_lo, leaf_hi, int_lo, int_hi, arrive, nodes2, d_depth);
+    int32_t root2 = 0;  // binary root
+    const char* mode = getenv("GSP_BVH");
+    if (mode && std::string(mode) == "lbvh") {
+      hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(n - 1)), dim3(kBlock), 0, stream, (int)n, keys_out, child_l, child_r,
+                         parent_int, parent_leaf);
+      hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, child_l, child_r, parent_int,
+                         parent_leaf, leaf_lo, leaf_hi, int_lo, int_hi, arrive, nodes2, d_depth);
+    } else {
+      // PLOC: cluster arrays ping-pong between (code_a, leaf_lo/hi) and (code_b, int_lo/hi)
+      int32_t *code_a = child_l, *code_b = child_r, *nn = (int32_t*)arrive;
+      uint32_t *keep = flag, *isnew = idx4, *kpos, *npos;
+      GSP_HIP_TRY(S.alloc(&kpos, n + 1ull));
+      GSP_HIP_TRY(S.alloc(&npos, n + 1ull));
+      size_t sb = 0;
+      GSP_HIP_TRY(rocprim::exclusive_scan(nullptr, sb, keep, kpos, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+      void* stmp = nullptr;
+      GSP_HIP_TRY(S.alloc((char**)&stmp, sb));
+      GSP_HIP_TRY(hipMemsetAsync(parent_int, 0xff, sizeof(int32_t) * n, stream));
+      GSP_HIP_TRY(hipMemsetAsync(parent_leaf, 0xff, sizeof(int32_t) * n, stream));
+      hipLaunchKernelGGL(k_ploc_init, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, code_a);
+      q4 *lo_a = leaf_lo, *hi_a = leaf_hi, *lo_b = int_lo, *hi_b = int_hi;
+      uint32_t m = n, node_base = 0;
+      while (m > 1) {
+        hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(m)), dim3(kBlock), 0, stream, (int)m, lo_a, hi_a, nn);
+        hipLaunchKernelGGL(k_ploc_flags, dim3(blocks_for(m)), dim3(kBlock), 0, stream, (int)m, nn, keep, isnew);
+        GSP_HIP_TRY(hipMemsetAsync(keep + m, 0, sizeof(uint32_t), stream));
+        GSP_HIP_TRY(hipMemsetAsync(isnew + m, 0, sizeof(uint32_t), stream));
+        GSP_HIP_TRY(rocprim::exclusive_scan(stmp, sb, keep, kpos, 0u, (size_t)m + 1, rocprim::plus<uint32_t>(), stream));
+        GSP_HIP_TRY(rocprim::exclusive_scan(stmp, sb, isnew, npos, 0u, (size_t)m + 1, rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(k_ploc_apply, dim3(blocks_for(m)), dim3(kBlock), 0, stream, (int)m, nn, keep, isnew, kpos, npos,
+                           node_base, code_a, lo_a, hi_a, code_b, lo_b, hi_b, nodes2, parent_int, parent_leaf);
+        uint32_t counts[2] = {0, 0};
+        GSP_HIP_TRY(hipMemcpyAsync(&counts[0], kpos + m, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        GSP_HIP_TRY(hipMemcpyAsync(&counts[1], npos + m, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        GSP_HIP_TRY(hipStreamSynchronize(stream));
+        if (counts[1] == 0 || counts[0] != m - counts[1]) {
+          err = "PLOC made no progress (internal error)";
+          return GSP_ERR_DEVICE;
+        }
+        node_base += counts[1];
+        m = counts[0];
+        std::swap(code_a, code_b);
+        std::swap(lo_a, lo_b);
+        std::swap(hi_a, hi_b);
+      }
+      GSP_HIP_TRY(hipMemcpyAsync(&root2, code_a, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+      GSP_HIP_TRY(hipStreamSynchronize(stream));
+      // leaf_lo/leaf_hi may have been overwritten by the ping-pong: nothing below reads them again
+    }
     hipLaunchKernelGGL(k_depth, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, parent_int, parent_leaf, d_depth);
     // ---- collapse to the 4-wide tree ----
     const int n_int = (int)n - 1;
@@ -493,7 +628,10 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
     out.bytes += b_nodes;
     hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes);
-    out.root = 0;
+    uint32_t root4 = 0;  // the binary root has depth 0, so it owns a 4-wide node
+    GSP_HIP_TRY(hipMemcpyAsync(&root4, idx4 + root2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSP_HIP_TRY(hipStreamSynchronize(stream));
+    out.root = (int32_t)root4;
   }
   GSP_HIP_TRY(hipGetLastError());
   uint32_t depth = 0;
