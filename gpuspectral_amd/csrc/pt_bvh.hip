@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     const f3 e1 = p1 - p0, e2 = p2 - p0;
     const f3 N = normalize(cross(e1, e2));  // rayhit.rchit:694
     isect[3ull * g + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float(g));
-    isect[3ull * g + 1] = mkq(p1.x, p1.y, p1.z, 0.0f);
+    isect[3ull * g + 1] = mkq(p1.x, p1.y, p1.z, __uint_as_float(I.bsdf >> 16));  // BSDF type of the hit, for the shade sort
     isect[3ull * g + 2] = mkq(p2.x, p2.y, p2.z, 0.0f);
     shade[4ull * g + 0] = mkq(N.x, N.y, N.z, __uint_as_float(a));
     shade[4ull * g + 1] = mkq(n0.x, n0.y, n0.z, 0.0f);

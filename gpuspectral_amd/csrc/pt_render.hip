@@ -117,8 +117,9 @@ struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
     tmin = 0.0f;
     tmax = 1e10f;
   }
-  __device__ __forceinline__ void store(uint32_t i, const HitRec& h) const {
-    hits[i] = mkq(h.t, h.u, h.v, ub((uint32_t)h.slot));
+  // hit word: slot in bits 0..27, BSDF type of the hit triangle in bits 28..30; miss = all ones
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux) const {
+    hits[i] = mkq(h.t, h.u, h.v, ub(h.slot < 0 ? 0xffffffffu : ((uint32_t)h.slot | ((aux & 7u) << 28))));
   }
 };
 
@@ -134,7 +135,7 @@ struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any h
     tmin = 0.01f;
     tmax = s0.w;
   }
-  __device__ __forceinline__ void store(uint32_t i, const HitRec& h) const {
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t) const {
     const q4 s1 = sq.S1[i], s2 = sq.S2[i], s3 = sq.S3[i];
     ShadowRay r;
     r.nee = mk3(s2.x, s2.y, s2.z);
@@ -162,7 +163,7 @@ struct TestIO {  // gsp_trace
     tmin = r[3];
     tmax = r[7];
   }
-  __device__ __forceinline__ void store(uint32_t i, const HitRec& h) const {
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t) const {
     const bool hit = h.slot >= 0 && num_tris != 0;
     if (any_hit) hits[i] = mkq(0.0f, 0.0f, 0.0f, ub(hit ? 0u : 0xffffffffu));
     else hits[i] = hit ? mkq(h.t, h.u, h.v, ub(slot_to_global[h.slot])) : mkq(0.0f, 0.0f, 0.0f, ub(0xffffffffu));
@@ -182,6 +183,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts
                                                         q4* __restrict__ result, uint32_t* __restrict__ counters,
                                                         uint32_t slot_paths, DevStats* __restrict__ stats) {
   __shared__ uint32_t s_dead[kMaxSlots];
+  __shared__ uint32_t s_bin[12];               // counting sort of the tile by BSDF type: counts, then starts
+  __shared__ uint16_t s_order[kShadeBlock];    // sorted position -> thread offset inside the tile
   __shared__ uint32_t s_cnt[2][kShadeWaves];   // per-wave survivor / shadow counts of this iteration
   __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave start in the global queues
   if (threadIdx.x < kMaxSlots) s_dead[threadIdx.x] = 0;
@@ -194,7 +197,34 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts
   const uint32_t iters = (n + stride - 1) / stride;
   unsigned long long shaded = 0;
   for (uint32_t it = 0; it < iters; ++it) {
-    const uint32_t i = it * stride + blockIdx.x * kShadeBlock + threadIdx.x;
+    // ---- order the tile by the BSDF type of the hit (8 = miss, 9 = beyond the queue) so that the
+    // lanes of a wave run the same branch of the 8-way BSDF switch (rayhit.rchit:630-654): LDS
+    // counting sort of 1024 keys
+    const uint32_t tile = it * stride + blockIdx.x * kShadeBlock;
+    {
+      if (threadIdx.x < 12) s_bin[threadIdx.x] = 0;
+      __syncthreads();
+      const uint32_t i0 = tile + threadIdx.x;
+      uint32_t key = 9;
+      if (i0 < n) {
+        const uint32_t w = fb(hits[i0].w);
+        key = (w == 0xffffffffu) ? 8u : ((w >> 28) & 7u);
+      }
+      const uint32_t rank = atomicAdd(&s_bin[key], 1u);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 10; ++k) {
+          const uint32_t c = s_bin[k];
+          s_bin[k] = acc;
+          acc += c;
+        }
+      }
+      __syncthreads();
+      s_order[s_bin[key] + rank] = (uint16_t)threadIdx.x;
+      __syncthreads();
+    }
+    const uint32_t i = tile + s_order[threadIdx.x];
     bool alive = false, has_shadow = false;
     uint32_t my_sid = 0;
     ShadeOut out;
@@ -208,7 +238,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts
       h.t = hq.x;
       h.u = hq.y;
       h.v = hq.z;
-      h.slot = (int32_t)fb(hq.w);
+      {
+        const uint32_t w = fb(hq.w);
+        h.slot = (w == 0xffffffffu) ? -1 : (int32_t)(w & 0x0fffffffu);
+      }
       if (h.slot >= 0) {  // miss: miss.rmiss:15-18, the path ends and adds nothing
         PathState in;
         in.o = mk3(p0.x, p0.y, p0.z);
@@ -530,8 +563,8 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     }
     total_tris += in.vertex_count / 3;
   }
-  if (total_tris >= (1ull << 29)) {
-    ctx->err = "too many triangles (limit 2^29)";
+  if (total_tris >= (1ull << 28)) {
+    ctx->err = "too many triangles (limit 2^28)";
     return GSP_ERR_SCENE;
   }
   if ((sc->num_instances && !sc->instances) || (sc->num_vertices && (!sc->positions || !sc->normals)) ||

@@ -14,7 +14,7 @@
 //           child <  0 : leaf, c = ~child, first slot = c >> 2, count = (c & 3) + 1
 //   triangle packet (48 B, in BVH leaf order):
 //                  p0 = {v0.x, v0.y, v0.z, bits(global triangle id)}
-//                  p1 = {v1.x, v1.y, v1.z, -}
+//                  p1 = {v1.x, v1.y, v1.z, bits(BSDF type of the owning instance)}
 //                  p2 = {v2.x, v2.y, v2.z, -}
 //   Closest hit = smallest t, ties broken by the smaller global triangle id, so
 //   the result does not depend on the BVH topology or traversal order.

@@ -105,7 +105,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 
 // IO contract:
 //   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const;
-//   __device__ void store(uint32_t i, const HitRec& h) const;   // h.slot < 0: miss / unoccluded
+//   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux) const;   // h.slot < 0: miss / unoccluded;
+//                                                  aux = p1.w of the accepted triangle (BSDF type)
 template <bool ANY, bool STATS, class IO>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
                                                         int32_t root, const uint32_t* __restrict__ n_ptr,
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
 
   // per-lane ray state
   int32_t cur = kSentinel, leaf = 0;
-  uint32_t ri = 0xffffffffu, best_id = 0xffffffffu;
+  uint32_t ri = 0xffffffffu, best_id = 0xffffffffu, best_aux = 0;
   f3 o = mk3(0, 0, 0), inv = mk3(0, 0, 0);
   RayShear rs;
   rs.kx = rs.ky = rs.kz = 0;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
   for (;;) {
     // ---- commit finished rays ------------------------------------------------------------
     if (ri != 0xffffffffu && cur == kSentinel && leaf == 0) {
-      io.store(ri, h);
+      io.store(ri, h, best_aux);
       ri = 0xffffffffu;
     }
     // ---- refill idle lanes from the wave-local pool -----------------------------------------
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
             h.v = v;
             h.slot = (int32_t)(first + k);
             best_id = id;
+            best_aux = __float_as_uint(p1.w);
           }
         }
       }
