@@ -19,10 +19,12 @@
 //             area, within a window of the cluster array) -- near-SAH quality; the Karras 2012 radix
 //             tree (LBVH) is kept behind GSP_BVH=lbvh for comparison
 //   fit       bottom-up boxes of the binary tree (each binary node holds both child boxes)
-//   collapse  binary tree -> 4-wide BVH: every binary node at even depth becomes one 128-B
-//             node whose children are its grandchildren (leaf children stay as they are), so
-//             a ray makes half as many dependent node fetches; node index = exclusive scan of
-//             the even-depth flags (rocPRIM), which keeps the Morton locality of the LBVH
+//   collapse  binary tree -> 4-wide BVH (128-B nodes): every binary node at even depth becomes one
+//             node whose children are its grandchildren (leaf children stay), so a ray makes half
+//             as many dependent node fetches; node index = exclusive scan of the even-depth flags
+//             (rocPRIM), which keeps the locality of the binary numbering.  GSP_COLLAPSE=greedy
+//             selects a breadth-first greedy surface-area collapse (always 4 children where
+//             possible): measured within +-3 % of the parity collapse, so it is not the default.
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -459,6 +461,77 @@ __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restric
   o[7] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+// Greedy 4-wide collapse, one thread per output node of the current level.
+// work item = {binary node id, 4-wide node id}
+__global__ __launch_bounds__(kBlock) void k_collapse4(int count, const int2* __restrict__ qin,
+                                                      const q4* __restrict__ nodes2, q4* __restrict__ nodes4,
+                                                      uint32_t* __restrict__ next_id, int2* __restrict__ qout,
+                                                      uint32_t* __restrict__ qout_count) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= count) return;
+  const int2 w = qin[t];
+  Entry4 e[4];
+  int cnt = 0;
+  auto load2 = [&](int32_t b, Entry4& x, Entry4& y) {
+    const q4* m = nodes2 + 4ll * b;
+    const q4 a = m[0], bq = m[1], d = m[2], k = m[3];
+    x.lo = mkq(a.x, a.y, a.z, 0.0f);
+    x.hi = mkq(a.w, bq.x, bq.y, 0.0f);
+    x.code = (int32_t)__float_as_uint(k.x);
+    y.lo = mkq(bq.z, bq.w, d.x, 0.0f);
+    y.hi = mkq(d.y, d.z, d.w, 0.0f);
+    y.code = (int32_t)__float_as_uint(k.y);
+  };
+  load2(w.x, e[0], e[1]);
+  cnt = 2;
+  while (cnt < 4) {
+    int best = -1;
+    float best_area = -1.0f;
+    for (int k = 0; k < cnt; ++k) {
+      if (e[k].code < 0) continue;
+      const float ar = half_area(e[k].lo, e[k].hi);
+      if (ar > best_area) {
+        best_area = ar;
+        best = k;
+      }
+    }
+    if (best < 0) break;
+    Entry4 x, y;
+    load2(e[best].code, x, y);
+    e[best] = x;
+    e[cnt++] = y;
+  }
+  // inner children become work items of the next level; their 4-wide ids are consecutive
+  int inner = 0;
+  for (int k = 0; k < cnt; ++k) inner += e[k].code >= 0 ? 1 : 0;
+  uint32_t id0 = 0, q0 = 0;
+  if (inner) {
+    id0 = atomicAdd(next_id, (uint32_t)inner);
+    q0 = atomicAdd(qout_count, (uint32_t)inner);
+  }
+  for (int k = 0; k < cnt; ++k) {
+    if (e[k].code >= 0) {
+      qout[q0++] = make_int2(e[k].code, (int)id0);
+      e[k].code = (int32_t)id0++;
+    }
+  }
+  for (; cnt < 4; ++cnt) {
+    e[cnt].lo = mkq(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);
+    e[cnt].hi = e[cnt].lo;
+    e[cnt].code = kEmptyChild;
+  }
+  q4* o = nodes4 + 8ll * w.y;
+  o[0] = mkq(e[0].lo.x, e[1].lo.x, e[2].lo.x, e[3].lo.x);
+  o[1] = mkq(e[0].lo.y, e[1].lo.y, e[2].lo.y, e[3].lo.y);
+  o[2] = mkq(e[0].lo.z, e[1].lo.z, e[2].lo.z, e[3].lo.z);
+  o[3] = mkq(e[0].hi.x, e[1].hi.x, e[2].hi.x, e[3].hi.x);
+  o[4] = mkq(e[0].hi.y, e[1].hi.y, e[2].hi.y, e[3].hi.y);
+  o[5] = mkq(e[0].hi.z, e[1].hi.z, e[2].hi.z, e[3].hi.z);
+  o[6] = mkq(__uint_as_float((uint32_t)e[0].code), __uint_as_float((uint32_t)e[1].code),
+             __uint_as_float((uint32_t)e[2].code), __uint_as_float((uint32_t)e[3].code));
+  o[7] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 struct Scratch {
   std::vector<void*> ptrs;
   size_t bytes = 0;
@@ -543,6 +616,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(S.alloc(&flag, n + 1ull));
   GSP_HIP_TRY(S.alloc(&idx4, n + 1ull));
 
+  uint32_t collapse_levels = 0;
   const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
   GSP_HIP_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
   GSP_HIP_TRY(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, stream));
@@ -613,31 +687,66 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     hipLaunchKernelGGL(k_depth, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, parent_int, parent_leaf, d_depth);
     // ---- collapse to the 4-wide tree ----
     const int n_int = (int)n - 1;
-    GSP_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t) * (n + 1ull), stream));
-    hipLaunchKernelGGL(k_flag_even, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, parent_int, flag);
-    size_t scan_bytes = 0;
-    GSP_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
-    void* scan_tmp = nullptr;
-    GSP_HIP_TRY(S.alloc((char**)&scan_tmp, scan_bytes));
-    GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
-    uint32_t n4 = 0;
-    GSP_HIP_TRY(hipMemcpyAsync(&n4, idx4 + n_int, sizeof(n4), hipMemcpyDeviceToHost, stream));
-    GSP_HIP_TRY(hipStreamSynchronize(stream));
-    out.num_nodes = n4;
-    const size_t b_nodes = (size_t)std::max<uint32_t>(n4, 1) * 128;
-    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
-    out.bytes += b_nodes;
-    hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes);
-    uint32_t root4 = 0;  // the binary root has depth 0, so it owns a 4-wide node
-    GSP_HIP_TRY(hipMemcpyAsync(&root4, idx4 + root2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSP_HIP_TRY(hipStreamSynchronize(stream));
-    out.root = (int32_t)root4;
+    const char* cmode = getenv("GSP_COLLAPSE");
+    if (!(cmode && std::string(cmode) == "greedy")) {
+      GSP_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t) * (n + 1ull), stream));
+      hipLaunchKernelGGL(k_flag_even, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, parent_int, flag);
+      size_t scan_bytes = 0;
+      GSP_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
+      void* scan_tmp = nullptr;
+      GSP_HIP_TRY(S.alloc((char**)&scan_tmp, scan_bytes));
+      GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
+      uint32_t n4 = 0;
+      GSP_HIP_TRY(hipMemcpyAsync(&n4, idx4 + n_int, sizeof(n4), hipMemcpyDeviceToHost, stream));
+      GSP_HIP_TRY(hipStreamSynchronize(stream));
+      out.num_nodes = n4;
+      const size_t b_nodes = (size_t)std::max<uint32_t>(n4, 1) * 128;
+      GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
+      out.bytes += b_nodes;
+      hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes);
+      uint32_t root4 = 0;  // the binary root has depth 0, so it owns a 4-wide node
+      GSP_HIP_TRY(hipMemcpyAsync(&root4, idx4 + root2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      GSP_HIP_TRY(hipStreamSynchronize(stream));
+      out.root = (int32_t)root4;
+      collapse_levels = 0;
+    } else {
+      // greedy SAH collapse, breadth-first; at most n - 1 output nodes
+      q4* all4 = nullptr;
+      GSP_HIP_TRY(hipMalloc((void**)&all4, (size_t)n_int * 128));
+      int2 *qa, *qb;
+      uint32_t* ctr;  // [0] next node id, [1] next-level queue size
+      GSP_HIP_TRY(S.alloc(&qa, (size_t)n_int));
+      GSP_HIP_TRY(S.alloc(&qb, (size_t)n_int));
+      GSP_HIP_TRY(S.alloc(&ctr, 2));
+      const int2 first = make_int2(root2, 0);
+      const uint32_t init[2] = {1u, 0u};
+      GSP_HIP_TRY(hipMemcpyAsync(qa, &first, sizeof(first), hipMemcpyHostToDevice, stream));
+      GSP_HIP_TRY(hipMemcpyAsync(ctr, init, sizeof(init), hipMemcpyHostToDevice, stream));
+      uint32_t count = 1, total = 1;
+      collapse_levels = 0;
+      while (count > 0) {
+        hipLaunchKernelGGL(k_collapse4, dim3(blocks_for(count)), dim3(kBlock), 0, stream, (int)count, qa, nodes2, all4,
+                           ctr, qb, ctr + 1);
+        uint32_t h[2];
+        GSP_HIP_TRY(hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
+        GSP_HIP_TRY(hipStreamSynchronize(stream));
+        GSP_HIP_TRY(hipMemsetAsync(ctr + 1, 0, sizeof(uint32_t), stream));
+        total = h[0];
+        count = h[1];
+        std::swap(qa, qb);
+        ++collapse_levels;
+      }
+      out.nodes = all4;
+      out.num_nodes = total;
+      out.bytes += (size_t)n_int * 128;
+      out.root = 0;
+    }
   }
   GSP_HIP_TRY(hipGetLastError());
   uint32_t depth = 0;
   GSP_HIP_TRY(hipMemcpyAsync(&depth, d_depth, sizeof(depth), hipMemcpyDeviceToHost, stream));
   GSP_HIP_TRY(hipStreamSynchronize(stream));
-  out.depth = depth / 2 + 1;  // levels of the 4-wide tree
+  out.depth = collapse_levels ? collapse_levels : depth / 2 + 1;  // levels of the 4-wide tree
   return GSP_OK;
 }
 

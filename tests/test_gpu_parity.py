@@ -252,3 +252,21 @@ def test_tiny_frames_and_small_queues(ctx, oracle_mod, materials_scene, size):
     ctx.render(spp=5)
     assert np.array_equal(ctx.download().reshape(-1, 4), ref)
     assert ctx.stats()["extension_rays"] == st["extension_rays"]
+
+
+def test_deep_dielectric_paths_max_depth_32(ctx, oracle_mod):
+    """BASELINE config 5 at test size: dielectric-heavy scene, max_depth 32 (all-delta vertices skip NEE,
+    Russian roulette from depth 11, depth cap)."""
+    from gpuspectral_amd import abi, scenes
+
+    sc = scenes.caustics(6000)
+    ctx.upload_scene(sc)
+    ctx.frame_begin(96, 96)
+    ctx.render(spp=4, max_depth=32)
+    p = abi.default_render_params()
+    p.max_depth = 32
+    ref, st = oracle_mod.Oracle(sc).render(96, 96, spp=4, params=p)
+    img = ctx.download().reshape(-1, 4)
+    assert rmse(img, ref) < TOL_RMSE
+    assert np.array_equal(img, ref)
+    assert ctx.stats()["shadow_rays"] > 0
