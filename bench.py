@@ -206,7 +206,7 @@ def main():
         ext_rays, sh_rays, samples = tot[1], tot[2], tot[3]
         rays = ext_rays + sh_rays
         # extend-kernel roofline (rank 0's launches): algorithmic bytes / HIP-event time
-        b_ray = 32.0 + 16.0 + 112.0 * nodes_per_ray + 48.0 * tris_per_ray  # 7 quads per 4-wide node
+        b_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray  # 64-B compressed 4-wide node
         ext_ms = st["extend_kernel_ms"]
         launches = max(1, st["extend_launches"])
         alg_bytes = st["extension_rays"] * b_ray

@@ -19,7 +19,7 @@
 //             area, within a window of the cluster array) -- near-SAH quality; the Karras 2012 radix
 //             tree (LBVH) is kept behind GSP_BVH=lbvh for comparison
 //   fit       bottom-up boxes of the binary tree (each binary node holds both child boxes)
-//   collapse  binary tree -> 4-wide BVH (128-B nodes): every binary node at even depth becomes one
+//   collapse  binary tree -> 4-wide BVH (compressed 64-B nodes, pt_trace.h): every binary node at even depth becomes one
 //             node whose children are its grandchildren (leaf children stay), so a ray makes half
 //             as many dependent node fetches; node index = exclusive scan of the even-depth flags
 //             (rocPRIM), which keeps the locality of the binary numbering.  GSP_COLLAPSE=greedy
@@ -411,8 +411,47 @@ struct Entry4 {
   int32_t code;
 };
 
-// 4-wide node (128 B = 8 quads, SoA over the children):
-//   {minx0..3} {miny0..3} {minz0..3} {maxx0..3} {maxy0..3} {maxz0..3} {child0..3} {-}
+// Writes one compressed 4-wide node (64 B, layout in pt_trace.h) from up to four child entries.
+__device__ void write_node4(q4* __restrict__ o, Entry4 (&e)[4], int cnt) {
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = 0; k < cnt; ++k) {
+    lo[0] = fminf(lo[0], e[k].lo.x); lo[1] = fminf(lo[1], e[k].lo.y); lo[2] = fminf(lo[2], e[k].lo.z);
+    hi[0] = fmaxf(hi[0], e[k].hi.x); hi[1] = fmaxf(hi[1], e[k].hi.y); hi[2] = fmaxf(hi[2], e[k].hi.z);
+  }
+  uint32_t ebits = 0;
+  float scale[3];
+  for (int a = 0; a < 3; ++a) {
+    const float ext = hi[a] - lo[a];
+    int ex = -100;
+    if (ext > 0.0f) (void)frexpf(ext / 255.0f, &ex);  // 2^ex >= ext / 255
+    int eb = min(max(ex + 127, 1), 254);
+    // the largest code must reach the far side of the node
+    while (eb < 254 && fmaf(255.0f, __uint_as_float((uint32_t)eb << 23), lo[a]) < hi[a]) ++eb;
+    scale[a] = __uint_as_float((uint32_t)eb << 23);
+    ebits |= (uint32_t)eb << (8 * a);
+  }
+  uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // qlo.x, qlo.y, qlo.z, qhi.x, qhi.y, qhi.z : one byte per child
+  for (int k = 0; k < cnt; ++k) {
+    const float cl[3] = {e[k].lo.x, e[k].lo.y, e[k].lo.z}, ch[3] = {e[k].hi.x, e[k].hi.y, e[k].hi.z};
+    for (int a = 0; a < 3; ++a) {
+      float ql = fminf(fmaxf(floorf((cl[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
+      while (ql > 0.0f && fmaf(ql, scale[a], lo[a]) > cl[a]) ql -= 1.0f;  // decoded plane must not exceed the box
+      float qh = fminf(fmaxf(ceilf((ch[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
+      while (qh < 255.0f && fmaf(qh, scale[a], lo[a]) < ch[a]) qh += 1.0f;
+      q[a] |= (uint32_t)ql << (8 * k);
+      q[3 + a] |= (uint32_t)qh << (8 * k);
+    }
+  }
+  int32_t code[4];
+  for (int k = 0; k < 4; ++k) code[k] = k < cnt ? e[k].code : kEmptyChild;
+  o[0] = mkq(lo[0], lo[1], lo[2], __uint_as_float(ebits));
+  o[1] = mkq(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
+  o[2] = mkq(__uint_as_float(q[4]), __uint_as_float(q[5]), __uint_as_float((uint32_t)code[0]),
+             __uint_as_float((uint32_t)code[1]));
+  o[3] = mkq(__uint_as_float((uint32_t)code[2]), __uint_as_float((uint32_t)code[3]), 0.0f, 0.0f);
+}
+
+// parity collapse: one thread per even-depth binary node
 __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restrict__ nodes2,
                                                   const uint32_t* __restrict__ flag,
                                                   const uint32_t* __restrict__ idx4, q4* __restrict__ nodes4) {
@@ -444,21 +483,7 @@ __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restric
   const q4 a = me[0], b = me[1], d = me[2], k = me[3];
   expand((int32_t)__float_as_uint(k.x), mkq(a.x, a.y, a.z, 0.0f), mkq(a.w, b.x, b.y, 0.0f));
   expand((int32_t)__float_as_uint(k.y), mkq(b.z, b.w, d.x, 0.0f), mkq(d.y, d.z, d.w, 0.0f));
-  for (; cnt < 4; ++cnt) {  // empty slot: far-away point box, never followed (code checked in the kernel)
-    e[cnt].lo = mkq(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);
-    e[cnt].hi = e[cnt].lo;
-    e[cnt].code = kEmptyChild;
-  }
-  q4* o = nodes4 + 8ll * idx4[i];
-  o[0] = mkq(e[0].lo.x, e[1].lo.x, e[2].lo.x, e[3].lo.x);
-  o[1] = mkq(e[0].lo.y, e[1].lo.y, e[2].lo.y, e[3].lo.y);
-  o[2] = mkq(e[0].lo.z, e[1].lo.z, e[2].lo.z, e[3].lo.z);
-  o[3] = mkq(e[0].hi.x, e[1].hi.x, e[2].hi.x, e[3].hi.x);
-  o[4] = mkq(e[0].hi.y, e[1].hi.y, e[2].hi.y, e[3].hi.y);
-  o[5] = mkq(e[0].hi.z, e[1].hi.z, e[2].hi.z, e[3].hi.z);
-  o[6] = mkq(__uint_as_float((uint32_t)e[0].code), __uint_as_float((uint32_t)e[1].code),
-             __uint_as_float((uint32_t)e[2].code), __uint_as_float((uint32_t)e[3].code));
-  o[7] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+  write_node4(nodes4 + 4ll * idx4[i], e, cnt);
 }
 
 // Greedy 4-wide collapse, one thread per output node of the current level.
@@ -515,21 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_collapse4(int count, const int2* __r
       e[k].code = (int32_t)id0++;
     }
   }
-  for (; cnt < 4; ++cnt) {
-    e[cnt].lo = mkq(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);
-    e[cnt].hi = e[cnt].lo;
-    e[cnt].code = kEmptyChild;
-  }
-  q4* o = nodes4 + 8ll * w.y;
-  o[0] = mkq(e[0].lo.x, e[1].lo.x, e[2].lo.x, e[3].lo.x);
-  o[1] = mkq(e[0].lo.y, e[1].lo.y, e[2].lo.y, e[3].lo.y);
-  o[2] = mkq(e[0].lo.z, e[1].lo.z, e[2].lo.z, e[3].lo.z);
-  o[3] = mkq(e[0].hi.x, e[1].hi.x, e[2].hi.x, e[3].hi.x);
-  o[4] = mkq(e[0].hi.y, e[1].hi.y, e[2].hi.y, e[3].hi.y);
-  o[5] = mkq(e[0].hi.z, e[1].hi.z, e[2].hi.z, e[3].hi.z);
-  o[6] = mkq(__uint_as_float((uint32_t)e[0].code), __uint_as_float((uint32_t)e[1].code),
-             __uint_as_float((uint32_t)e[2].code), __uint_as_float((uint32_t)e[3].code));
-  o[7] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+  write_node4(nodes4 + 4ll * w.y, e, cnt);
 }
 
 struct Scratch {
@@ -700,7 +711,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       GSP_HIP_TRY(hipMemcpyAsync(&n4, idx4 + n_int, sizeof(n4), hipMemcpyDeviceToHost, stream));
       GSP_HIP_TRY(hipStreamSynchronize(stream));
       out.num_nodes = n4;
-      const size_t b_nodes = (size_t)std::max<uint32_t>(n4, 1) * 128;
+      const size_t b_nodes = (size_t)std::max<uint32_t>(n4, 1) * 64;
       GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
       out.bytes += b_nodes;
       hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes);
@@ -712,7 +723,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     } else {
       // greedy SAH collapse, breadth-first; at most n - 1 output nodes
       q4* all4 = nullptr;
-      GSP_HIP_TRY(hipMalloc((void**)&all4, (size_t)n_int * 128));
+      GSP_HIP_TRY(hipMalloc((void**)&all4, (size_t)n_int * 64));
       int2 *qa, *qb;
       uint32_t* ctr;  // [0] next node id, [1] next-level queue size
       GSP_HIP_TRY(S.alloc(&qa, (size_t)n_int));
@@ -738,7 +749,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       }
       out.nodes = all4;
       out.num_nodes = total;
-      out.bytes += (size_t)n_int * 128;
+      out.bytes += (size_t)n_int * 64;
       out.root = 0;
     }
   }

@@ -21,7 +21,7 @@ namespace gsp {
 
 // Result of the device BVH build; all pointers are device memory owned by the caller's context.
 struct DeviceBvh {
-  q4* nodes = nullptr;      // 4-wide BVH, 8 quads (128 B) per node
+  q4* nodes = nullptr;      // 4-wide BVH, 4 quads (64 B, compressed) per node
   q4* tri_isect = nullptr;  // 3 quads per slot
   q4* tri_shade = nullptr;  // 4 quads per slot
   uint32_t* slot_to_global = nullptr;

@@ -432,7 +432,10 @@ struct gsp_context {
     v.root = bvh.root;
     return v;
   }
-  uint32_t max_blocks() const { return (uint32_t)num_cus * 6u; }  // 6 x 256 threads: what 24 KB of LDS per block admits
+#ifndef GSP_BLOCKS_PER_CU
+#define GSP_BLOCKS_PER_CU 6
+#endif
+  uint32_t max_blocks() const { return (uint32_t)num_cus * GSP_BLOCKS_PER_CU; }  // resident 256-thread blocks per CU
   uint32_t grid_for(uint64_t n) const {
     uint64_t b = (n + kBlock - 1) / kBlock;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, max_blocks()));

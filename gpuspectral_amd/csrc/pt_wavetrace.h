@@ -26,7 +26,13 @@
 namespace gsp {
 
 constexpr int kTraceBlock = 256;
-constexpr int kLdsStackDepth = 24;          // LDS levels per lane (24 KB per block)
+#ifndef GSP_LDS_LEVELS
+#define GSP_LDS_LEVELS 24
+#endif
+#ifndef GSP_TRACE_WAVES
+#define GSP_TRACE_WAVES 1
+#endif
+constexpr int kLdsStackDepth = GSP_LDS_LEVELS;  // LDS levels per lane (1 KB per level per block)
 #ifndef GSP_REFILL_LANES
 #define GSP_REFILL_LANES 16
 #endif
@@ -108,7 +114,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 //   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux) const;   // h.slot < 0: miss / unoccluded;
 //                                                  aux = p1.w of the accepted triangle (BSDF type)
 template <bool ANY, bool STATS, class IO>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
+__global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
                                                         int32_t root, const uint32_t* __restrict__ n_ptr,
                                                         uint32_t n_imm, uint32_t chunk, IO io,
                                                         uint32_t* __restrict__ work,
@@ -206,67 +212,77 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const q4* __restrict__ no
     // ---- one inner-node step for every lane that sits on an inner node ---------------------------
     const bool leaf_step = __popcll(leaf_m) >= kLeafBatch || node_m == 0;
     if (node_m != 0 && !leaf_step) {
-      if (on_node) {
-        // 4-wide node: 7 quads SoA over the children (pt_bvh.hip k_emit4)
-        const q4* nd = nodes + 8ll * cur;
-        const q4 mnx = nd[0], mny = nd[1], mnz = nd[2], mxx = nd[3], mxy = nd[4], mxz = nd[5], cc = nd[6];
-        if (STATS) ++c_nodes;
-        const int32_t c0 = (int32_t)__float_as_uint(cc.x), c1 = (int32_t)__float_as_uint(cc.y),
-                      c2 = (int32_t)__float_as_uint(cc.z), c3 = (int32_t)__float_as_uint(cc.w);
-        // four slab tests, two children per packed-f32 instruction (v_pk_add_f32 / v_pk_mul_f32:
-        // the kernel is VALU-issue bound, so halving the instruction count of the 48 subtract /
-        // multiply operations matters).  Same arithmetic as slab() in pt_trace.h.
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-        const v2f ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-        const v2f tmn = {tmin, tmin}, tmx = {h.t, h.t};
-        float lo4[4];
-        bool hit4[4];
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const v2f bx0 = pr ? v2f{mnx.z, mnx.w} : v2f{mnx.x, mnx.y}, bx1 = pr ? v2f{mxx.z, mxx.w} : v2f{mxx.x, mxx.y};
-          const v2f by0 = pr ? v2f{mny.z, mny.w} : v2f{mny.x, mny.y}, by1 = pr ? v2f{mxy.z, mxy.w} : v2f{mxy.x, mxy.y};
-          const v2f bz0 = pr ? v2f{mnz.z, mnz.w} : v2f{mnz.x, mnz.y}, bz1 = pr ? v2f{mxz.z, mxz.w} : v2f{mxz.x, mxz.y};
-          const v2f t0x = (bx0 - ox) * ix, t1x = (bx1 - ox) * ix;
-          const v2f t0y = (by0 - oy) * iy, t1y = (by1 - oy) * iy;
-          const v2f t0z = (bz0 - oz) * iz, t1z = (bz1 - oz) * iz;
-          const v2f lo = __builtin_elementwise_max(
-              __builtin_elementwise_max(__builtin_elementwise_min(t0x, t1x), __builtin_elementwise_min(t0y, t1y)),
-              __builtin_elementwise_max(__builtin_elementwise_min(t0z, t1z), tmn));
-          const v2f hi = __builtin_elementwise_min(
-              __builtin_elementwise_min(__builtin_elementwise_max(t0x, t1x), __builtin_elementwise_max(t0y, t1y)),
-              __builtin_elementwise_min(__builtin_elementwise_max(t0z, t1z), tmx));
-          const v2f hs = hi * v2f{1.000001f, 1.000001f};
-          lo4[2 * pr] = lo.x;
-          lo4[2 * pr + 1] = lo.y;
-          hit4[2 * pr] = lo.x <= hs.x;
-          hit4[2 * pr + 1] = lo.y <= hs.y;
-        }
-        const float l0 = lo4[0], l1 = lo4[1], l2 = lo4[2], l3 = lo4[3];
-        const bool h0 = hit4[0] && c0 != kEmptyChild, h1 = hit4[1] && c1 != kEmptyChild,
-                   h2 = hit4[2] && c2 != kEmptyChild, h3 = hit4[3] && c3 != kEmptyChild;
-        // order the hit children by entry distance: sort 4 keys = {distance bits | child slot}
-        uint32_t k0 = h0 ? ((__float_as_uint(l0) & 0x7ffffffcu) | 0u) : 0xffffffffu;
-        uint32_t k1 = h1 ? ((__float_as_uint(l1) & 0x7ffffffcu) | 1u) : 0xffffffffu;
-        uint32_t k2 = h2 ? ((__float_as_uint(l2) & 0x7ffffffcu) | 2u) : 0xffffffffu;
-        uint32_t k3 = h3 ? ((__float_as_uint(l3) & 0x7ffffffcu) | 3u) : 0xffffffffu;
-        uint32_t t;
-#define GSP_CSWAP(a, b) t = min(a, b); b = max(a, b); a = t;
-        GSP_CSWAP(k0, k1)
-        GSP_CSWAP(k2, k3)
-        GSP_CSWAP(k0, k2)
-        GSP_CSWAP(k1, k3)
-        GSP_CSWAP(k1, k2)
-#undef GSP_CSWAP
-        const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-#define GSP_CODE(k) (((k) & 2u) ? (((k) & 1u) ? c3 : c2) : (((k) & 1u) ? c1 : c0))
-        stk.push_sorted(nh > 0 ? nh - 1 : 0, GSP_CODE(k1), GSP_CODE(k2), GSP_CODE(k3));
-        if (nh > 0) cur = GSP_CODE(k0);
-        else cur = stk.pop();
-#undef GSP_CODE
-        if (cur < 0 && leaf == 0) {  // first leaf: postpone it and keep descending
-          leaf = cur;
-          cur = stk.pop();
+#ifndef GSP_NODE_REPS
+#define GSP_NODE_REPS 2
+#endif
+      // up to GSP_NODE_REPS node steps per pass through the bookkeeping above, as long as most
+      // lanes are still on inner nodes
+      for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
+        const bool on = (uint32_t)cur < (uint32_t)kSentinel;
+        if (rep > 0 && __popcll(__ballot(on)) < 40) break;
+      if (on) {
+          // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip write_node4)
+          const q4* nd = nodes + 4ll * cur;
+          const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+          if (STATS) ++c_nodes;
+          const int32_t c0 = (int32_t)__float_as_uint(n2.z), c1 = (int32_t)__float_as_uint(n2.w),
+                        c2 = (int32_t)__float_as_uint(n3.x), c3 = (int32_t)__float_as_uint(n3.y);
+          // decode: plane = origin + q * 2^e, taken relative to the ray origin as
+          // fma(q, scale, origin - o) (same rounding class as the uncompressed (b - o)), then * 1/d
+          const uint32_t eb = __float_as_uint(n0.w);
+          const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
+                      sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
+          const float dx = n0.x - o.x, dy = n0.y - o.y, dz = n0.z - o.z;
+          const uint32_t qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z),
+                         qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
+          float lo4[4];
+          bool hit4[4];
+// (float)((q >> 8k) & 0xff) compiles to v_cvt_f32_ubyteK
+#define GSP_UB0(q) ((float)((q) & 0xffu))
+#define GSP_UB1(q) ((float)(((q) >> 8) & 0xffu))
+#define GSP_UB2(q) ((float)(((q) >> 16) & 0xffu))
+#define GSP_UB3(q) ((float)((q) >> 24))
+#define GSP_CHILD(K, CVT)                                                                               \
+  {                                                                                                     \
+    const float t0x = __builtin_fmaf(CVT(qlx), sx, dx) * inv.x, t1x = __builtin_fmaf(CVT(qhx), sx, dx) * inv.x; \
+    const float t0y = __builtin_fmaf(CVT(qly), sy, dy) * inv.y, t1y = __builtin_fmaf(CVT(qhy), sy, dy) * inv.y; \
+    const float t0z = __builtin_fmaf(CVT(qlz), sz, dz) * inv.z, t1z = __builtin_fmaf(CVT(qhz), sz, dz) * inv.z; \
+    const float lo = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));       \
+    const float hi = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), h.t));        \
+    lo4[K] = lo;                                                                                        \
+    hit4[K] = lo <= hi * 1.000001f;                                                                     \
+  }
+          GSP_CHILD(0, GSP_UB0)
+          GSP_CHILD(1, GSP_UB1)
+          GSP_CHILD(2, GSP_UB2)
+          GSP_CHILD(3, GSP_UB3)
+#undef GSP_CHILD
+          const float l0 = lo4[0], l1 = lo4[1], l2 = lo4[2], l3 = lo4[3];
+          const bool h0 = hit4[0] && c0 != kEmptyChild, h1 = hit4[1] && c1 != kEmptyChild,
+                     h2 = hit4[2] && c2 != kEmptyChild, h3 = hit4[3] && c3 != kEmptyChild;
+          // order the hit children by entry distance: sort 4 keys = {distance bits | child slot}
+          uint32_t k0 = h0 ? ((__float_as_uint(l0) & 0x7ffffffcu) | 0u) : 0xffffffffu;
+          uint32_t k1 = h1 ? ((__float_as_uint(l1) & 0x7ffffffcu) | 1u) : 0xffffffffu;
+          uint32_t k2 = h2 ? ((__float_as_uint(l2) & 0x7ffffffcu) | 2u) : 0xffffffffu;
+          uint32_t k3 = h3 ? ((__float_as_uint(l3) & 0x7ffffffcu) | 3u) : 0xffffffffu;
+          uint32_t t;
+  #define GSP_CSWAP(a, b) t = min(a, b); b = max(a, b); a = t;
+          GSP_CSWAP(k0, k1)
+          GSP_CSWAP(k2, k3)
+          GSP_CSWAP(k0, k2)
+          GSP_CSWAP(k1, k3)
+          GSP_CSWAP(k1, k2)
+  #undef GSP_CSWAP
+          const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+  #define GSP_CODE(k) (((k) & 2u) ? (((k) & 1u) ? c3 : c2) : (((k) & 1u) ? c1 : c0))
+          stk.push_sorted(nh > 0 ? nh - 1 : 0, GSP_CODE(k1), GSP_CODE(k2), GSP_CODE(k3));
+          if (nh > 0) cur = GSP_CODE(k0);
+          else cur = stk.pop();
+  #undef GSP_CODE
+          if (cur < 0 && leaf == 0) {  // first leaf: postpone it and keep descending
+            leaf = cur;
+            cur = stk.pop();
+          }
         }
       }
       continue;
