@@ -29,8 +29,9 @@ def probe(name, sc, W, H, spp, K=0):
         ctx.reset_stats()
         ctx.render(spp=1, first_timestamp=100, collect_traversal_stats=1)
         st = ctx.stats()
-        print("   traversal: %.1f nodes/ray, %.2f tris/ray over %d rays" % (
-            st["nodes_visited"] / max(1, st["stat_rays"]), st["tris_tested"] / max(1, st["stat_rays"]), st["stat_rays"]), flush=True)
+        print("   traversal: %.1f nodes/ray, %.2f tris/ray over %d rays | shadow: %.1f nodes/ray, %.2f tris/ray over %d rays" % (
+            st["nodes_visited"] / max(1, st["stat_rays"]), st["tris_tested"] / max(1, st["stat_rays"]), st["stat_rays"],
+            st["shadow_nodes_visited"] / max(1, st["shadow_stat_rays"]), st["shadow_tris_tested"] / max(1, st["shadow_stat_rays"]), st["shadow_stat_rays"]), flush=True)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cornell", "mats", "interior"]
