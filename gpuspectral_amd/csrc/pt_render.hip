@@ -176,7 +176,10 @@ struct TestIO {  // gsp_trace
 // an 8M-path launch serialise at the ~88/us a single address sustains (MI355X_MICROARCH.md,
 // "dequeue" row) and cost half the kernel.  So survivors are counted per block through LDS and the
 // block reserves its ranges with ONE atomic pair per 1024 paths.
-constexpr int kShadeBlock = 1024;
+#ifndef GSP_SHADE_BLOCK
+#define GSP_SHADE_BLOCK 1024
+#endif
+constexpr int kShadeBlock = GSP_SHADE_BLOCK;
 constexpr int kShadeWaves = kShadeBlock / 64;
 __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
                                                         const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
@@ -820,7 +823,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
       const uint32_t shade_grid =
-          (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2));
+          (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2 * (1024 / kShadeBlock)));
       hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
                          Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, (uint32_t)batch_paths, ctx->dstats.p);
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[2], st));

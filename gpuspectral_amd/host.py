@@ -53,6 +53,8 @@ def load():
     L.gsph_pathtracer_download.argtypes = [vp, vp, u64]
     L.gsph_pathtracer_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.gsph_write_pfm.argtypes = [C.c_char_p, vp, u32, u32]
+    L.gsph_write_ppm.argtypes = [C.c_char_p, vp, u32, u32, C.c_int]
+    L.gsph_tone_map.argtypes = [vp, u32, u32, C.c_int, vp]
     _LIB = L
     return L
 
@@ -173,3 +175,21 @@ def write_pfm(path, rgba):
     L = load()
     if L.gsph_write_pfm(path.encode(), rgba.ctypes.data, w, h) != 0:
         raise GspError("write_pfm: %s" % _err(L))
+
+
+def tone_map(rgba, aces=False):
+    """uint8 RGB image: clamp (or ACESFilm, S/assets/shaders/common.glsl:74-82) then gamma 2.2."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[0], rgba.shape[1]
+    out = np.zeros((h, w, 3), np.uint8)
+    L = load()
+    if L.gsph_tone_map(rgba.ctypes.data, w, h, 1 if aces else 0, out.ctypes.data) != 0:
+        raise GspError("tone_map: %s" % _err(L))
+    return out
+
+
+def write_ppm(path, rgba, aces=False):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    L = load()
+    if L.gsph_write_ppm(path.encode(), rgba.ctypes.data, rgba.shape[1], rgba.shape[0], 1 if aces else 0) != 0:
+        raise GspError("write_ppm: %s" % _err(L))

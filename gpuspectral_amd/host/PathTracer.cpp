@@ -1,6 +1,7 @@
 // PathTracer.cpp -- see PathTracer.h.  Reference: S/renderer/PathTracer.cpp:5-93.
 #include "PathTracer.h"
 
+#include <cmath>
 #include <cstdio>
 #include <stdexcept>
 
@@ -82,6 +83,35 @@ void writePfm(const std::string& path, const float* rgba, uint32_t width, uint32
     }
     std::fwrite(row.data(), sizeof(float), row.size(), f);
   }
+  std::fclose(f);
+}
+
+// ACESFilm, S/assets/shaders/common.glsl:74-82
+static inline float acesFilm(float x) {
+  const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+  float y = (x * (a * x + b)) / (x * (c * x + d) + e);
+  return y < 0.0f ? 0.0f : (y > 1.0f ? 1.0f : y);
+}
+
+void toneMapToRgb8(const float* rgba, uint32_t width, uint32_t height, bool toneMap, std::vector<uint8_t>& rgb8) {
+  rgb8.resize(3ull * width * height);
+  for (size_t i = 0; i < (size_t)width * height; ++i)
+    for (int c = 0; c < 3; ++c) {
+      float v = rgba[4 * i + c];
+      if (!(v == v)) v = 0.0f;
+      v = toneMap ? acesFilm(v) : (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+      v = std::pow(v, 1.0f / 2.2f);
+      rgb8[3 * i + c] = (uint8_t)(v * 255.0f + 0.5f);
+    }
+}
+
+void writePpm(const std::string& path, const float* rgba, uint32_t width, uint32_t height, bool toneMap) {
+  std::vector<uint8_t> rgb;
+  toneMapToRgb8(rgba, width, height, toneMap, rgb);
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) throw std::runtime_error("cannot write " + path);
+  std::fprintf(f, "P6\n%u %u\n255\n", width, height);
+  std::fwrite(rgb.data(), 1, rgb.size(), f);
   std::fclose(f);
 }
 

@@ -62,4 +62,12 @@ class PathTracer : public RenderPassCreator {
 // Headless output step: little-endian PFM ("PF", bottom-to-top rows) of the RGB channels.
 void writePfm(const std::string& path, const float* rgba, uint32_t width, uint32_t height);
 
+// Display transform of the presentation pass.  The reference blits the accumulate image unchanged
+// (S/assets/shaders/DrawTexture.frag:9-13; `RenderParams.toneMap` is never read, S/renderer/
+// PathTracer.h:36-41) and keeps the ACES fit as a dormant helper (S/assets/shaders/common.glsl:74-82).
+// toneMap = false: clamp + gamma 2.2 (the ldrfilm setting of the shipped scenes); true: ACESFilm, then gamma.
+void toneMapToRgb8(const float* rgba, uint32_t width, uint32_t height, bool toneMap, std::vector<uint8_t>& rgb8);
+// Binary PPM ("P6") of the tone-mapped image (top-to-bottom rows).
+void writePpm(const std::string& path, const float* rgba, uint32_t width, uint32_t height, bool toneMap);
+
 }  // namespace GPUSpectral

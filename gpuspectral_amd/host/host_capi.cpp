@@ -89,4 +89,15 @@ int gsph_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t
   return guard([&] { writePfm(path, rgba, width, height); });
 }
 
+int gsph_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height, int tone_map) {
+  return guard([&] { writePpm(path, rgba, width, height, tone_map != 0); });
+}
+int gsph_tone_map(const float* rgba, uint32_t width, uint32_t height, int tone_map, uint8_t* rgb8) {
+  return guard([&] {
+    std::vector<uint8_t> v;
+    toneMapToRgb8(rgba, width, height, tone_map != 0, v);
+    std::memcpy(rgb8, v.data(), v.size());
+  });
+}
+
 }  // extern "C"

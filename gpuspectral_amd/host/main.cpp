@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <string>
 
 #include "Loader.h"
 #include "PathTracer.h"
@@ -31,6 +32,7 @@ int main(int argc, char** argv) {
     double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     gsp_stats st = pt.stats();
     writePfm(argv[2], img.data(), width, height);
+    writePpm(std::string(argv[2]) + ".ppm", img.data(), width, height, false);  // LDR preview, gamma 2.2
     std::printf("%llu triangles, %ux%u x %u spp in %.3f s: %.1f Mrays/s, %.2f Msamples/s (BVH build %.1f ms)\n",
                 (unsigned long long)st.num_triangles, width, height, spp, s,
                 (st.extension_rays + st.shadow_rays) / s / 1e6, st.samples / s / 1e6, st.bvh_build_ms);

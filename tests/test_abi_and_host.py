@@ -241,3 +241,23 @@ def test_cpp_loader_on_reference_scenes(name):
         assert len(a.lights) > 0
     assert sorted(s.warnings) == sorted(b.warnings) or len(s.warnings) >= len(b.warnings)
     print(name, a.num_triangles, "triangles,", len(a.instances), "objects,", len(a.lights), "lights;", len(s.warnings), "warnings")
+
+
+def test_tone_map_and_ppm(tmp_path):
+    """Presentation step: gamma 2.2 (ldrfilm) and the reference's dormant ACES fit (common.glsl:74-82)."""
+    from gpuspectral_amd import host
+
+    x = np.zeros((2, 3, 4), np.float32)
+    x[0, 0, :3] = (0.0, 0.5, 1.0)
+    x[0, 1, :3] = (2.0, -1.0, np.nan)
+    x[1, 2, :3] = (0.18, 0.18, 0.18)
+    ldr = host.tone_map(x)
+    assert ldr[0, 0].tolist() == [0, int(0.5 ** (1 / 2.2) * 255 + 0.5), 255]
+    assert ldr[0, 1].tolist() == [255, 0, 0]
+    aces = host.tone_map(x, aces=True)
+    f = lambda v: min(max((v * (2.51 * v + 0.03)) / (v * (2.43 * v + 0.59) + 0.14), 0.0), 1.0)
+    assert abs(int(aces[1, 2, 0]) - int(f(0.18) ** (1 / 2.2) * 255 + 0.5)) <= 1
+    p = str(tmp_path / "o.ppm")
+    host.write_ppm(p, x)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"P6\n3 2\n255\n") and len(raw) == len(b"P6\n3 2\n255\n") + 18

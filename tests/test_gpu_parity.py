@@ -270,3 +270,25 @@ def test_deep_dielectric_paths_max_depth_32(ctx, oracle_mod):
     assert rmse(img, ref) < TOL_RMSE
     assert np.array_equal(img, ref)
     assert ctx.stats()["shadow_rays"] > 0
+
+
+def test_checkpoint_resume(oracle_mod, cornell):
+    """Accumulate buffer + next timestamp are the whole integrator state (checkpoint/resume):
+    a second context resumed from a downloaded buffer continues bit-exactly."""
+    import gpuspectral_amd as g
+
+    a = g.Context(0)
+    a.upload_scene(cornell)
+    a.frame_begin(48, 48)
+    a.render(spp=3)
+    saved = a.download_compact().copy()
+    a.close()
+    b = g.Context(0)
+    b.upload_scene(cornell)
+    b.frame_begin(48, 48)
+    b.upload_accum(saved)
+    b.render(spp=4, first_timestamp=3)
+    img = b.download().reshape(-1, 4)
+    b.close()
+    ref, _ = oracle_mod.Oracle(cornell).render(48, 48, spp=7)
+    assert np.array_equal(img, ref)
