@@ -416,6 +416,23 @@ struct gsp_context {
   gsp_stats stats{};
   std::vector<hipEvent_t> ev;
 
+  // streaming pipeline state: survives across gsp_render calls, drained by gsp_sync & friends
+  struct Batch {
+    uint32_t t0, kb, slot;
+  };
+  struct Pipeline {
+    bool active = false;
+    gsp_render_params params{};
+    uint64_t Kb = 1, batch_paths = 0, pool_target = 0, cap = 0;
+    uint32_t num_slots = 0;
+    std::deque<Batch> inflight;
+    std::vector<char> slot_used;
+    uint64_t n = 0;
+    int cur = 0;
+    uint32_t iteration = 0;
+    uint32_t next_ts = 0, remaining = 0;
+  } pipe;
+
   SceneView view() const {
     SceneView v;
     v.nodes = bvh.nodes;
@@ -504,6 +521,8 @@ static void set_create_error(const std::string& s) {
   g_create_error = s;
 }
 
+static int pipeline_drain(gsp_context* ctx);
+
 int gsp_ctx_create(int device, gsp_context** out) {
   if (!out) return GSP_ERR_INVALID;
   *out = nullptr;
@@ -542,6 +561,7 @@ int gsp_ctx_create(int device, gsp_context** out) {
 void gsp_ctx_destroy(gsp_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  (void)pipeline_drain(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   free_bvh(ctx->bvh);
@@ -553,6 +573,10 @@ void gsp_ctx_destroy(gsp_context* ctx) {
 int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   if (!ctx || !sc) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   ctx->have_scene = false;
   // ---- validate ----
   uint64_t total_tris = 0;
@@ -647,6 +671,10 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uin
                     uint64_t num_pixels) {
   if (!ctx || width == 0 || height == 0) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   const uint64_t frame = (uint64_t)width * height;
   if (frame >= (1ull << 32)) {
     ctx->err = "frame too large";
@@ -706,41 +734,19 @@ static int ensure_pool(gsp_context* ctx, uint64_t cap, uint64_t result_entries) 
   return GSP_OK;
 }
 
-int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
-  if (!ctx || !rp) return GSP_ERR_INVALID;
-  if (!ctx->have_scene || !ctx->have_frame) {
-    ctx->err = "gsp_render needs gsp_upload_scene and gsp_frame_begin first";
-    return GSP_ERR_INVALID;
-  }
-  if (rp->max_depth > 250) {
-    ctx->err = "max_depth > 250 unsupported";
-    return GSP_ERR_INVALID;
-  }
-  CTX_TRY(ctx, hipSetDevice(ctx->device));
-  if (rp->spp == 0 || ctx->num_pixels == 0) return GSP_OK;
+// Runs the streaming pipeline: injects the queued samples and iterates extend / shade / connect.
+// drain == false: returns as soon as every queued sample has been injected (stragglers of the last
+// batches stay in flight and ride along with the next call's launches); drain == true: runs until
+// nothing is in flight and every batch has been folded into the accumulate buffer.
+static int pipeline_run(gsp_context* ctx, bool drain) {
+  gsp_context::Pipeline& P = ctx->pipe;
+  if (!P.active) return GSP_OK;
   const auto t_begin = std::chrono::steady_clock::now();
   hipStream_t st = ctx->stream;
+  const gsp_render_params* rp = &P.params;
   const uint64_t npix = ctx->num_pixels;
-  // Streaming path pool.  Samples enter in batches of Kb timestamps (>= ~1M paths); a new batch is
-  // injected whenever the pool has room, so every launch works on ~8M paths even though 95 % of a
-  // batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
-  // owns a slot of the sample-result ring and is folded into the accumulate buffer, in timestamp
-  // order, once its live count has dropped to zero.
-  uint64_t Kb = rp->timestamps_in_flight;
-  if (Kb == 0) Kb = std::max<uint64_t>(1, (1ull << 20) / npix);
-  Kb = std::min<uint64_t>(Kb, rp->spp);
-  while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
-  const uint64_t batch_paths = Kb * npix;
-  const uint64_t pool_target = std::max<uint64_t>(8ull << 20, 2 * batch_paths);
-  const uint64_t cap = pool_target + batch_paths;
-  const uint32_t num_slots =
-      (uint32_t)std::min<uint64_t>(kMaxSlots, std::max<uint64_t>(4, 8 * ((pool_target + batch_paths - 1) / batch_paths)));
-  if (cap >= (1ull << 32) || (uint64_t)num_slots * batch_paths >= (1ull << 32)) {
-    ctx->err = "frame too large for 32-bit path indices";
-    return GSP_ERR_INVALID;
-  }
-  int rc = ensure_pool(ctx, cap, (uint64_t)num_slots * batch_paths);
-  if (rc != GSP_OK) return rc;
+  const uint64_t batch_paths = P.batch_paths, pool_target = P.pool_target, cap = P.cap;
+  const uint32_t num_slots = P.num_slots;
 
   RenderConsts rcst;
   rcst.width = ctx->width;
@@ -768,42 +774,36 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   PathQueue Q[2];
   for (int k = 0; k < 2; ++k) Q[k] = PathQueue{ctx->P0[k].p, ctx->P1[k].p, ctx->P2[k].p, ctx->FL[k].p};
   ShadowQueue SQ{ctx->S0.p, ctx->S1.p, ctx->S2.p, ctx->S3.p};
-
   const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
-  struct Batch {
-    uint32_t t0, kb, slot;
-  };
-  std::deque<Batch> inflight;
-  std::vector<char> slot_used(num_slots, 0);
-  uint32_t next_ts = rp->first_timestamp, remaining = rp->spp;
-  uint64_t n = 0;
-  int cur = 0;
-  uint32_t iteration = 0;
-  while (remaining > 0 || n > 0 || !inflight.empty()) {
+
+  while (P.remaining > 0 || (drain && (P.n > 0 || !P.inflight.empty()))) {
     // ---- inject new batches while there is room ----
-    while (remaining > 0 && n < pool_target) {
-      const uint32_t kb = (uint32_t)std::min<uint64_t>(Kb, remaining);
+    while (P.remaining > 0 && P.n < pool_target) {
+      const uint32_t kb = (uint32_t)std::min<uint64_t>(P.Kb, P.remaining);
       uint32_t slot = num_slots;
       for (uint32_t s2 = 0; s2 < num_slots; ++s2)
-        if (!slot_used[s2]) {
+        if (!P.slot_used[s2]) {
           slot = s2;
           break;
         }
-      if (slot == num_slots || n + (uint64_t)kb * npix > cap) break;
+      if (slot == num_slots || P.n + (uint64_t)kb * npix > cap) break;
       const uint64_t paths = (uint64_t)kb * npix;
-      hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, next_ts,
-                         ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur], (uint32_t)n,
+      hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
+                         ctx->subset ? ctx->pixel_ids.p : nullptr, Q[P.cur], (uint32_t)P.n,
                          (uint32_t)(slot * batch_paths), ctx->result.p);
       CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->counters.p + C_LIVE + slot), (int)paths, 1, st));
-      slot_used[slot] = 1;
-      inflight.push_back(Batch{next_ts, kb, slot});
-      n += paths;
-      next_ts += kb;
-      remaining -= kb;
+      ctx->h_counters[C_LIVE + slot] = (uint32_t)paths;  // not resolvable before the next read-back
+      P.slot_used[slot] = 1;
+      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot});
+      P.n += paths;
+      P.next_ts += kb;
+      P.remaining -= kb;
     }
-    if (n > 0) {
-      const uint32_t bounce = iteration++;
+    if (P.n > 0) {
+      const uint64_t n = P.n;
+      const int cur = P.cur;
+      const uint32_t bounce = P.iteration++;
       const uint32_t chunk = n >= (1u << 20) ? kChunkLarge : kChunkSmall;
       const uint32_t grid = ctx->trace_grid(n, chunk);
       CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 2 * sizeof(uint32_t), st));
@@ -822,8 +822,8 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
                              ctx->spill_stride, so_ext);
       }
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-      const uint32_t shade_grid =
-          (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2 * (1024 / kShadeBlock)));
+      const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
+          1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2 * (1024 / kShadeBlock)));
       hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
                          Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, (uint32_t)batch_paths, ctx->dstats.p);
       if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[2], st));
@@ -857,35 +857,99 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
         ctx->stats.connect_kernel_ms += ms;
         if (getenv("GSP_TRACE_BOUNCES"))
           fprintf(stderr, "iter %3u: n %9llu shadow %9u inflight %2zu | extend %8.3f ms shade %8.3f ms connect %8.3f ms\n",
-                  bounce, (unsigned long long)n, ctx->h_counters[C_SHADOW], inflight.size(), e_ms, s_ms, ms);
+                  bounce, (unsigned long long)n, ctx->h_counters[C_SHADOW], P.inflight.size(), e_ms, s_ms, ms);
       }
-      n = ctx->h_counters[C_NEXT];
-      cur ^= 1;
+      P.n = ctx->h_counters[C_NEXT];
+      P.cur ^= 1;
     }
     // ---- fold finished batches into the accumulate buffer, strictly in timestamp order ----
-    while (!inflight.empty() && ctx->h_counters[C_LIVE + inflight.front().slot] == 0) {
-      const Batch b = inflight.front();
-      inflight.pop_front();
+    while (!P.inflight.empty() && ctx->h_counters[C_LIVE + P.inflight.front().slot] == 0) {
+      const gsp_context::Batch b = P.inflight.front();
+      P.inflight.pop_front();
       hipLaunchKernelGGL(k_resolve, dim3(ctx->grid_for(npix)), dim3(kBlock), 0, st, (uint32_t)npix, b.kb, b.t0,
                          ctx->result.p + (uint64_t)b.slot * batch_paths, ctx->accum.p);
       CTX_TRY(ctx, hipGetLastError());
-      slot_used[b.slot] = 0;
+      P.slot_used[b.slot] = 0;
       ctx->stats.samples += (uint64_t)b.kb * npix;
     }
-    if (n == 0 && remaining == 0 && !inflight.empty()) {
+    if (P.n == 0 && P.remaining == 0 && !P.inflight.empty()) {
       ctx->err = "internal error: paths exhausted with unresolved sample batches";
       return GSP_ERR_DEVICE;
     }
   }
   CTX_TRY(ctx, hipStreamSynchronize(st));
+  if (drain) P.active = false;
   ctx->stats.render_seconds +=
       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
   return GSP_OK;
 }
 
+// Completes everything gsp_render has queued.
+static int pipeline_drain(gsp_context* ctx) { return pipeline_run(ctx, true); }
+
+int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
+  if (!ctx || !rp) return GSP_ERR_INVALID;
+  if (!ctx->have_scene || !ctx->have_frame) {
+    ctx->err = "gsp_render needs gsp_upload_scene and gsp_frame_begin first";
+    return GSP_ERR_INVALID;
+  }
+  if (rp->max_depth > 250) {
+    ctx->err = "max_depth > 250 unsupported";
+    return GSP_ERR_INVALID;
+  }
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  if (rp->spp == 0 || ctx->num_pixels == 0) return GSP_OK;
+  gsp_context::Pipeline& P = ctx->pipe;
+  const uint64_t npix = ctx->num_pixels;
+  // A running pipeline is continued when the integrator constants and the batch size are unchanged
+  // (paths in flight carry no copy of them); otherwise it is drained first.
+  uint64_t Kb = rp->timestamps_in_flight;
+  if (Kb == 0) Kb = std::max<uint64_t>(1, (1ull << 20) / npix);
+  while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
+  if (P.active && (P.params.max_depth != rp->max_depth || P.params.rr_start_depth != rp->rr_start_depth ||
+                   P.params.clamp != rp->clamp || P.Kb != Kb)) {
+    int rc = pipeline_drain(ctx);
+    if (rc != GSP_OK) return rc;
+  }
+  if (!P.active) {
+    // Streaming path pool.  Samples enter in batches of Kb timestamps (>= ~1M paths); a new batch is
+    // injected whenever the pool has room, so every launch works on ~8M paths even though 95 % of a
+    // batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
+    // owns a slot of the sample-result ring and is folded into the accumulate buffer, in timestamp
+    // order, once its live count has dropped to zero.
+    P.Kb = Kb;
+    P.batch_paths = Kb * npix;
+    P.pool_target = std::max<uint64_t>(8ull << 20, 2 * P.batch_paths);
+    P.cap = P.pool_target + P.batch_paths;
+    P.num_slots = (uint32_t)std::min<uint64_t>(
+        kMaxSlots, std::max<uint64_t>(4, 8 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths)));
+    if (P.cap >= (1ull << 32) || (uint64_t)P.num_slots * P.batch_paths >= (1ull << 32)) {
+      ctx->err = "frame too large for 32-bit path indices";
+      return GSP_ERR_INVALID;
+    }
+    int rc = ensure_pool(ctx, P.cap, (uint64_t)P.num_slots * P.batch_paths);
+    if (rc != GSP_OK) return rc;
+    P.inflight.clear();
+    P.slot_used.assign(P.num_slots, 0);
+    P.n = 0;
+    P.cur = 0;
+    P.iteration = 0;
+    P.remaining = 0;
+    P.active = true;
+  }
+  P.params = *rp;  // (stats / timing flags may change from call to call)
+  P.next_ts = rp->first_timestamp;
+  P.remaining += rp->spp;
+  return pipeline_run(ctx, false);
+}
+
 int gsp_sync(gsp_context* ctx) {
   if (!ctx) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc = pipeline_drain(ctx);
+    if (rc != GSP_OK) return rc;
+  }
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GSP_OK;
 }
@@ -893,6 +957,10 @@ int gsp_sync(gsp_context* ctx) {
 int gsp_download_compact(gsp_context* ctx, float* out) {
   if (!ctx || !out || !ctx->have_frame) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   CTX_TRY(ctx, hipMemcpyAsync(out, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GSP_OK;
@@ -912,6 +980,10 @@ int gsp_download(gsp_context* ctx, float* out) {
 
 int gsp_copy_accum_to_device(gsp_context* ctx, void* dst, uint64_t bytes) {
   if (!ctx || !dst || !ctx->have_frame) return GSP_ERR_INVALID;
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   if (bytes < ctx->num_pixels * sizeof(q4)) {
     ctx->err = "destination too small";
     return GSP_ERR_INVALID;
@@ -924,6 +996,10 @@ int gsp_copy_accum_to_device(gsp_context* ctx, void* dst, uint64_t bytes) {
 
 int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels) {
   if (!ctx || !rgba || !ctx->have_frame || num_pixels != ctx->num_pixels) return GSP_ERR_INVALID;
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   CTX_TRY(ctx, hipSetDevice(ctx->device));
   CTX_TRY(ctx, hipMemcpyAsync(ctx->accum.p, rgba, num_pixels * sizeof(q4), hipMemcpyHostToDevice, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -932,6 +1008,10 @@ int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels) {
 
 int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
   if (!ctx || !out) return GSP_ERR_INVALID;
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   CTX_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->dstats.p) {
     DevStats d;
@@ -955,6 +1035,10 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
 
 int gsp_reset_stats(gsp_context* ctx) {
   if (!ctx) return GSP_ERR_INVALID;
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   CTX_TRY(ctx, hipSetDevice(ctx->device));
   ctx->stats = gsp_stats{};
   if (ctx->dstats.p) {

@@ -239,7 +239,12 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height,
                     const uint32_t* pixel_ids, uint64_t num_pixels);
 
 /* Trace params->spp more samples for every owned pixel and fold them into the
- * accumulate buffer with the reference's running mean (raygen.rgen:84-108). */
+ * accumulate buffer with the reference's running mean (raygen.rgen:84-108).
+ * Returns once every sample has been injected into the path pool; the last
+ * paths may still be in flight (they share launches with the next call's
+ * samples) and samples are always folded in call / timestamp order.  gsp_sync,
+ * the download / copy / upload_accum calls, gsp_get_stats, gsp_reset_stats,
+ * gsp_frame_begin, gsp_upload_scene and gsp_ctx_destroy complete them first. */
 int gsp_render(gsp_context* ctx, const gsp_render_params* params);
 
 /* Block until all queued work of the context has finished. */

@@ -7,7 +7,7 @@ with g.Context(0) as ctx:
     ctx.upload_scene(sc); ctx.frame_begin(1920, 1080); ctx.render(spp=8); ts = 8
     best = None
     for rep in range(2):
-        ctx.reset_stats(); t = time.time(); ctx.render(spp=48, first_timestamp=ts, collect_kernel_times=1); dt = time.time() - t; ts += 48
+        ctx.reset_stats(); t = time.time(); ctx.render(spp=48, first_timestamp=ts, collect_kernel_times=1); ctx.sync(); dt = time.time() - t; ts += 48
         st = ctx.stats()
         r = ((st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, st["extend_kernel_ms"], st["shade_kernel_ms"], st["connect_kernel_ms"])
         best = r if best is None or r[0] > best[0] else best

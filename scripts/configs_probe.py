@@ -6,7 +6,7 @@ from gpuspectral_amd import scenes
 def run(name, sc, W, H, spp, **kw):
     with g.Context(0) as ctx:
         ctx.upload_scene(sc); ctx.frame_begin(W, H); ctx.render(spp=4, **kw); ctx.reset_stats()
-        t = time.time(); ctx.render(spp=spp, first_timestamp=4, **kw); dt = time.time() - t
+        t = time.time(); ctx.render(spp=spp, first_timestamp=4, **kw); ctx.sync(); dt = time.time() - t
         st = ctx.stats()
         print("%s: %d tris, %dx%d x %d spp: %.2f s, %.1f Mrays/s, %.1f Msamples/s, %.2f rays/sample, mem %.1f GB" % (
             name, st["num_triangles"], W, H, spp, dt, (st["extension_rays"] + st["shadow_rays"]) / dt / 1e6,

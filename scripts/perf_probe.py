@@ -18,6 +18,7 @@ def probe(name, sc, W, H, spp, K=0):
         ctx.reset_stats()
         t = time.time()
         ctx.render(spp=spp, first_timestamp=2, timestamps_in_flight=K, collect_kernel_times=1)
+        ctx.sync()
         dt = time.time() - t
         st = ctx.stats()
         rays = st["extension_rays"] + st["shadow_rays"]

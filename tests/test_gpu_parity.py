@@ -292,3 +292,42 @@ def test_checkpoint_resume(oracle_mod, cornell):
     b.close()
     ref, _ = oracle_mod.Oracle(cornell).render(48, 48, spp=7)
     assert np.array_equal(img, ref)
+
+
+def test_pipelined_calls_without_sync(ctx, oracle_mod, materials_scene):
+    """gsp_render only queues work: paths of earlier calls stay in flight while later calls inject theirs
+    (the reference's one-createRenderPass-per-frame loop, main.cpp:20-28).  24 one-sample calls, a change of
+    max_depth in between (forces a drain), and the ray counters must equal the all-at-once result."""
+    W, H = 72, 40
+    ctx.upload_scene(materials_scene)
+    ctx.frame_begin(W, H)
+    ctx.reset_stats()
+    for t in range(24):
+        ctx.render(spp=1, first_timestamp=t)
+    st_a = ctx.stats()
+    a = ctx.download().copy()
+    ctx.frame_begin(W, H)
+    ctx.reset_stats()
+    ctx.render(spp=24)
+    st_b = ctx.stats()
+    b = ctx.download().copy()
+    assert np.array_equal(a, b)
+    for k in ("extension_rays", "shadow_rays", "samples"):
+        assert st_a[k] == st_b[k], k
+    ref, st_o = oracle_mod.Oracle(materials_scene).render(W, H, spp=24)
+    assert np.array_equal(b.reshape(-1, 4), ref)
+    assert st_b["extension_rays"] == st_o["extension_rays"] and st_b["shadow_rays"] == st_o["shadow_rays"]
+    # integrator constants change while paths are in flight: earlier samples keep the old constants
+    ctx.frame_begin(W, H)
+    ctx.render(spp=5, first_timestamp=0, max_depth=3)
+    ctx.render(spp=5, first_timestamp=5, max_depth=50)
+    c = ctx.download().copy()
+    from gpuspectral_amd import abi
+
+    o = oracle_mod.Oracle(materials_scene)
+    p = abi.default_render_params(5, 0)
+    p.max_depth = 3
+    acc, _ = o.render(W, H, spp=5, params=p)
+    p.max_depth = 50
+    acc, _ = o.render(W, H, spp=5, first_timestamp=5, params=p, accum=acc)
+    assert np.array_equal(c.reshape(-1, 4), acc)
