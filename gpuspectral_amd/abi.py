@@ -200,3 +200,20 @@ class SceneArrays:
             d.camera.to_world[i] = float(self.to_world[i])
         d.camera.fov = float(self.fov)
         return d
+
+    def save(self, path):
+        """Write the flattened scene as one .npz (the POD arrays that cross the C ABI)."""
+        np.savez_compressed(
+            path, instances=self.instances, positions=self.positions, normals=self.normals, lights=self.lights,
+            to_world=np.asarray(self.to_world, np.float32), fov=np.float32(self.fov),
+            **{"bsdf_" + n: b for n, b in zip(BSDF_NAMES, self.bsdfs)})
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path)
+        s = cls()
+        s.instances = z["instances"].astype(INSTANCE_DT)
+        s.positions, s.normals, s.lights = z["positions"], z["normals"], z["lights"].astype(LIGHT_DT)
+        s.bsdfs = [z["bsdf_" + n].astype(dt) for n, dt in zip(BSDF_NAMES, BSDF_DTYPES)]
+        s.to_world, s.fov = z["to_world"].copy(), np.float32(z["fov"])
+        return s
