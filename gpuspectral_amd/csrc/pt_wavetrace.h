@@ -141,6 +141,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
   int32_t cur = kSentinel, leaf = 0;
   uint32_t ri = 0xffffffffu, best_id = 0xffffffffu, best_aux = 0;
   f3 o = mk3(0, 0, 0), inv = mk3(0, 0, 0);
+  bool negx = false, negy = false, negz = false;  // sign of 1/d per axis: which plane of a slab is the near one
   RayShear rs;
   rs.kx = rs.ky = rs.kz = 0;
   rs.Sx = rs.Sy = rs.Sz = 0.0f;
@@ -180,6 +181,9 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           f3 d;
           io.load(ri, o, d, tmin, tmax);
           inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+          negx = inv.x < 0.0f;
+          negy = inv.y < 0.0f;
+          negz = inv.z < 0.0f;
           rs = make_shear(d);
           h.t = tmax;
           h.u = h.v = 0.0f;
@@ -238,6 +242,12 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           const float dx = n0.x - o.x, dy = n0.y - o.y, dz = n0.z - o.z;
           const uint32_t qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z),
                          qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
+          // Near / far planes picked by the sign of 1/d instead of min / max per child: for inv > 0
+          // (lo - o) * inv <= (hi - o) * inv by monotonic rounding, so the values are the ones min / max
+          // would return; a NaN (0 * inf) is dropped by max3 / min3 and leaves that side unconstrained.
+          const uint32_t qnx = negx ? qhx : qlx, qfx = negx ? qlx : qhx;
+          const uint32_t qny = negy ? qhy : qly, qfy = negy ? qly : qhy;
+          const uint32_t qnz = negz ? qhz : qlz, qfz = negz ? qlz : qhz;
           float lo4[4];
           bool hit4[4];
 // (float)((q >> 8k) & 0xff) compiles to v_cvt_f32_ubyteK
@@ -247,11 +257,11 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
 #define GSP_UB3(q) ((float)((q) >> 24))
 #define GSP_CHILD(K, CVT)                                                                               \
   {                                                                                                     \
-    const float t0x = __builtin_fmaf(CVT(qlx), sx, dx) * inv.x, t1x = __builtin_fmaf(CVT(qhx), sx, dx) * inv.x; \
-    const float t0y = __builtin_fmaf(CVT(qly), sy, dy) * inv.y, t1y = __builtin_fmaf(CVT(qhy), sy, dy) * inv.y; \
-    const float t0z = __builtin_fmaf(CVT(qlz), sz, dz) * inv.z, t1z = __builtin_fmaf(CVT(qhz), sz, dz) * inv.z; \
-    const float lo = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));       \
-    const float hi = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), h.t));        \
+    const float tnx = __builtin_fmaf(CVT(qnx), sx, dx) * inv.x, tfx = __builtin_fmaf(CVT(qfx), sx, dx) * inv.x; \
+    const float tny = __builtin_fmaf(CVT(qny), sy, dy) * inv.y, tfy = __builtin_fmaf(CVT(qfy), sy, dy) * inv.y; \
+    const float tnz = __builtin_fmaf(CVT(qnz), sz, dz) * inv.z, tfz = __builtin_fmaf(CVT(qfz), sz, dz) * inv.z; \
+    const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));                                            \
+    const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, h.t));                                             \
     lo4[K] = lo;                                                                                        \
     hit4[K] = lo <= hi * 1.000001f;                                                                     \
   }
@@ -260,28 +270,33 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           GSP_CHILD(2, GSP_UB2)
           GSP_CHILD(3, GSP_UB3)
 #undef GSP_CHILD
-          const float l0 = lo4[0], l1 = lo4[1], l2 = lo4[2], l3 = lo4[3];
           const bool h0 = hit4[0] && c0 != kEmptyChild, h1 = hit4[1] && c1 != kEmptyChild,
                      h2 = hit4[2] && c2 != kEmptyChild, h3 = hit4[3] && c3 != kEmptyChild;
-          // order the hit children by entry distance: sort 4 keys = {distance bits | child slot}
-          uint32_t k0 = h0 ? ((__float_as_uint(l0) & 0x7ffffffcu) | 0u) : 0xffffffffu;
-          uint32_t k1 = h1 ? ((__float_as_uint(l1) & 0x7ffffffcu) | 1u) : 0xffffffffu;
-          uint32_t k2 = h2 ? ((__float_as_uint(l2) & 0x7ffffffcu) | 2u) : 0xffffffffu;
-          uint32_t k3 = h3 ? ((__float_as_uint(l3) & 0x7ffffffcu) | 3u) : 0xffffffffu;
-          uint32_t t;
-  #define GSP_CSWAP(a, b) t = min(a, b); b = max(a, b); a = t;
-          GSP_CSWAP(k0, k1)
-          GSP_CSWAP(k2, k3)
-          GSP_CSWAP(k0, k2)
-          GSP_CSWAP(k1, k3)
-          GSP_CSWAP(k1, k2)
+          // order the hit children by entry distance: 5-comparator network on {distance bits, child}
+          // (entry distances are >= tmin >= 0, so their bit patterns order like unsigned integers)
+          uint32_t k0 = h0 ? __float_as_uint(lo4[0]) : 0xffffffffu, k1 = h1 ? __float_as_uint(lo4[1]) : 0xffffffffu;
+          uint32_t k2 = h2 ? __float_as_uint(lo4[2]) : 0xffffffffu, k3 = h3 ? __float_as_uint(lo4[3]) : 0xffffffffu;
+          int32_t e0 = c0, e1 = c1, e2 = c2, e3 = c3;
+  #define GSP_CSWAP(ka, kb, ea, eb)                 \
+    {                                               \
+      const bool sw = kb < ka;                      \
+      const uint32_t tk = sw ? kb : ka;             \
+      kb = sw ? ka : kb;                            \
+      ka = tk;                                      \
+      const int32_t te = sw ? eb : ea;              \
+      eb = sw ? ea : eb;                            \
+      ea = te;                                      \
+    }
+          GSP_CSWAP(k0, k1, e0, e1)
+          GSP_CSWAP(k2, k3, e2, e3)
+          GSP_CSWAP(k0, k2, e0, e2)
+          GSP_CSWAP(k1, k3, e1, e3)
+          GSP_CSWAP(k1, k2, e1, e2)
   #undef GSP_CSWAP
           const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-  #define GSP_CODE(k) (((k) & 2u) ? (((k) & 1u) ? c3 : c2) : (((k) & 1u) ? c1 : c0))
-          stk.push_sorted(nh > 0 ? nh - 1 : 0, GSP_CODE(k1), GSP_CODE(k2), GSP_CODE(k3));
-          if (nh > 0) cur = GSP_CODE(k0);
+          stk.push_sorted(nh > 0 ? nh - 1 : 0, e1, e2, e3);
+          if (nh > 0) cur = e0;
           else cur = stk.pop();
-  #undef GSP_CODE
           if (cur < 0 && leaf == 0) {  // first leaf: postpone it and keep descending
             leaf = cur;
             cur = stk.pop();
