@@ -10,9 +10,9 @@
 // lever is lanes doing useful work per issued instruction.  Hence a flat, wave-uniform
 // state machine (every decision is a ballot + scalar branch, no divergent loops):
 //   * each lane owns a ray state {cur node, postponed leaf, stack}; per loop iteration the
-//     wave runs ONE node step for all lanes that sit on an inner node, and a leaf step
-//     (triangle tests) only when kLeafBatch lanes have a leaf pending or nothing else can
-//     run -- triangle tests execute with many lanes enabled instead of one at a time
+//     wave runs a few node steps for all lanes that sit on an inner node, and a leaf step
+//     (ONE triangle test per lane; longer leaves stay pending) only when kLeafBatch lanes have
+//     a leaf pending or nothing else can run -- triangle tests execute with many lanes enabled
 //     (leaf postponing after Aila & Laine 2009, re-tuned for 64 lanes);
 //   * lanes whose ray finished commit their result and are refilled from a wave-local pool
 //     as soon as kRefillLanes of them are idle; the pool takes 256-ray chunks from 8
@@ -216,14 +216,19 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
     // ---- one inner-node step for every lane that sits on an inner node ---------------------------
     const bool leaf_step = __popcll(leaf_m) >= kLeafBatch || node_m == 0;
     if (node_m != 0 && !leaf_step) {
+      // measured on the 1M-triangle bench scene (scripts/ab_variants.sh): closest-hit 3 steps while >= 32 lanes
+      // are on inner nodes, any-hit 4 steps while >= 24 are (+3.6 % Mrays/s over 2 steps / 40 lanes)
 #ifndef GSP_NODE_REPS
-#define GSP_NODE_REPS 2
+#define GSP_NODE_REPS (ANY ? 4 : 3)
+#endif
+#ifndef GSP_REP_LANES
+#define GSP_REP_LANES (ANY ? 24 : 32)
 #endif
       // up to GSP_NODE_REPS node steps per pass through the bookkeeping above, as long as most
       // lanes are still on inner nodes
       for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
         const bool on = (uint32_t)cur < (uint32_t)kSentinel;
-        if (rep > 0 && __popcll(__ballot(on)) < 40) break;
+        if (rep > 0 && __popcll(__ballot(on)) < GSP_REP_LANES) break;
       if (on) {
           // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip write_node4)
           const q4* nd = nodes + 4ll * cur;
@@ -306,12 +311,14 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       continue;
     }
     // ---- leaf step: triangle tests for every lane with a postponed leaf -----------------------------
+    // one triangle per lane per step: a leaf with more triangles stays pending (first + 1, count - 1), so
+    // short leaves do not idle while long ones finish and leaves that arrive in between join the next step
     if (leaf < 0) {
       const uint32_t c = (uint32_t)~leaf;
-      const uint32_t first = c >> 2, count = (c & 3u) + 1u;
+      const uint32_t first = c >> 2;
       bool stop = false;
-      for (uint32_t k = 0; k < count; ++k) {
-        const q4* p = tris + 3ll * (first + k);
+      {
+        const q4* p = tris + 3ll * first;
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
         if (STATS) ++c_tris;
         float t, u, v;
@@ -319,27 +326,31 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
                           v)) {
           if (ANY) {
             h.t = t;
-            h.slot = (int32_t)(first + k);
+            h.slot = (int32_t)first;
             stop = true;
-            break;
-          }
-          const uint32_t id = __float_as_uint(p0.w);
-          if (t < h.t || (t == h.t && id < best_id)) {
-            h.t = t;
-            h.u = u;
-            h.v = v;
-            h.slot = (int32_t)(first + k);
-            best_id = id;
-            best_aux = __float_as_uint(p1.w);
+          } else {
+            const uint32_t id = __float_as_uint(p0.w);
+            if (t < h.t || (t == h.t && id < best_id)) {
+              h.t = t;
+              h.u = u;
+              h.v = v;
+              h.slot = (int32_t)first;
+              best_id = id;
+              best_aux = __float_as_uint(p1.w);
+            }
           }
         }
       }
-      leaf = 0;
-      if (ANY && stop) {
-        cur = kSentinel;
-      } else if (cur < 0) {  // a second leaf was waiting in `cur`
-        leaf = cur;
-        cur = stk.pop();
+      if ((c & 3u) != 0u && !(ANY && stop)) {
+        leaf = ~(int32_t)(c + 3u);  // first + 1 (bits 2..), count - 1 (bits 0..1): +4 - 1
+      } else {
+        leaf = 0;
+        if (ANY && stop) {
+          cur = kSentinel;
+        } else if (cur < 0) {  // a second leaf was waiting in `cur`
+          leaf = cur;
+          cur = stk.pop();
+        }
       }
     }
   }

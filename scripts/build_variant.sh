@@ -1,0 +1,11 @@
+#!/bin/bash
+# scripts/build_variant.sh NAME "-DFLAG ..." : build libgpuspectral_pt.so with extra flags into lib/variants/NAME.so
+set -e
+cd "$(dirname "$0")/../gpuspectral_amd/csrc"
+mkdir -p build/var_$1 ../lib/variants
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $2"
+hipcc $F -c pt_render.hip -o build/var_$1/pt_render.o &
+hipcc $F -c pt_bvh.hip -o build/var_$1/pt_bvh.o &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/$1.so build/var_$1/pt_render.o build/var_$1/pt_bvh.o
+echo built $1
