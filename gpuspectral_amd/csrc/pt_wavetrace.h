@@ -39,6 +39,12 @@ constexpr int kLdsStackDepth = GSP_LDS_LEVELS;  // LDS levels per lane (1 KB per
 #ifndef GSP_LEAF_BATCH
 #define GSP_LEAF_BATCH 20
 #endif
+#ifndef GSP_STALL_BATCH
+#define GSP_STALL_BATCH 8
+#endif
+#ifndef GSP_LEAF_BATCH_CLOSEST
+#define GSP_LEAF_BATCH_CLOSEST 32
+#endif
 constexpr int kRefillLanes = GSP_REFILL_LANES;  // idle lanes that trigger a refill
 constexpr int kLeafBatch = GSP_LEAF_BATCH;      // pending leaves that trigger a leaf step
 constexpr uint32_t kChunkLarge = 256;       // rays per hand-out (big queues)
@@ -214,7 +220,11 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       continue;                             // (all lanes idle: the refill above runs next)
     }
     // ---- one inner-node step for every lane that sits on an inner node ---------------------------
-    const bool leaf_step = __popcll(leaf_m) >= kLeafBatch || node_m == 0;
+    // closest hit: lanes that cannot advance without a leaf step (leaf pending, no inner node to work on)
+    // trigger it early; lanes that still descend can wait for a fuller batch
+    const uint64_t stall_m = leaf_m & ~node_m;
+    const bool leaf_step = (!ANY && __popcll(stall_m) >= GSP_STALL_BATCH) ||
+                           __popcll(leaf_m) >= (ANY ? kLeafBatch : GSP_LEAF_BATCH_CLOSEST) || node_m == 0;
     if (node_m != 0 && !leaf_step) {
       // measured on the 1M-triangle bench scene (scripts/ab_variants.sh): closest-hit 3 steps while >= 32 lanes
       // are on inner nodes, any-hit 4 steps while >= 24 are (+3.6 % Mrays/s over 2 steps / 40 lanes)
