@@ -248,9 +248,10 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
                         c2 = (int32_t)__float_as_uint(n3.x), c3 = (int32_t)__float_as_uint(n3.y);
           // decode: plane = origin + q * 2^e, taken relative to the ray origin as
           // fma(q, scale, origin - o) (same rounding class as the uncompressed (b - o)), then * 1/d.
-          // (Folding the 1/d into per-node constants, t = fma(q, 2^e/d, (origin-o)/d), saves 36
-          // multiplies per step but measured 11 % / 48 % SLOWER for extend / connect on the same box
-          // with identical traversal statistics -- kept as three ops.)
+          // (Folding the 1/d into per-node constants, t = fma(q, 2^e/d, (origin-o)/d), removes 36 of the
+          // multiplies per step -- same instruction mix otherwise, identical nodes / triangles per ray --
+          // yet measured 13 % / 47 % SLOWER for extend / connect, three times, A/B on one box, at the same
+          // 2.35 GHz and LOWER board power (0.9 vs 1.0 kW: it stalls, it is not throttled).  Kept as three ops.)
           const uint32_t eb = __float_as_uint(n0.w);
           const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
                       sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);

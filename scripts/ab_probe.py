@@ -6,7 +6,7 @@ sc = scenes.interior(1_000_000)
 with g.Context(0) as ctx:
     ctx.upload_scene(sc); ctx.frame_begin(1920, 1080); ctx.render(spp=8); ts = 8
     best = None
-    for rep in range(2):
+    for rep in range(int(os.environ.get("REPS", "2"))):
         ctx.reset_stats(); t = time.time(); ctx.render(spp=48, first_timestamp=ts, collect_kernel_times=1); ctx.sync(); dt = time.time() - t; ts += 48
         st = ctx.stats()
         r = ((st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, st["extend_kernel_ms"], st["shade_kernel_ms"], st["connect_kernel_ms"])
