@@ -412,13 +412,12 @@ struct Entry4 {
 };
 
 // Writes one compressed 4-wide node (64 B, layout in pt_trace.h) from up to four child entries.
-__device__ void write_node4(q4* __restrict__ o, Entry4 (&e)[4], int cnt) {
+__device__ void write_node4(q4* __restrict__ o, Entry4 (&e)[4], int cnt, uint32_t dummy_slot) {
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   for (int k = 0; k < cnt; ++k) {
     lo[0] = fminf(lo[0], e[k].lo.x); lo[1] = fminf(lo[1], e[k].lo.y); lo[2] = fminf(lo[2], e[k].lo.z);
     hi[0] = fmaxf(hi[0], e[k].hi.x); hi[1] = fmaxf(hi[1], e[k].hi.y); hi[2] = fmaxf(hi[2], e[k].hi.z);
   }
-  uint32_t ebits = 0;
   float scale[3];
   for (int a = 0; a < 3; ++a) {
     const float ext = hi[a] - lo[a];
@@ -428,7 +427,6 @@ __device__ void write_node4(q4* __restrict__ o, Entry4 (&e)[4], int cnt) {
     // the largest code must reach the far side of the node
     while (eb < 254 && fmaf(255.0f, __uint_as_float((uint32_t)eb << 23), lo[a]) < hi[a]) ++eb;
     scale[a] = __uint_as_float((uint32_t)eb << 23);
-    ebits |= (uint32_t)eb << (8 * a);
   }
   uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // qlo.x, qlo.y, qlo.z, qhi.x, qhi.y, qhi.z : one byte per child
   for (int k = 0; k < cnt; ++k) {
@@ -442,24 +440,29 @@ __device__ void write_node4(q4* __restrict__ o, Entry4 (&e)[4], int cnt) {
       q[3 + a] |= (uint32_t)qh << (8 * k);
     }
   }
+  // unused slots: inverted box (near plane beyond the far plane: misses) that leads to the degenerate
+  // triangle, so the traversal needs no empty-slot test and a rounding fluke costs one triangle test
+  for (int k = cnt; k < 4; ++k)
+    for (int a = 0; a < 3; ++a) q[a] |= 255u << (8 * k);
   int32_t code[4];
-  for (int k = 0; k < 4; ++k) code[k] = k < cnt ? e[k].code : kEmptyChild;
-  o[0] = mkq(lo[0], lo[1], lo[2], __uint_as_float(ebits));
+  for (int k = 0; k < 4; ++k) code[k] = k < cnt ? e[k].code : make_leaf(dummy_slot, 1);
+  o[0] = mkq(lo[0], lo[1], lo[2], scale[0]);
   o[1] = mkq(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
   o[2] = mkq(__uint_as_float(q[4]), __uint_as_float(q[5]), __uint_as_float((uint32_t)code[0]),
              __uint_as_float((uint32_t)code[1]));
-  o[3] = mkq(__uint_as_float((uint32_t)code[2]), __uint_as_float((uint32_t)code[3]), 0.0f, 0.0f);
+  o[3] = mkq(__uint_as_float((uint32_t)code[2]), __uint_as_float((uint32_t)code[3]), scale[1], scale[2]);
 }
 
 // parity collapse: one thread per even-depth binary node
 __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restrict__ nodes2,
                                                   const uint32_t* __restrict__ flag,
-                                                  const uint32_t* __restrict__ idx4, q4* __restrict__ nodes4) {
+                                                  const uint32_t* __restrict__ idx4, q4* __restrict__ nodes4,
+                                                  uint32_t dummy_slot) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_int || !flag[i]) return;
   Entry4 e[4];
   int cnt = 0;
-  auto conv = [&](int32_t g) { return g < 0 ? g : (int32_t)idx4[g]; };
+  auto conv = [&](int32_t g) { return g < 0 ? g : (int32_t)(idx4[g] * 64u); };  // inner child = byte offset of its node
   auto expand = [&](int32_t c, q4 lo, q4 hi) {
     if (c < 0) {
       e[cnt].lo = lo;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restric
   const q4 a = me[0], b = me[1], d = me[2], k = me[3];
   expand((int32_t)__float_as_uint(k.x), mkq(a.x, a.y, a.z, 0.0f), mkq(a.w, b.x, b.y, 0.0f));
   expand((int32_t)__float_as_uint(k.y), mkq(b.z, b.w, d.x, 0.0f), mkq(d.y, d.z, d.w, 0.0f));
-  write_node4(nodes4 + 4ll * idx4[i], e, cnt);
+  write_node4(nodes4 + 4ll * idx4[i], e, cnt, dummy_slot);
 }
 
 // Greedy 4-wide collapse, one thread per output node of the current level.
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restric
 __global__ __launch_bounds__(kBlock) void k_collapse4(int count, const int2* __restrict__ qin,
                                                       const q4* __restrict__ nodes2, q4* __restrict__ nodes4,
                                                       uint32_t* __restrict__ next_id, int2* __restrict__ qout,
-                                                      uint32_t* __restrict__ qout_count) {
+                                                      uint32_t* __restrict__ qout_count, uint32_t dummy_slot) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= count) return;
   const int2 w = qin[t];
@@ -537,10 +540,10 @@ __global__ __launch_bounds__(kBlock) void k_collapse4(int count, const int2* __r
   for (int k = 0; k < cnt; ++k) {
     if (e[k].code >= 0) {
       qout[q0++] = make_int2(e[k].code, (int)id0);
-      e[k].code = (int32_t)id0++;
+      e[k].code = (int32_t)(id0++ * 64u);
     }
   }
-  write_node4(nodes4 + 4ll * w.y, e, cnt);
+  write_node4(nodes4 + 4ll * w.y, e, cnt, dummy_slot);
 }
 
 struct Scratch {
@@ -576,7 +579,8 @@ void free_bvh(DeviceBvh& b) {
 int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::string& err) {
   free_bvh(out);
   const uint32_t n = in.num_tris;
-  const uint32_t slots = n ? n : 1;  // an empty scene keeps one degenerate triangle (det == 0: never hit)
+  const uint32_t slots = n + 1;  // slot n is a degenerate all-zero triangle (det == 0: never hit): the target of
+                                  // empty child slots and the leaf of an empty scene
   out.num_tris = n;
   out.num_nodes = 0;
   size_t b_is = (size_t)slots * 48, b_sh = (size_t)slots * 64, b_map = (size_t)slots * 4;
@@ -587,7 +591,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(hipMemsetAsync(out.tri_isect, 0, b_is, stream));
   GSP_HIP_TRY(hipMemsetAsync(out.tri_shade, 0, b_sh, stream));
   GSP_HIP_TRY(hipMemsetAsync(out.slot_to_global, 0, b_map, stream));
-  out.root = make_leaf(0, 1);
+  out.root = make_leaf(0, 1);  // n == 0: slot 0 is the degenerate triangle
   out.depth = 0;
   if (n < 2) {  // no inner node: the root is the single (or dummy) triangle's leaf
     GSP_HIP_TRY(hipMalloc((void**)&out.nodes, 128));
@@ -711,14 +715,18 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       GSP_HIP_TRY(hipMemcpyAsync(&n4, idx4 + n_int, sizeof(n4), hipMemcpyDeviceToHost, stream));
       GSP_HIP_TRY(hipStreamSynchronize(stream));
       out.num_nodes = n4;
+      if ((uint64_t)n4 * 64ull >= 0x7fffff00ull) {
+        err = "scene too large: BVH node offsets exceed 31 bits";
+        return GSP_ERR_INVALID;
+      }
       const size_t b_nodes = (size_t)std::max<uint32_t>(n4, 1) * 64;
       GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
       out.bytes += b_nodes;
-      hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes);
+      hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes, n);
       uint32_t root4 = 0;  // the binary root has depth 0, so it owns a 4-wide node
       GSP_HIP_TRY(hipMemcpyAsync(&root4, idx4 + root2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       GSP_HIP_TRY(hipStreamSynchronize(stream));
-      out.root = (int32_t)root4;
+      out.root = (int32_t)(root4 * 64u);
       collapse_levels = 0;
     } else {
       // greedy SAH collapse, breadth-first; at most n - 1 output nodes
@@ -737,7 +745,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       collapse_levels = 0;
       while (count > 0) {
         hipLaunchKernelGGL(k_collapse4, dim3(blocks_for(count)), dim3(kBlock), 0, stream, (int)count, qa, nodes2, all4,
-                           ctr, qb, ctr + 1);
+                           ctr, qb, ctr + 1, n);
         uint32_t h[2];
         GSP_HIP_TRY(hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
         GSP_HIP_TRY(hipStreamSynchronize(stream));

@@ -8,14 +8,16 @@
 // HBM layout (all records are whole float4s so one lane moves 16 B per load):
 //   4-wide node (64 B, compressed; the kernels are bound by the number of divergent 16-B load
 //   instructions per node step, so a node is 4 loads instead of the 7 an uncompressed one needs):
-//                  q0 = {origin.x, origin.y, origin.z, bits(ex | ey << 8 | ez << 16)}
-//                       plane = origin + q * 2^(e - 127), q in 0..255 (per axis power-of-two scale)
+//                  q0 = {origin.x, origin.y, origin.z, scale.x}
+//                       plane = origin + q * scale, q in 0..255, scale = a power of two per axis
 //                  q1 = {qlo.x[child0..3], qlo.y[0..3], qlo.z[0..3], qhi.x[0..3]}   one byte per child
 //                  q2 = {qhi.y[0..3], qhi.z[0..3], bits(child0), bits(child1)}
-//                  q3 = {bits(child2), bits(child3), -, -}
+//                  q3 = {bits(child2), bits(child3), scale.y, scale.z}
 //           child boxes are quantised outward (floor / ceil, verified against the decode), so they
 //           contain the exact boxes: culling stays conservative and results do not change
-//           child >= 0 : inner node index;  0x7ffffffe : empty slot
+//           child >= 0 : inner node, BYTE offset of the node (index * 64) from the node array
+//           unused slot: inverted box (qlo = 255, qhi = 0) + the leaf of the degenerate triangle kept
+//                        in slot num_tris, so the traversal has no empty-slot test
 //           child <  0 : leaf, c = ~child, first slot = c >> 2, count = (c & 3) + 1
 //   (the host-side test harness tests/emu keeps an uncompressed binary layout of its own:
 //    q0 = {lmin.xyz, lmax.x} q1 = {lmax.yz, rmin.xy} q2 = {rmin.z, rmax.xyz} q3 = {left, right, -, -})

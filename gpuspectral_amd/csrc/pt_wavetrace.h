@@ -241,20 +241,19 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
         if (rep > 0 && __popcll(__ballot(on)) < GSP_REP_LANES) break;
       if (on) {
           // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip write_node4)
-          const q4* nd = nodes + 4ll * cur;
+          // (`cur` is the node's byte offset: 32-bit offset + uniform base, no 64-bit address arithmetic)
+          const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
           const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
           if (STATS) ++c_nodes;
           const int32_t c0 = (int32_t)__float_as_uint(n2.z), c1 = (int32_t)__float_as_uint(n2.w),
                         c2 = (int32_t)__float_as_uint(n3.x), c3 = (int32_t)__float_as_uint(n3.y);
-          // decode: plane = origin + q * 2^e, taken relative to the ray origin as
-          // fma(q, scale, origin - o) (same rounding class as the uncompressed (b - o)), then * 1/d.
-          // (Folding the 1/d into per-node constants, t = fma(q, 2^e/d, (origin-o)/d), removes 36 of the
-          // multiplies per step -- same instruction mix otherwise, identical nodes / triangles per ray --
-          // yet measured 13 % / 47 % SLOWER for extend / connect, three times, A/B on one box, at the same
-          // 2.35 GHz and LOWER board power (0.9 vs 1.0 kW: it stalls, it is not throttled).  Kept as three ops.)
-          const uint32_t eb = __float_as_uint(n0.w);
-          const float sx = __uint_as_float((eb & 0xffu) << 23), sy = __uint_as_float(((eb >> 8) & 0xffu) << 23),
-                      sz = __uint_as_float(((eb >> 16) & 0xffu) << 23);
+          // decode: plane = origin + q * scale (per-axis power of two, stored as a float), taken relative to
+          // the ray origin as fma(q, scale, origin - o) (same rounding class as the uncompressed (b - o)),
+          // then * 1/d.  (Folding 1/d into per-node constants, t = fma(q, scale/d, (origin-o)/d), is one
+          // multiply per plane cheaper but cancels catastrophically for rays with a tiny direction component:
+          // those rays lose their culling, run far longer than the rest and stretch every launch -- measured
+          // +13 % / +47 % kernel time at unchanged mean nodes per ray.)
+          const float sx = n0.w, sy = n3.z, sz = n3.w;
           const float dx = n0.x - o.x, dy = n0.y - o.y, dz = n0.z - o.z;
           const uint32_t qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z),
                          qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
@@ -286,8 +285,8 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           GSP_CHILD(2, GSP_UB2)
           GSP_CHILD(3, GSP_UB3)
 #undef GSP_CHILD
-          const bool h0 = hit4[0] && c0 != kEmptyChild, h1 = hit4[1] && c1 != kEmptyChild,
-                     h2 = hit4[2] && c2 != kEmptyChild, h3 = hit4[3] && c3 != kEmptyChild;
+          // (unused slots carry an inverted box and the degenerate triangle's leaf: no test needed)
+          const bool h0 = hit4[0], h1 = hit4[1], h2 = hit4[2], h3 = hit4[3];
           // order the hit children by entry distance: 5-comparator network on {distance bits, child}
           // (entry distances are >= tmin >= 0, so their bit patterns order like unsigned integers)
           uint32_t k0 = h0 ? __float_as_uint(lo4[0]) : 0xffffffffu, k1 = h1 ? __float_as_uint(lo4[1]) : 0xffffffffu;
