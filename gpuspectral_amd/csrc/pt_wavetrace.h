@@ -59,47 +59,57 @@ typedef __attribute__((address_space(3))) int32_t lds_i32;
 typedef __attribute__((address_space(1))) int32_t glb_i32;
 
 struct WaveStack {
-  lds_i32* lds;    // &lds_stack[threadIdx.x], stride kTraceBlock
+  lds_i32* lds;    // &lds_stack[threadIdx.x]; level L of this lane lives at lds + L * kTraceBlock
   glb_i32* spill;  // &spill[global thread], stride spill_stride
   uint32_t spill_stride;
-  int sp;
-  // Slow, per-lane form: LDS level or HBM spill level.
-  __device__ __forceinline__ void store_at(int level, int32_t v) {
-    if (level < kLdsStackDepth) lds[level * kTraceBlock] = v;
-    else spill[(size_t)(level - kLdsStackDepth) * spill_stride] = v;
+  // BYTE offset of the next free level from `lds` (level * kLevelBytes): a push or pop is one add and a
+  // ds access with an immediate offset -- no per-access shifts (v_lshl_or_b32 issues at half the rate
+  // of v_add_u32 on this chip, profiles/r01_h_microbench/valu_rate.txt)
+  uint32_t sp;
+  static constexpr uint32_t kLevelBytes = 4u * kTraceBlock;
+  static constexpr uint32_t kLdsBytes = (uint32_t)kLdsStackDepth * kLevelBytes;
+  __device__ __forceinline__ lds_i32* at(uint32_t off) const {
+    return (lds_i32*)((__attribute__((address_space(3))) char*)lds + off);
   }
-  __device__ __forceinline__ int32_t load_at(int level) {
+  // Slow, per-lane form: LDS level or HBM spill level.
+  __device__ __forceinline__ void store_at(uint32_t off, int32_t v) {
+    if (off < kLdsBytes) *at(off) = v;
+    else spill[(size_t)((off - kLdsBytes) / kLevelBytes) * spill_stride] = v;
+  }
+  __device__ __forceinline__ int32_t load_at(uint32_t off) {
     int32_t v;
-    if (level < kLdsStackDepth) v = lds[level * kTraceBlock];
-    else v = spill[(size_t)(level - kLdsStackDepth) * spill_stride];
+    if (off < kLdsBytes) v = *at(off);
+    else v = spill[(size_t)((off - kLdsBytes) / kLevelBytes) * spill_stride];
     return v;
   }
   __device__ __forceinline__ void push(int32_t v) {
     store_at(sp, v);
-    ++sp;
+    sp += kLevelBytes;
   }
   // Hot path: the LDS-or-spill decision is taken once per wave (a ballot and a scalar branch);
   // almost always every lane is inside the LDS levels and the access is a bare ds_read/ds_write.
   __device__ __forceinline__ int32_t pop() {
-    --sp;
-    if (__builtin_expect(__ballot(sp >= kLdsStackDepth) == 0, 1)) return lds[sp * kTraceBlock];
+    sp -= kLevelBytes;
+    if (__builtin_expect(__ballot(sp >= kLdsBytes) == 0, 1)) return *at(sp);
     return load_at(sp);
   }
-  // Pushes the `m` (0..3) entries e1 (nearest of the three) .. e3 (farthest), farthest first, without
-  // branches: an entry that does not exist is written to this lane's scratch level instead.
-  __device__ __forceinline__ void push_sorted(int m, int32_t e1, int32_t e2, int32_t e3) {
-    const int p1 = sp + m - 1, p2 = sp + m - 2, p3 = sp + m - 3;
-    if (__builtin_expect(__ballot(sp + 3 >= kLdsStackDepth - 1) == 0, 1)) {
-      const int scratch = kLdsStackDepth - 1;  // never a live level on this path (sp + 3 < scratch)
-      lds[(m > 0 ? p1 : scratch) * kTraceBlock] = e1;
-      lds[(m > 1 ? p2 : scratch) * kTraceBlock] = e2;
-      lds[(m > 2 ? p3 : scratch) * kTraceBlock] = e3;
+  // Pushes the m = mb / kLevelBytes (0..3) entries e1 (nearest of the three) .. e3 (farthest), farthest
+  // first.  Hot path: three stores at FIXED offsets from the old top -- which value goes where depends on m,
+  // and whatever lands above the new top is never read.
+  __device__ __forceinline__ void push_sorted(uint32_t mb, int32_t e1, int32_t e2, int32_t e3) {
+    if (__builtin_expect(__ballot(sp + 3u * kLevelBytes > kLdsBytes) == 0, 1)) {
+      const int32_t w0 = mb == 3u * kLevelBytes ? e3 : (mb == 2u * kLevelBytes ? e2 : e1);
+      const int32_t w1 = mb == 3u * kLevelBytes ? e2 : e1;
+      lds_i32* p = at(sp);
+      p[0] = w0;
+      p[kTraceBlock] = w1;
+      p[2 * kTraceBlock] = e1;
     } else {
-      if (m > 2) store_at(p3, e3);
-      if (m > 1) store_at(p2, e2);
-      if (m > 0) store_at(p1, e1);
+      if (mb > 2u * kLevelBytes) store_at(sp + mb - 3u * kLevelBytes, e3);
+      if (mb > kLevelBytes) store_at(sp + mb - 2u * kLevelBytes, e2);
+      if (mb > 0u) store_at(sp + mb - kLevelBytes, e1);
     }
-    sp += m;
+    sp += mb;
   }
 };
 
@@ -308,9 +318,10 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           GSP_CSWAP(k1, k3, e1, e3)
           GSP_CSWAP(k1, k2, e1, e2)
   #undef GSP_CSWAP
-          const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-          stk.push_sorted(nh > 0 ? nh - 1 : 0, e1, e2, e3);
-          if (nh > 0) cur = e0;
+          constexpr uint32_t L = WaveStack::kLevelBytes;  // hit count kept in stack-offset units
+          const uint32_t nb = (h0 ? L : 0u) + (h1 ? L : 0u) + (h2 ? L : 0u) + (h3 ? L : 0u);
+          stk.push_sorted(nb > 0u ? nb - L : 0u, e1, e2, e3);
+          if (nb > 0u) cur = e0;
           else cur = stk.pop();
           if (cur < 0 && leaf == 0) {  // first leaf: postpone it and keep descending
             leaf = cur;
