@@ -453,7 +453,7 @@ struct gsp_context {
     return v;
   }
 #ifndef GSP_BLOCKS_PER_CU
-#define GSP_BLOCKS_PER_CU 6
+#define GSP_BLOCKS_PER_CU 7  // 7 x 22 KB LDS stack, 7 waves per SIMD (A/B: 5 -> -4 %, 6 -> -1 %, 8 spills)
 #endif
   uint32_t max_blocks() const { return (uint32_t)num_cus * GSP_BLOCKS_PER_CU; }  // resident 256-thread blocks per CU
   uint32_t grid_for(uint64_t n) const {
@@ -942,6 +942,12 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   P.remaining += rp->spp;
   return pipeline_run(ctx, false);
 }
+
+#ifdef GSP_WAVE_PROFILE
+extern "C" void gsp_debug_wave_profile(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsp::g_wave_profile), 16 * sizeof(unsigned long long));
+}
+#endif
 
 int gsp_sync(gsp_context* ctx) {
   if (!ctx) return GSP_ERR_INVALID;

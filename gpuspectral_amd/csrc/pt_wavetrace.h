@@ -27,10 +27,10 @@ namespace gsp {
 
 constexpr int kTraceBlock = 256;
 #ifndef GSP_LDS_LEVELS
-#define GSP_LDS_LEVELS 24
+#define GSP_LDS_LEVELS 22
 #endif
 #ifndef GSP_TRACE_WAVES
-#define GSP_TRACE_WAVES 1
+#define GSP_TRACE_WAVES 7  // waves per SIMD the register allocator must allow (<= 72 VGPRs; 8 would spill)
 #endif
 constexpr int kLdsStackDepth = GSP_LDS_LEVELS;  // LDS levels per lane (1 KB per level per block)
 #ifndef GSP_REFILL_LANES
@@ -113,6 +113,11 @@ struct WaveStack {
   }
 };
 
+#ifdef GSP_WAVE_PROFILE
+// [0] node steps (per wave) [1] lanes enabled in them [2] leaf steps [3] lanes enabled [4] loop passes
+// [5] refill passes [6] lanes refilled [7] lanes idle (no ray) summed over node steps [8] lanes stalled (leaf pending, no node) over node steps
+__device__ unsigned long long g_wave_profile[16];
+#endif
 struct TraceStatsOut {
   unsigned long long* nodes;
   unsigned long long* tris;
@@ -168,7 +173,13 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
   h.slot = -1;
   uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
 
+#ifdef GSP_WAVE_PROFILE
+  unsigned long long wp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {
+#ifdef GSP_WAVE_PROFILE
+    ++wp[4];
+#endif
     // ---- commit finished rays ------------------------------------------------------------
     if (ri != 0xffffffffu && cur == kSentinel && leaf == 0) {
       io.store(ri, h, best_aux);
@@ -177,6 +188,10 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
     // ---- refill idle lanes from the wave-local pool -----------------------------------------
     uint64_t idle_m = __ballot(ri == 0xffffffffu);
     if (!exhausted && __popcll(idle_m) >= kRefillLanes) {
+#ifdef GSP_WAVE_PROFILE
+      ++wp[5];
+      wp[6] += __popcll(idle_m);
+#endif
       while (idle_m) {  // wave-uniform
         if (pool_next >= pool_end) {
           uint32_t k = 0;
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           negy = inv.y < 0.0f;
           negz = inv.z < 0.0f;
           rs = make_shear(d);
+          rs.Sz = comp(inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
           h.t = tmax;
           h.u = h.v = 0.0f;
           h.slot = -1;
@@ -249,6 +265,12 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
         const bool on = (uint32_t)cur < (uint32_t)kSentinel;
         if (rep > 0 && __popcll(__ballot(on)) < GSP_REP_LANES) break;
+#ifdef GSP_WAVE_PROFILE
+        ++wp[0];
+        wp[1] += __popcll(__ballot(on));
+        wp[7] += __popcll(__ballot(ri == 0xffffffffu));
+        wp[8] += __popcll(__ballot(ri != 0xffffffffu && !on));
+#endif
       if (on) {
           // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip write_node4)
           // (`cur` is the node's byte offset: 32-bit offset + uniform base, no 64-bit address arithmetic)
@@ -332,6 +354,10 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       continue;
     }
     // ---- leaf step: triangle tests for every lane with a postponed leaf -----------------------------
+#ifdef GSP_WAVE_PROFILE
+    ++wp[2];
+    wp[3] += __popcll(__ballot(leaf < 0));
+#endif
     // one triangle per lane per step: a leaf with more triangles stays pending (first + 1, count - 1), so
     // short leaves do not idle while long ones finish and leaves that arrive in between join the next step
     if (leaf < 0) {
@@ -375,6 +401,10 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       }
     }
   }
+#ifdef GSP_WAVE_PROFILE
+  if (lane == 0 && !ANY)
+    for (int k = 0; k < 9; ++k) atomicAdd(&g_wave_profile[k], wp[k]);
+#endif
   if (STATS) {
     const unsigned long long a = wave_sum_u64(c_nodes), b = wave_sum_u64(c_tris), c = wave_sum_u64(c_rays);
     if (lane == 0) {
