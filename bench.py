@@ -76,7 +76,7 @@ def cpu_baseline(sc, args, scene_name):
     from gpuspectral_amd import scenes
     from oracle import oracle as orc
 
-    threads = os.cpu_count() or 1
+    threads = orc.usable_cpus()
     o = orc.Oracle(sc)
     W, H = args.width, args.height
     # probe 1/64 of the frame at 1 spp to size the sample for ~cpu_seconds
@@ -84,10 +84,13 @@ def cpu_baseline(sc, args, scene_name):
     _, st = o.render(W, H, spp=1, pixel_ids=ids, threads=threads)
     rate = (st["extension_rays"] + st["shadow_rays"]) / max(st["seconds"], 1e-9)
     per_px = (st["extension_rays"] + st["shadow_rays"]) / max(len(ids), 1)
-    want_px = int(min(W * H, max(len(ids), args.cpu_seconds * rate / max(per_px, 1e-9))))
-    parts = max(1, int(round(W * H / want_px)))
+    want_px = max(len(ids), args.cpu_seconds * rate / max(per_px, 1e-9))
+    if want_px >= W * H:  # the hosts are fast enough for whole frames: several samples per pixel
+        spp_c, parts = int(min(64, max(1, round(want_px / (W * H))))), 1
+    else:
+        spp_c, parts = 1, max(1, int(round(W * H / want_px)))
     ids = scenes.tile_pixel_ids(W, H, 0, parts, tile=16)
-    _, st = o.render(W, H, spp=1, pixel_ids=ids, threads=threads)
+    _, st = o.render(W, H, spp=spp_c, pixel_ids=ids, threads=threads)
     rays = st["extension_rays"] + st["shadow_rays"]
     return {
         "value": rays / st["seconds"] / 1e6,
@@ -95,8 +98,8 @@ def cpu_baseline(sc, args, scene_name):
         "cores": threads,
         "kind": "port",
         "msamples_per_s": st["samples"] / st["seconds"] / 1e6,
-        "sample": "%s, %dx%d, 1 spp on %d pixels (every %d-th 16x16 tile), %.1f s, scalar C++ oracle with %d std::threads; BVH build %.2f s excluded"
-        % (scene_name, W, H, len(ids), parts, st["seconds"], threads, o.build_seconds),
+        "sample": "%s, %dx%d, %d spp on %d pixels (every %d-th 16x16 tile), %.1f s, scalar C++ oracle with %d std::threads (= the CPUs the cgroup grants); BVH build %.2f s excluded"
+        % (scene_name, W, H, spp_c, len(ids), parts, st["seconds"], threads, o.build_seconds),
     }
 
 

@@ -14,6 +14,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def usable_cpus():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes
+    show 256 hardware threads but grant 16 CPUs of time; oversubscribing a quota only adds throttling stalls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 class OracleStats(C.Structure):
     _fields_ = [
         ("extension_rays", C.c_uint64),
@@ -110,6 +123,8 @@ class Oracle:
         """Returns (accum[n,4] float32, stats dict).  accum is updated in place when given."""
         p = params or abi.default_render_params(spp, first_timestamp)
         p.spp, p.first_timestamp = spp, first_timestamp
+        if threads <= 0:
+            threads = usable_cpus()
         if pixel_ids is not None:
             pixel_ids = np.ascontiguousarray(pixel_ids, np.uint32)
             n = len(pixel_ids)

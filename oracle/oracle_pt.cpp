@@ -657,7 +657,12 @@ int oracle_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixe
   const uint64_t chunk = 256;
   auto t0 = std::chrono::steady_clock::now();
   auto worker = [&](int tid) {
-    Counters& C = counters[tid];
+    Counters C;  // thread-local: neighbouring elements of `counters` share cache lines
+    struct Flush {
+      Counters& dst;
+      Counters& src;
+      ~Flush() { dst = src; }
+    } flush{counters[tid], C};
     for (;;) {
       uint64_t b = next.fetch_add(chunk);
       if (b >= npix) break;
