@@ -106,10 +106,10 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     isect[3ull * g + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float(g));
     isect[3ull * g + 1] = mkq(p1.x, p1.y, p1.z, __uint_as_float(I.bsdf >> 16));  // BSDF type of the hit, for the shade sort
     isect[3ull * g + 2] = mkq(p2.x, p2.y, p2.z, 0.0f);
-    shade[4ull * g + 0] = mkq(N.x, N.y, N.z, __uint_as_float(a));
-    shade[4ull * g + 1] = mkq(n0.x, n0.y, n0.z, 0.0f);
-    shade[4ull * g + 2] = mkq(n1.x, n1.y, n1.z, 0.0f);
-    shade[4ull * g + 3] = mkq(n2.x, n2.y, n2.z, 0.0f);
+    shade[4ull * g + 0] = mkq(N.x, N.y, N.z, __uint_as_float(pack_material(I.bsdf, I.twofaced)));
+    shade[4ull * g + 1] = mkq(n0.x, n0.y, n0.z, I.emission[0]);
+    shade[4ull * g + 2] = mkq(n1.x, n1.y, n1.z, I.emission[1]);
+    shade[4ull * g + 3] = mkq(n2.x, n2.y, n2.z, I.emission[2]);
     const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
     float l[3], h[3];
 #pragma unroll

@@ -380,7 +380,6 @@ struct gsp_context {
   // scene
   bool have_scene = false;
   DeviceBvh bvh;
-  DevBuf<InstanceRec> instances;
   DevBuf<gsp_diffuse_bsdf> b0;
   DevBuf<gsp_smooth_dielectric_bsdf> b1;
   DevBuf<gsp_smooth_conductor_bsdf> b2;
@@ -438,7 +437,6 @@ struct gsp_context {
     v.nodes = bvh.nodes;
     v.tri_isect = bvh.tri_isect;
     v.tri_shade = bvh.tri_shade;
-    v.instances = instances.p;
     v.bsdf.diffuse = b0.p;
     v.bsdf.smooth_dielectric = b1.p;
     v.bsdf.smooth_conductor = b2.p;
@@ -605,7 +603,6 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   auto t0 = std::chrono::steady_clock::now();
   hipStream_t st = ctx->stream;
   // ---- PathTracer::prepareScene (PathTracer.cpp:58-93): per-instance table ----
-  std::vector<InstanceRec> recs(sc->num_instances);
   std::vector<float> inv_t(16ull * sc->num_instances);
   std::vector<uint32_t> tri_first(sc->num_instances + 1ull);
   uint32_t acc = 0;
@@ -614,18 +611,10 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     float tr[16];
     transpose4(in.transform, tr);
     inverse4(tr, &inv_t[16ull * i]);
-    InstanceRec& r = recs[i];
-    std::memset(&r, 0, sizeof(r));
-    r.emission[0] = in.emission[0];
-    r.emission[1] = in.emission[1];
-    r.emission[2] = in.emission[2];
-    r.bsdf = in.bsdf;
-    r.twofaced = in.twofaced;
     tri_first[i] = acc;
     acc += in.vertex_count / 3;
   }
   tri_first[sc->num_instances] = acc;
-  CTX_TRY(ctx, ctx->instances.upload(recs.data(), recs.size(), st, &ctx->bytes));
   CTX_TRY(ctx, ctx->b0.upload(sc->diffuse_bsdfs, sc->num_bsdfs[0], st, &ctx->bytes));
   CTX_TRY(ctx, ctx->b1.upload(sc->smooth_dielectric_bsdfs, sc->num_bsdfs[1], st, &ctx->bytes));
   CTX_TRY(ctx, ctx->b2.upload(sc->smooth_conductor_bsdfs, sc->num_bsdfs[2], st, &ctx->bytes));

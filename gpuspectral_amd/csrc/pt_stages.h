@@ -20,13 +20,11 @@
 
 namespace gsp {
 
-// per-instance shading record (32 B)
-struct InstanceRec {
-  float emission[3];
-  uint32_t bsdf;
-  uint32_t twofaced;
-  uint32_t pad[3];
-};
+// The per-instance shading data of RenderState::Instance (emission, bsdf, twofaced; PathTracer.h:27-34) is baked
+// into the w components of every triangle's shading packet: one dependent fetch less per shaded vertex.
+GSP_HD uint32_t pack_material(uint32_t bsdf, uint32_t twofaced) {
+  return (bsdf & 0x7fffffffu) | (twofaced == 1u ? 0x80000000u : 0u);
+}
 
 struct RenderConsts {
   uint32_t width, height;
@@ -40,8 +38,7 @@ struct RenderConsts {
 struct SceneView {
   const q4* nodes;
   const q4* tri_isect;  // 3 quads per slot
-  const q4* tri_shade;  // 4 quads per slot: {N, bits(instance)}, {n0}, {n1}, {n2}
-  const InstanceRec* instances;
+  const q4* tri_shade;  // 4 quads per slot: {N, bits(bsdf | twofaced << 31)}, {n0, emission.r}, {n1, .g}, {n2, .b}
   BsdfTables bsdf;
   const gsp_triangle_light* lights;
   uint32_t num_lights;
@@ -111,15 +108,17 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   uint32_t rng = in.seed;                                                 // rchit:668
   const q4* sp = S.tri_shade + 4ll * hit.slot;
   const q4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-  const InstanceRec inst = S.instances[f2u(s0.w)];                        // :672
-  const f3 emission = mk3(inst.emission[0], inst.emission[1], inst.emission[2]);
+  const uint32_t material = f2u(s0.w);                                    // :672 (instance record, baked per triangle)
+  const uint32_t bsdf = material & 0x7fffffffu;
+  const bool twofaced = (material >> 31) != 0u;
+  const f3 emission = mk3(s1.w, s2.w, s3.w);
   const f3 rayDir = in.d;                                                 // :696
   const f3 position = in.o + rayDir * hit.t;                              // :692
   const float b0 = (1.0f - hit.u) - hit.v;                                // :690
   f3 SN = normalize((b0 * mk3(s1.x, s1.y, s1.z) + hit.u * mk3(s2.x, s2.y, s2.z)) + hit.v * mk3(s3.x, s3.y, s3.z));
   f3 N = mk3(s0.x, s0.y, s0.z);                                           // :694 (precomputed at bake)
   if (dot(N, -rayDir) < 0.0f) {                                           // :698-707
-    if (inst.twofaced == 1 && emission.x == 0.0f && emission.y == 0.0f && emission.z == 0.0f) {
+    if (twofaced && emission.x == 0.0f && emission.y == 0.0f && emission.z == 0.0f) {
       N = N * -1.0f;
       SN = SN * -1.0f;
     }
@@ -128,7 +127,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   const f3 wo = normalize(to_local(onb, -rayDir));                        // :713
   BsdfResult bs;
   f3 wi_l;
-  bsdf_sample(S.bsdf, inst.bsdf, rng, wo, wi_l, bs);                      // :716
+  bsdf_sample(S.bsdf, bsdf, rng, wo, wi_l, bs);                      // :716
   const float NoW = gabs(wi_l.z);                                         // :717
   const f3 wi = to_world(onb, wi_l);                                      // :718
 
@@ -140,9 +139,9 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   const float NoL = gabs(dot(SN, L));                                     // :725
   const float lightPdf = ls.pdf;
   BsdfResult lb;
-  bsdf_eval(S.bsdf, inst.bsdf, wo, wL, lb);                               // :729
+  bsdf_eval(S.bsdf, bsdf, wo, wL, lb);                               // :729
 
-  const bool transmits = bsdf_transmits(inst.bsdf);
+  const bool transmits = bsdf_transmits(bsdf);
   const float NdotV = dot(N, -rayDir);
   // :735-736 gate; `lightPdf != 0` (:750) is known before tracing
   const bool want_shadow = !bs.delta && ((NdotV > 0.0f && dot(N, L) > 0.0f) || transmits) && (lightPdf != 0.0f);

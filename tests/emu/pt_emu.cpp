@@ -54,7 +54,6 @@ struct Emu {
   std::vector<gsp_rough_floor_bsdf> b6;
   std::vector<gsp_rough_plastic_bsdf> b7;
   std::vector<gsp_triangle_light> lights;
-  std::vector<InstanceRec> recs;
   std::vector<q4> nodes, isect, shade;
   std::vector<uint32_t> slot_to_global;
   std::vector<float> lo, hi;  // per slot padded boxes
@@ -82,10 +81,10 @@ struct Emu {
         gi.push_back(mkq(p0.x, p0.y, p0.z, u2f(g)));
         gi.push_back(mkq(p1.x, p1.y, p1.z, 0));
         gi.push_back(mkq(p2.x, p2.y, p2.z, 0));
-        gs.push_back(mkq(N.x, N.y, N.z, u2f(a)));
-        gs.push_back(mkq(n0.x, n0.y, n0.z, 0));
-        gs.push_back(mkq(n1.x, n1.y, n1.z, 0));
-        gs.push_back(mkq(n2.x, n2.y, n2.z, 0));
+        gs.push_back(mkq(N.x, N.y, N.z, u2f(pack_material(I.bsdf, I.twofaced))));
+        gs.push_back(mkq(n0.x, n0.y, n0.z, I.emission[0]));
+        gs.push_back(mkq(n1.x, n1.y, n1.z, I.emission[1]));
+        gs.push_back(mkq(n2.x, n2.y, n2.z, I.emission[2]));
         const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
         float l3[3], h3[3];
         for (int c = 0; c < 3; ++c) {
@@ -174,7 +173,6 @@ struct Emu {
     view.nodes = nodes.data();
     view.tri_isect = isect.data();
     view.tri_shade = shade.data();
-    view.instances = recs.data();
     view.bsdf.diffuse = b0.data();
     view.bsdf.smooth_dielectric = b1.data();
     view.bsdf.smooth_conductor = b2.data();
@@ -216,16 +214,10 @@ void* emu_create(const gsp_scene_desc* sc) {
   copyv(e->b7, sc->rough_plastic_bsdfs, sc->num_bsdfs[7]);
   copyv(e->lights, sc->lights, sc->num_lights);
   e->inv_t.resize(16ull * sc->num_instances);
-  e->recs.resize(sc->num_instances);
   for (uint32_t i = 0; i < sc->num_instances; ++i) {
     float tr[16];
     transpose4(e->instances[i].transform, tr);
     inverse4(tr, &e->inv_t[16ull * i]);
-    InstanceRec& r = e->recs[i];
-    std::memset(&r, 0, sizeof(r));
-    for (int k = 0; k < 3; ++k) r.emission[k] = e->instances[i].emission[k];
-    r.bsdf = e->instances[i].bsdf;
-    r.twofaced = e->instances[i].twofaced;
   }
   e->bake();
   return e;
