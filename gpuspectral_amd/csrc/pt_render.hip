@@ -190,6 +190,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts
   __shared__ uint16_t s_order[kShadeBlock];    // sorted position -> thread offset inside the tile
   __shared__ uint32_t s_cnt[2][kShadeWaves];   // per-wave survivor / shadow counts of this iteration
   __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave start in the global queues
+  __shared__ q4 s_hq[kShadeBlock], s_p0[kShadeBlock], s_p1[kShadeBlock], s_p2[kShadeBlock];
+  __shared__ uint32_t s_fl[kShadeBlock];
   if (threadIdx.x < kMaxSlots) s_dead[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
@@ -209,8 +211,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts
       __syncthreads();
       const uint32_t i0 = tile + threadIdx.x;
       uint32_t key = 9;
+      // the tile is read in queue order (fully coalesced) and handed to its sorted position through LDS
       if (i0 < n) {
-        const uint32_t w = fb(hits[i0].w);
+        const q4 hq0 = hits[i0];
+        s_hq[threadIdx.x] = hq0;
+        s_p0[threadIdx.x] = cur.P0[i0];
+        s_p1[threadIdx.x] = cur.P1[i0];
+        s_p2[threadIdx.x] = cur.P2[i0];
+        s_fl[threadIdx.x] = cur.FL[i0];
+        const uint32_t w = fb(hq0.w);
         key = (w == 0xffffffffu) ? 8u : ((w >> 28) & 7u);
       }
       const uint32_t rank = atomicAdd(&s_bin[key], 1u);
@@ -227,15 +236,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts
       s_order[s_bin[key] + rank] = (uint16_t)threadIdx.x;
       __syncthreads();
     }
-    const uint32_t i = tile + s_order[threadIdx.x];
+    const uint32_t src = s_order[threadIdx.x];
+    const uint32_t i = tile + src;
     bool alive = false, has_shadow = false;
     uint32_t my_sid = 0;
     ShadeOut out;
     if (i < n) {
-      // everything that does not depend on the hit is requested up front (one latency, not two)
-      const q4 hq = hits[i];
-      const q4 p0 = cur.P0[i], p1 = cur.P1[i], p2 = cur.P2[i];
-      const uint32_t fl = cur.FL[i];
+      const q4 hq = s_hq[src];
+      const q4 p0 = s_p0[src], p1 = s_p1[src], p2 = s_p2[src];
+      const uint32_t fl = s_fl[src];
       my_sid = fb(p1.w);
       HitRec h;
       h.t = hq.x;
