@@ -261,3 +261,37 @@ def test_tone_map_and_ppm(tmp_path):
     host.write_ppm(p, x)
     raw = open(p, "rb").read()
     assert raw.startswith(b"P6\n3 2\n255\n") and len(raw) == len(b"P6\n3 2\n255\n") + 18
+
+
+def test_scene_arrays_npz_round_trip(tmp_path, cornell):
+    """SceneArrays.save / load (the scene cache scripts/export_reference_scenes.py ships to the GPU box)."""
+    from gpuspectral_amd import abi
+
+    f = str(tmp_path / "scene.npz")
+    cornell.save(f)
+    back = abi.SceneArrays.load(f)
+    assert back.num_triangles == cornell.num_triangles
+    assert np.array_equal(back.instances, cornell.instances) and np.array_equal(back.positions, cornell.positions)
+    assert np.array_equal(back.normals, cornell.normals) and np.array_equal(back.lights, cornell.lights)
+    for a, b in zip(back.bsdfs, cornell.bsdfs):
+        assert np.array_equal(a, b)
+    assert np.array_equal(back.to_world, cornell.to_world) and back.fov == cornell.fov
+
+
+def test_usable_cpus_respects_cgroup_quota(oracle_mod, monkeypatch, tmp_path):
+    """cpu_baseline.cores must be the CPUs actually granted (the GPU boxes show 256 threads, quota 16)."""
+    import builtins
+
+    n = oracle_mod.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text("200000 100000\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert oracle_mod.usable_cpus() == min(2, len(os.sched_getaffinity(0)))
