@@ -89,10 +89,12 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t num_pixels, uint32_t K,
                                                       uint32_t first_timestamp,
                                                       const uint32_t* __restrict__ pixel_ids, PathQueue q,
-                                                      uint32_t offset, uint32_t sid_base, q4* __restrict__ result) {
+                                                      uint32_t offset, uint32_t sid_base, q4* __restrict__ result,
+                                                      uint32_t lane, uint32_t lanes) {
+  // num_pixels = pixels of this pipeline lane: owned pixel lp * lanes + lane for lp in [0, num_pixels)
   const uint64_t total = (uint64_t)num_pixels * K;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
-    const uint32_t k = (uint32_t)(i / num_pixels), lp = (uint32_t)(i % num_pixels);
+    const uint32_t k = (uint32_t)(i / num_pixels), lp = (uint32_t)(i % num_pixels) * lanes + lane;
     const uint32_t gid = pixel_ids ? pixel_ids[lp] : lp;
     const uint32_t sid = sid_base + (uint32_t)i;
     PathState p;
@@ -333,10 +335,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts
 
 // ---- resolve ----------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_t K, uint32_t first_timestamp,
-                                                     const q4* __restrict__ result, q4* __restrict__ accum) {
-  for (uint32_t lp = blockIdx.x * kBlock + threadIdx.x; lp < num_pixels; lp += gridDim.x * kBlock) {
+                                                     const q4* __restrict__ result, q4* __restrict__ accum,
+                                                     uint32_t lane, uint32_t lanes) {
+  for (uint32_t l = blockIdx.x * kBlock + threadIdx.x; l < num_pixels; l += gridDim.x * kBlock) {
+    const uint64_t lp = (uint64_t)l * lanes + lane;
     q4 a = accum[lp];
-    for (uint32_t k = 0; k < K; ++k) resolve_sample(first_timestamp + k, result[(uint64_t)k * num_pixels + lp], a);
+    for (uint32_t k = 0; k < K; ++k) resolve_sample(first_timestamp + k, result[(uint64_t)k * num_pixels + l], a);
     accum[lp] = a;
   }
 }
@@ -411,26 +415,16 @@ struct gsp_context {
   std::vector<uint32_t> pixel_ids_host;
   DevBuf<q4> accum;
 
-  // pool
-  uint64_t pool_cap = 0, result_cap = 0;
-  DevBuf<q4> P0[2], P1[2], P2[2], hits, result, S0, S1, S2, S3;
-  DevBuf<uint32_t> FL[2];
-  DevBuf<uint32_t> counters;
   DevBuf<DevStats> dstats;
-  DevBuf<int32_t> spill;
   uint32_t spill_stride = 0;
-  uint32_t* h_counters = nullptr;  // pinned
-
   gsp_stats stats{};
-  std::vector<hipEvent_t> ev;
 
-  // streaming pipeline state: survives across gsp_render calls, drained by gsp_sync & friends
+  // Streaming pipeline state: survives across gsp_render calls, drained by gsp_sync & friends.
   struct Batch {
     uint32_t t0, kb, slot;
   };
   struct Pipeline {
     bool active = false;
-    gsp_render_params params{};
     uint64_t Kb = 1, batch_paths = 0, pool_target = 0, cap = 0;
     uint32_t num_slots = 0;
     std::deque<Batch> inflight;
@@ -439,7 +433,34 @@ struct gsp_context {
     int cur = 0;
     uint32_t iteration = 0;
     uint32_t next_ts = 0, remaining = 0;
-  } pipe;
+  };
+  // The owned pixels are dealt to kLanes independent pipelines (pixel lp belongs to lane lp % lanes), each
+  // with its own pool, counters and stream.  While the host reads one lane's counters back and queues its
+  // next iteration, the other lane's kernels keep the GPU busy, and a latency-bound k_shade of one lane
+  // overlaps a VALU-bound k_trace of the other.  Same arithmetic per pixel, so the image does not depend on
+  // the lane count.  Default 1 lane: with the large pool the second lane adds 2-3 %, and concurrent kernels
+  // make per-kernel durations (the roofline measurement) meaningless.
+  struct Lane {
+    uint32_t index = 0;
+    hipStream_t stream = nullptr;
+    uint64_t num_pixels = 0;
+    uint64_t pool_cap = 0, result_cap = 0;
+    DevBuf<q4> P0[2], P1[2], P2[2], hits, result, S0, S1, S2, S3;
+    DevBuf<uint32_t> FL[2];
+    DevBuf<uint32_t> counters;
+    DevBuf<int32_t> spill;
+    uint32_t* h_counters = nullptr;  // pinned
+    std::vector<hipEvent_t> ev;
+    Pipeline pipe;
+    bool in_flight = false;   // an iteration is queued on `stream` and its counters have not been read back
+    uint64_t it_n = 0;        // paths of that iteration
+    bool it_timing = false;
+  };
+  static constexpr int kMaxLanes = 2;
+  Lane lanes[kMaxLanes];
+  uint32_t num_lanes = 1;  // GSP_LANES=2: +2-3 % with the 32 M-path pool, but per-kernel event times overlap
+  gsp_render_params pipe_params{};  // integrator constants the lanes are running with
+  bool pipe_active = false;
 
   SceneView view() const {
     SceneView v;
@@ -481,7 +502,7 @@ struct gsp_context {
     const uint32_t bound = 3 * bvh.depth + 4;
     const uint32_t need = bound > (uint32_t)kLdsStackDepth ? bound - kLdsStackDepth : 1;
     spill_stride = max_blocks() * kBlock;
-    GSP_HIP_TRY(spill.ensure((size_t)need * spill_stride, &bytes));
+    for (uint32_t l = 0; l < num_lanes; ++l) GSP_HIP_TRY(lanes[l].spill.ensure((size_t)need * spill_stride, &bytes));
     return GSP_OK;
   }
 };
@@ -529,6 +550,7 @@ static void set_create_error(const std::string& s) {
 }
 
 static int pipeline_drain(gsp_context* ctx);
+void gsp_ctx_destroy(gsp_context* ctx);
 
 int gsp_ctx_create(int device, gsp_context** out) {
   if (!out) return GSP_ERR_INVALID;
@@ -554,13 +576,19 @@ int gsp_ctx_create(int device, gsp_context** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_counters, 1024, hipHostMallocDefault);
+  if (const char* nl = getenv("GSP_LANES")) c->num_lanes = (uint32_t)std::min(std::max(atoi(nl), 1), (int)gsp_context::kMaxLanes);
+  for (uint32_t l = 0; l < c->num_lanes && e == hipSuccess; ++l) {
+    gsp_context::Lane& L = c->lanes[l];
+    L.index = l;
+    e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&L.h_counters, 1024, hipHostMallocDefault);
+    if (e == hipSuccess) std::memset(L.h_counters, 0, 1024);
+  }
   if (e != hipSuccess) {
     set_create_error(std::string("context setup: ") + hipGetErrorString(e));
-    delete c;
+    gsp_ctx_destroy(c);
     return GSP_ERR_DEVICE;
   }
-  std::memset(c->h_counters, 0, 1024);
   *out = c;
   return GSP_OK;
 }
@@ -570,9 +598,13 @@ void gsp_ctx_destroy(gsp_context* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)pipeline_drain(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+  for (gsp_context::Lane& L : ctx->lanes) {
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    for (hipEvent_t e : L.ev) (void)hipEventDestroy(e);
+    if (L.h_counters) (void)hipHostFree(L.h_counters);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
   free_bvh(ctx->bvh);
-  if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -696,6 +728,8 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uin
   ctx->width = width;
   ctx->height = height;
   ctx->num_pixels = num_pixels;
+  for (uint32_t l = 0; l < ctx->num_lanes; ++l)
+    ctx->lanes[l].num_pixels = (num_pixels + ctx->num_lanes - 1 - l) / ctx->num_lanes;  // owned pixels lp with lp % lanes == l
   CTX_TRY(ctx, ctx->accum.ensure(num_pixels, &ctx->bytes));
   CTX_TRY(ctx, hipMemsetAsync(ctx->accum.p, 0, std::max<uint64_t>(num_pixels, 1) * sizeof(q4), ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -703,49 +737,38 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uin
   return GSP_OK;
 }
 
-static int ensure_pool(gsp_context* ctx, uint64_t cap, uint64_t result_entries) {
-  if (result_entries > ctx->result_cap) {
-    CTX_TRY(ctx, ctx->result.ensure(result_entries, &ctx->bytes));
-    ctx->result_cap = result_entries;
+static int ensure_pool(gsp_context* ctx, gsp_context::Lane& L, uint64_t cap, uint64_t result_entries) {
+  if (result_entries > L.result_cap) {
+    CTX_TRY(ctx, L.result.ensure(result_entries, &ctx->bytes));
+    L.result_cap = result_entries;
   }
-  if (!ctx->counters.p) {
-    CTX_TRY(ctx, ctx->counters.ensure(C_COUNT, &ctx->bytes));
-    CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, C_COUNT * sizeof(uint32_t), ctx->stream));
+  if (!L.counters.p) {
+    CTX_TRY(ctx, L.counters.ensure(C_COUNT, &ctx->bytes));
+    CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, C_COUNT * sizeof(uint32_t), L.stream));
   }
   if (!ctx->dstats.p) {
     CTX_TRY(ctx, ctx->dstats.ensure(1, &ctx->bytes));
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
+    CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
-  if (cap <= ctx->pool_cap) return GSP_OK;
+  if (cap <= L.pool_cap) return GSP_OK;
   for (int k = 0; k < 2; ++k) {
-    CTX_TRY(ctx, ctx->P0[k].ensure(cap, &ctx->bytes));
-    CTX_TRY(ctx, ctx->P1[k].ensure(cap, &ctx->bytes));
-    CTX_TRY(ctx, ctx->P2[k].ensure(cap, &ctx->bytes));
-    CTX_TRY(ctx, ctx->FL[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, L.P0[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, L.P1[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, L.P2[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, L.FL[k].ensure(cap, &ctx->bytes));
   }
-  CTX_TRY(ctx, ctx->hits.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, ctx->S0.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, ctx->S1.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, ctx->S2.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, ctx->S3.ensure(cap, &ctx->bytes));
-  ctx->pool_cap = cap;
+  CTX_TRY(ctx, L.hits.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, L.S0.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, L.S1.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, L.S2.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, L.S3.ensure(cap, &ctx->bytes));
+  L.pool_cap = cap;
   return GSP_OK;
 }
 
-// Runs the streaming pipeline: injects the queued samples and iterates extend / shade / connect.
-// drain == false: returns as soon as every queued sample has been injected (stragglers of the last
-// batches stay in flight and ride along with the next call's launches); drain == true: runs until
-// nothing is in flight and every batch has been folded into the accumulate buffer.
-static int pipeline_run(gsp_context* ctx, bool drain) {
-  gsp_context::Pipeline& P = ctx->pipe;
-  if (!P.active) return GSP_OK;
-  const auto t_begin = std::chrono::steady_clock::now();
-  hipStream_t st = ctx->stream;
-  const gsp_render_params* rp = &P.params;
-  const uint64_t npix = ctx->num_pixels;
-  const uint64_t batch_paths = P.batch_paths, pool_target = P.pool_target, cap = P.cap;
-  const uint32_t num_slots = P.num_slots;
-
+static RenderConsts render_consts(const gsp_context* ctx) {
+  const gsp_render_params* rp = &ctx->pipe_params;
   RenderConsts rcst;
   rcst.width = ctx->width;
   rcst.height = ctx->height;
@@ -758,127 +781,193 @@ static int pipeline_run(gsp_context* ctx, bool drain) {
   rcst.cam_origin[0] = ctx->camera.to_world[12];  // Camera::getPosition, Camera.cpp:41-45
   rcst.cam_origin[1] = ctx->camera.to_world[13];
   rcst.cam_origin[2] = ctx->camera.to_world[14];
+  return rcst;
+}
 
-  const SceneView view = ctx->view();
+// Queues one iteration of a lane on its stream without waiting: new batches while there is room, then
+// extend / shade / connect over the lane's dense queues and the copy of its counters to the host.
+static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderConsts& rcst, const SceneView& view) {
+  gsp_context::Pipeline& P = L.pipe;
+  hipStream_t st = L.stream;
+  const gsp_render_params* rp = &ctx->pipe_params;
+  const uint64_t npix = L.num_pixels;
+  const uint64_t batch_paths = P.batch_paths;
   const bool stats_mode = rp->collect_traversal_stats != 0;
   const bool timing = rp->collect_kernel_times != 0;  // per-kernel HIP event timing (bench)
-  if (timing && ctx->ev.size() < 6) {
-    while (ctx->ev.size() < 6) {
-      hipEvent_t e;
-      CTX_TRY(ctx, hipEventCreate(&e));
-      ctx->ev.push_back(e);
-    }
+  while (timing && L.ev.size() < 4) {
+    hipEvent_t e;
+    CTX_TRY(ctx, hipEventCreate(&e));
+    L.ev.push_back(e);
   }
   PathQueue Q[2];
-  for (int k = 0; k < 2; ++k) Q[k] = PathQueue{ctx->P0[k].p, ctx->P1[k].p, ctx->P2[k].p, ctx->FL[k].p};
-  ShadowQueue SQ{ctx->S0.p, ctx->S1.p, ctx->S2.p, ctx->S3.p};
+  for (int k = 0; k < 2; ++k) Q[k] = PathQueue{L.P0[k].p, L.P1[k].p, L.P2[k].p, L.FL[k].p};
+  ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p};
   const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
 
-  while (P.remaining > 0 || (drain && (P.n > 0 || !P.inflight.empty()))) {
-    // ---- inject new batches while there is room ----
-    while (P.remaining > 0 && P.n < pool_target) {
-      const uint32_t kb = (uint32_t)std::min<uint64_t>(P.Kb, P.remaining);
-      uint32_t slot = num_slots;
-      for (uint32_t s2 = 0; s2 < num_slots; ++s2)
-        if (!P.slot_used[s2]) {
-          slot = s2;
-          break;
-        }
-      if (slot == num_slots || P.n + (uint64_t)kb * npix > cap) break;
-      const uint64_t paths = (uint64_t)kb * npix;
-      hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
-                         ctx->subset ? ctx->pixel_ids.p : nullptr, Q[P.cur], (uint32_t)P.n,
-                         (uint32_t)(slot * batch_paths), ctx->result.p);
-      CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->counters.p + C_LIVE + slot), (int)paths, 1, st));
-      ctx->h_counters[C_LIVE + slot] = (uint32_t)paths;  // not resolvable before the next read-back
-      P.slot_used[slot] = 1;
-      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot});
-      P.n += paths;
-      P.next_ts += kb;
-      P.remaining -= kb;
-    }
-    if (P.n > 0) {
-      const uint64_t n = P.n;
-      const int cur = P.cur;
-      const uint32_t bounce = P.iteration++;
-      const uint32_t chunk = n >= (1u << 20) ? kChunkLarge : kChunkSmall;
-      const uint32_t grid = ctx->trace_grid(n, chunk);
-      CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, 2 * sizeof(uint32_t), st));
-      CTX_TRY(ctx, hipMemsetAsync(ctx->counters.p + C_WORK_EXT, 0, (C_COUNT - C_WORK_EXT) * sizeof(uint32_t), st));
-      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-      {
-        const ExtendIO io{Q[cur], ctx->hits.p};
-        uint32_t* work = ctx->counters.p + C_WORK_EXT;
-        if (stats_mode)
-          hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, ctx->spill.p,
-                             ctx->spill_stride, so_ext);
-        else
-          hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, ctx->spill.p,
-                             ctx->spill_stride, so_ext);
+  // ---- inject new batches while there is room ----
+  while (P.remaining > 0 && P.n < P.pool_target) {
+    const uint32_t kb = (uint32_t)std::min<uint64_t>(P.Kb, P.remaining);
+    uint32_t slot = P.num_slots;
+    for (uint32_t s2 = 0; s2 < P.num_slots; ++s2)
+      if (!P.slot_used[s2]) {
+        slot = s2;
+        break;
       }
-      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-      const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
-          1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2 * (1024 / kShadeBlock)));
-      hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], ctx->hits.p,
-                         Q[cur ^ 1], SQ, ctx->result.p, ctx->counters.p, (uint32_t)batch_paths, ctx->dstats.p);
-      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-      {
-        const ConnectIO io{SQ, Q[cur ^ 1].P2, ctx->result.p, rcst.clamp};
-        uint32_t* work = ctx->counters.p + C_WORK_SH;
-        if (stats_mode)
-          hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, chunk, io, work,
-                             ctx->spill.p, ctx->spill_stride, so_sh);
-        else
-          hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes,
-                             view.tri_isect, view.root, (const uint32_t*)(ctx->counters.p + C_SHADOW), 0u, chunk, io, work,
-                             ctx->spill.p, ctx->spill_stride, so_sh);
-      }
-      if (timing) CTX_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-      CTX_TRY(ctx, hipMemcpyAsync(ctx->h_counters, ctx->counters.p, (C_LIVE + kMaxSlots) * sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, st));
-      CTX_TRY(ctx, hipStreamSynchronize(st));
-      CTX_TRY(ctx, hipGetLastError());
-      ctx->stats.extension_rays += n;
-      ctx->stats.shadow_rays += ctx->h_counters[C_SHADOW];
-      if (timing) {
-        float ms = 0.0f, e_ms = 0.0f, s_ms = 0.0f;
-        CTX_TRY(ctx, hipEventElapsedTime(&e_ms, ctx->ev[0], ctx->ev[1]));
-        ctx->stats.extend_kernel_ms += e_ms;
-        ctx->stats.extend_launches += 1;
-        CTX_TRY(ctx, hipEventElapsedTime(&s_ms, ctx->ev[1], ctx->ev[2]));
-        ctx->stats.shade_kernel_ms += s_ms;
-        CTX_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
-        ctx->stats.connect_kernel_ms += ms;
-        if (getenv("GSP_TRACE_BOUNCES"))
-          fprintf(stderr, "iter %3u: n %9llu shadow %9u inflight %2zu | extend %8.3f ms shade %8.3f ms connect %8.3f ms\n",
-                  bounce, (unsigned long long)n, ctx->h_counters[C_SHADOW], P.inflight.size(), e_ms, s_ms, ms);
-      }
-      P.n = ctx->h_counters[C_NEXT];
-      P.cur ^= 1;
-    }
-    // ---- fold finished batches into the accumulate buffer, strictly in timestamp order ----
-    while (!P.inflight.empty() && ctx->h_counters[C_LIVE + P.inflight.front().slot] == 0) {
-      const gsp_context::Batch b = P.inflight.front();
-      P.inflight.pop_front();
-      hipLaunchKernelGGL(k_resolve, dim3(ctx->grid_for(npix)), dim3(kBlock), 0, st, (uint32_t)npix, b.kb, b.t0,
-                         ctx->result.p + (uint64_t)b.slot * batch_paths, ctx->accum.p);
-      CTX_TRY(ctx, hipGetLastError());
-      P.slot_used[b.slot] = 0;
-      ctx->stats.samples += (uint64_t)b.kb * npix;
-    }
-    if (P.n == 0 && P.remaining == 0 && !P.inflight.empty()) {
-      ctx->err = "internal error: paths exhausted with unresolved sample batches";
-      return GSP_ERR_DEVICE;
-    }
+    if (slot == P.num_slots || P.n + (uint64_t)kb * npix > P.cap) break;
+    const uint64_t paths = (uint64_t)kb * npix;
+    hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
+                       ctx->subset ? ctx->pixel_ids.p : nullptr, Q[P.cur], (uint32_t)P.n, (uint32_t)(slot * batch_paths),
+                       L.result.p, L.index, ctx->num_lanes);
+    CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(L.counters.p + C_LIVE + slot), (int)paths, 1, st));
+    L.h_counters[C_LIVE + slot] = (uint32_t)paths;  // not resolvable before the next read-back
+    P.slot_used[slot] = 1;
+    P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot});
+    P.n += paths;
+    P.next_ts += kb;
+    P.remaining -= kb;
   }
-  CTX_TRY(ctx, hipStreamSynchronize(st));
-  if (drain) P.active = false;
-  ctx->stats.render_seconds +=
-      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  if (P.n == 0) return GSP_OK;
+  const uint64_t n = P.n;
+  const int cur = P.cur;
+  const uint32_t chunk = n >= (1u << 20) ? kChunkLarge : kChunkSmall;
+  const uint32_t grid = ctx->trace_grid(n, chunk);
+  CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, 2 * sizeof(uint32_t), st));
+  CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_WORK_EXT, 0, (C_COUNT - C_WORK_EXT) * sizeof(uint32_t), st));
+  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[0], st));
+  {
+    const ExtendIO io{Q[cur], L.hits.p};
+    uint32_t* work = L.counters.p + C_WORK_EXT;
+    if (stats_mode)
+      hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                         view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, L.spill.p, ctx->spill_stride,
+                         so_ext);
+    else
+      hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                         view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, L.spill.p, ctx->spill_stride,
+                         so_ext);
+  }
+  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[1], st));
+  const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
+      1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2 * (1024 / kShadeBlock)));
+  hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], L.hits.p,
+                     Q[cur ^ 1], SQ, L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
+  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[2], st));
+  {
+    const ConnectIO io{SQ, Q[cur ^ 1].P2, L.result.p, rcst.clamp};
+    uint32_t* work = L.counters.p + C_WORK_SH;
+    if (stats_mode)
+      hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                         view.root, (const uint32_t*)(L.counters.p + C_SHADOW), 0u, chunk, io, work, L.spill.p,
+                         ctx->spill_stride, so_sh);
+    else
+      hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                         view.root, (const uint32_t*)(L.counters.p + C_SHADOW), 0u, chunk, io, work, L.spill.p,
+                         ctx->spill_stride, so_sh);
+  }
+  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[3], st));
+  CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, (C_LIVE + kMaxSlots) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  L.in_flight = true;
+  L.it_n = n;
+  L.it_timing = timing;
+  return GSP_OK;
+}
+
+// Waits for the lane's queued iteration, reads its counters and folds finished batches into the
+// accumulate buffer, strictly in timestamp order.
+static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
+  gsp_context::Pipeline& P = L.pipe;
+  hipStream_t st = L.stream;
+  if (L.in_flight) {
+    CTX_TRY(ctx, hipStreamSynchronize(st));
+    CTX_TRY(ctx, hipGetLastError());
+    L.in_flight = false;
+    ctx->stats.extension_rays += L.it_n;
+    ctx->stats.shadow_rays += L.h_counters[C_SHADOW];
+    const uint32_t bounce = P.iteration++;
+    if (L.it_timing) {
+      float ms = 0.0f, e_ms = 0.0f, s_ms = 0.0f;
+      CTX_TRY(ctx, hipEventElapsedTime(&e_ms, L.ev[0], L.ev[1]));
+      ctx->stats.extend_kernel_ms += e_ms;
+      ctx->stats.extend_launches += 1;
+      CTX_TRY(ctx, hipEventElapsedTime(&s_ms, L.ev[1], L.ev[2]));
+      ctx->stats.shade_kernel_ms += s_ms;
+      CTX_TRY(ctx, hipEventElapsedTime(&ms, L.ev[2], L.ev[3]));
+      ctx->stats.connect_kernel_ms += ms;
+      if (getenv("GSP_TRACE_BOUNCES"))
+        fprintf(stderr, "lane %u iter %3u: n %9llu shadow %9u inflight %2zu | extend %8.3f ms shade %8.3f ms connect %8.3f ms\n",
+                L.index, bounce, (unsigned long long)L.it_n, L.h_counters[C_SHADOW], P.inflight.size(), e_ms, s_ms, ms);
+    }
+    P.n = L.h_counters[C_NEXT];
+    P.cur ^= 1;
+  }
+  while (!P.inflight.empty() && L.h_counters[C_LIVE + P.inflight.front().slot] == 0) {
+    const gsp_context::Batch b = P.inflight.front();
+    P.inflight.pop_front();
+    hipLaunchKernelGGL(k_resolve, dim3(ctx->grid_for(L.num_pixels)), dim3(kBlock), 0, st, (uint32_t)L.num_pixels, b.kb, b.t0,
+                       L.result.p + (uint64_t)b.slot * P.batch_paths, ctx->accum.p, L.index, ctx->num_lanes);
+    CTX_TRY(ctx, hipGetLastError());
+    P.slot_used[b.slot] = 0;
+    ctx->stats.samples += (uint64_t)b.kb * L.num_pixels;
+  }
+  if (P.n == 0 && P.remaining == 0 && !P.inflight.empty()) {
+    ctx->err = "internal error: paths exhausted with unresolved sample batches";
+    return GSP_ERR_DEVICE;
+  }
+  return GSP_OK;
+}
+
+// Runs the streaming pipelines.  drain == false: returns as soon as every queued sample has been
+// injected (stragglers of the last batches stay in flight and ride along with the next call's
+// launches); drain == true: runs until nothing is in flight and every batch has been folded into the
+// accumulate buffer.  The lanes alternate: while the host waits for one lane's counters the other
+// lane's iteration is already queued.
+static int pipeline_run(gsp_context* ctx, bool drain) {
+  if (!ctx->pipe_active) return GSP_OK;
+  const auto t_begin = std::chrono::steady_clock::now();
+  const RenderConsts rcst = render_consts(ctx);
+  const SceneView view = ctx->view();
+  auto has_work = [&](const gsp_context::Lane& L) {
+    const gsp_context::Pipeline& P = L.pipe;
+    return P.active && (P.remaining > 0 || (drain && (P.n > 0 || !P.inflight.empty())));
+  };
+  uint32_t turn = 0;
+  for (;;) {
+    for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
+      gsp_context::Lane& L = ctx->lanes[l];
+      if (!L.in_flight && has_work(L)) {
+        int rc = lane_enqueue(ctx, L, rcst, view);
+        if (rc != GSP_OK) return rc;
+        if (!L.in_flight) {  // nothing left to trace: only batches to fold
+          rc = lane_collect(ctx, L);
+          if (rc != GSP_OK) return rc;
+        }
+      }
+    }
+    int pick = -1;
+    for (uint32_t k = 0; k < ctx->num_lanes; ++k) {
+      const uint32_t l = (turn + k) % ctx->num_lanes;
+      if (ctx->lanes[l].in_flight) {
+        pick = (int)l;
+        break;
+      }
+    }
+    if (pick < 0) {
+      bool more = false;
+      for (uint32_t l = 0; l < ctx->num_lanes; ++l) more = more || has_work(ctx->lanes[l]);
+      if (!more) break;
+      continue;
+    }
+    int rc = lane_collect(ctx, ctx->lanes[pick]);
+    if (rc != GSP_OK) return rc;
+    turn = ((uint32_t)pick + 1) % ctx->num_lanes;
+  }
+  for (uint32_t l = 0; l < ctx->num_lanes; ++l) CTX_TRY(ctx, hipStreamSynchronize(ctx->lanes[l].stream));
+  if (drain) {
+    ctx->pipe_active = false;
+    for (uint32_t l = 0; l < ctx->num_lanes; ++l) ctx->lanes[l].pipe.active = false;
+  }
+  ctx->stats.render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
   return GSP_OK;
 }
 
@@ -897,47 +986,58 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   }
   CTX_TRY(ctx, hipSetDevice(ctx->device));
   if (rp->spp == 0 || ctx->num_pixels == 0) return GSP_OK;
-  gsp_context::Pipeline& P = ctx->pipe;
-  const uint64_t npix = ctx->num_pixels;
   // A running pipeline is continued when the integrator constants and the batch size are unchanged
   // (paths in flight carry no copy of them); otherwise it is drained first.
-  uint64_t Kb = rp->timestamps_in_flight;
-  if (Kb == 0) Kb = std::max<uint64_t>(1, (1ull << 20) / npix);
-  while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
-  if (P.active && (P.params.max_depth != rp->max_depth || P.params.rr_start_depth != rp->rr_start_depth ||
-                   P.params.clamp != rp->clamp || P.Kb != Kb)) {
+  if (ctx->pipe_active &&
+      (ctx->pipe_params.max_depth != rp->max_depth || ctx->pipe_params.rr_start_depth != rp->rr_start_depth ||
+       ctx->pipe_params.clamp != rp->clamp || ctx->pipe_params.timestamps_in_flight != rp->timestamps_in_flight)) {
     int rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
   }
-  if (!P.active) {
-    // Streaming path pool.  Samples enter in batches of Kb timestamps (>= ~1M paths); a new batch is
-    // injected whenever the pool has room, so every launch works on ~8M paths even though 95 % of a
-    // batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
+  if (!ctx->pipe_active) {
+    // Streaming path pool, per lane.  Samples enter in batches of Kb timestamps (>= ~1M paths); a new batch
+    // is injected whenever the pool has room, so every launch works on millions of paths even though 95 %
+    // of a batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
     // owns a slot of the sample-result ring and is folded into the accumulate buffer, in timestamp
     // order, once its live count has dropped to zero.
-    P.Kb = Kb;
-    P.batch_paths = Kb * npix;
-    P.pool_target = std::max<uint64_t>(8ull << 20, 2 * P.batch_paths);
-    P.cap = P.pool_target + P.batch_paths;
-    P.num_slots = (uint32_t)std::min<uint64_t>(
-        kMaxSlots, std::max<uint64_t>(4, 8 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths)));
-    if (P.cap >= (1ull << 32) || (uint64_t)P.num_slots * P.batch_paths >= (1ull << 32)) {
-      ctx->err = "frame too large for 32-bit path indices";
-      return GSP_ERR_INVALID;
+    // paths in flight over all lanes: per-launch fixed costs (drained wave tails, launch gaps, the host's
+    // counter read-back) amortise over the pool size -- bench: 8 M 5.35, 12 M 5.76, 24 M 6.11, 48 M 6.16, 96 M 6.25
+    // Grays/s; 32 M paths = 5.9 GB of queues
+    uint64_t total_target = 32ull << 20;
+    if (const char* e = getenv("GSP_POOL_PATHS")) total_target = std::max<uint64_t>(1ull << 16, strtoull(e, nullptr, 10));
+    for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
+      gsp_context::Lane& L = ctx->lanes[l];
+      gsp_context::Pipeline& P = L.pipe;
+      P = gsp_context::Pipeline{};
+      const uint64_t npix = L.num_pixels;
+      if (npix == 0) continue;  // fewer pixels than lanes
+      uint64_t Kb = rp->timestamps_in_flight;
+      if (Kb == 0) Kb = std::max<uint64_t>(1, (1ull << 20) / npix);
+      while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
+      P.Kb = Kb;
+      P.batch_paths = Kb * npix;
+      P.pool_target = std::max<uint64_t>(total_target / ctx->num_lanes, 2 * P.batch_paths);
+      P.cap = P.pool_target + P.batch_paths;
+      P.num_slots = (uint32_t)std::min<uint64_t>(
+          kMaxSlots, std::max<uint64_t>(4, 8 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths)));
+      if (P.cap >= (1ull << 32) || (uint64_t)P.num_slots * P.batch_paths >= (1ull << 32)) {
+        ctx->err = "frame too large for 32-bit path indices";
+        return GSP_ERR_INVALID;
+      }
+      int rc = ensure_pool(ctx, L, P.cap, (uint64_t)P.num_slots * P.batch_paths);
+      if (rc != GSP_OK) return rc;
+      P.slot_used.assign(P.num_slots, 0);
+      P.active = true;
     }
-    int rc = ensure_pool(ctx, P.cap, (uint64_t)P.num_slots * P.batch_paths);
-    if (rc != GSP_OK) return rc;
-    P.inflight.clear();
-    P.slot_used.assign(P.num_slots, 0);
-    P.n = 0;
-    P.cur = 0;
-    P.iteration = 0;
-    P.remaining = 0;
-    P.active = true;
+    ctx->pipe_active = true;
   }
-  P.params = *rp;  // (stats / timing flags may change from call to call)
-  P.next_ts = rp->first_timestamp;
-  P.remaining += rp->spp;
+  ctx->pipe_params = *rp;  // (stats / timing flags may change from call to call)
+  for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
+    gsp_context::Pipeline& P = ctx->lanes[l].pipe;
+    if (!P.active) continue;
+    P.next_ts = rp->first_timestamp;
+    P.remaining += rp->spp;
+  }
   return pipeline_run(ctx, false);
 }
 
@@ -1074,11 +1174,11 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   if (any_hit)
     hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
                        view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, kChunkSmall, io, d_work.p,
-                       ctx->spill.p, ctx->spill_stride, none);
+                       ctx->lanes[0].spill.p, ctx->spill_stride, none);
   else
     hipLaunchKernelGGL((k_trace<false, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
                        view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, kChunkSmall, io, d_work.p,
-                       ctx->spill.p, ctx->spill_stride, none);
+                       ctx->lanes[0].spill.p, ctx->spill_stride, none);
   CTX_TRY(ctx, hipGetLastError());
   CTX_TRY(ctx, hipMemcpyAsync(hits, d_hits.p, n * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));

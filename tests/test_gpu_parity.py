@@ -417,3 +417,32 @@ def test_triangle_soup_hits_do_not_depend_on_bvh(ctx, oracle_mod):
     sh[:, 7] = np.random.RandomState(3).uniform(0.05, 5.0, len(sh)).astype(np.float32)
     g2, r2 = ctx.trace(sh, any_hit=True), o.trace(sh, any_hit=True)
     assert (g2["prim"] == r2["prim"]).all()
+
+
+def test_two_pipeline_lanes_give_the_same_image(oracle_mod, materials_scene, monkeypatch):
+    """GSP_LANES=2 deals the owned pixels to two independent pipelines on two streams; the per-pixel arithmetic
+    is unchanged, so the frame, the ray counts and a pixel-subset context are bit-identical to one lane."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd.scenes import tile_pixel_ids
+
+    W, H, spp = 71, 45, 9  # odd pixel count: the lanes own different numbers of pixels
+    out = {}
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("GSP_LANES", lanes)
+        with g.Context(0) as c:
+            c.upload_scene(materials_scene)
+            c.frame_begin(W, H)
+            for t in range(0, spp, 3):
+                c.render(spp=3, first_timestamp=t)
+            st = c.stats()
+            out[lanes] = (c.download().copy(), st["extension_rays"], st["shadow_rays"], st["samples"])
+            ids = tile_pixel_ids(W, H, 1, 3, tile=8)
+            c.frame_begin(W, H, ids)
+            c.render(spp=spp)
+            sub = c.download_compact()
+            assert np.array_equal(sub, out[lanes][0].reshape(-1, 4)[ids])
+    assert np.array_equal(out["1"][0], out["2"][0])
+    assert out["1"][1:] == out["2"][1:]
+    ref, st_o = oracle_mod.Oracle(materials_scene).render(W, H, spp=spp)
+    assert np.array_equal(out["2"][0].reshape(-1, 4), ref)
+    assert out["2"][1] == st_o["extension_rays"] and out["2"][2] == st_o["shadow_rays"]
