@@ -1016,7 +1016,8 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
       P.Kb = Kb;
       P.batch_paths = Kb * npix;
-      P.pool_target = std::max<uint64_t>(total_target / ctx->num_lanes, 2 * P.batch_paths);
+      // (at most 64 samples per pixel in flight: small frames do not allocate gigabytes)
+      P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 64 * npix), 2 * P.batch_paths);
       P.cap = P.pool_target + P.batch_paths;
       P.num_slots = (uint32_t)std::min<uint64_t>(
           kMaxSlots, std::max<uint64_t>(4, 8 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths)));

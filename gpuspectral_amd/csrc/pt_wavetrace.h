@@ -47,7 +47,10 @@ constexpr int kLdsStackDepth = GSP_LDS_LEVELS;  // LDS levels per lane (1 KB per
 #endif
 constexpr int kRefillLanes = GSP_REFILL_LANES;  // idle lanes that trigger a refill
 constexpr int kLeafBatch = GSP_LEAF_BATCH;      // pending leaves that trigger a leaf step
-constexpr uint32_t kChunkLarge = 256;       // rays per hand-out (big queues)
+#ifndef GSP_CHUNK_LARGE
+#define GSP_CHUNK_LARGE 256
+#endif
+constexpr uint32_t kChunkLarge = GSP_CHUNK_LARGE;  // rays per hand-out (big queues)
 constexpr uint32_t kChunkSmall = 64;        // ... when the queue is small: one ray per lane, all waves busy
 constexpr int kWorkShards = 8;
 constexpr int kWorkStride = 32;             // counters sit on separate 128-B lines
