@@ -119,6 +119,7 @@ struct WaveStack {
 #ifdef GSP_WAVE_PROFILE
 // [0] node steps (per wave) [1] lanes enabled in them [2] leaf steps [3] lanes enabled [4] loop passes
 // [5] refill passes [6] lanes refilled [7] lanes idle (no ray) summed over node steps [8] lanes stalled (leaf pending, no node) over node steps
+// [9] node steps after the hand-out ran dry [10] lanes enabled in them
 __device__ unsigned long long g_wave_profile[16];
 #endif
 struct TraceStatsOut {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
   uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
 
 #ifdef GSP_WAVE_PROFILE
-  unsigned long long wp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long wp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (;;) {
 #ifdef GSP_WAVE_PROFILE
@@ -273,6 +274,10 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
         wp[1] += __popcll(__ballot(on));
         wp[7] += __popcll(__ballot(ri == 0xffffffffu));
         wp[8] += __popcll(__ballot(ri != 0xffffffffu && !on));
+        if (exhausted) {  // end game: the hand-out is empty, idle lanes stay idle
+          ++wp[9];
+          wp[10] += __popcll(__ballot(on));
+        }
 #endif
       if (on) {
           // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip write_node4)
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
   }
 #ifdef GSP_WAVE_PROFILE
   if (lane == 0 && !ANY)
-    for (int k = 0; k < 9; ++k) atomicAdd(&g_wave_profile[k], wp[k]);
+    for (int k = 0; k < 12; ++k) atomicAdd(&g_wave_profile[k], wp[k]);
 #endif
   if (STATS) {
     const unsigned long long a = wave_sum_u64(c_nodes), b = wave_sum_u64(c_tris), c = wave_sum_u64(c_rays);

@@ -10,6 +10,7 @@ with g.Context(0) as ctx:
     out = (ctypes.c_ulonglong * 16)()
     L.gsp_debug_wave_profile(out)
     ns, nl, ls, ll, loops, rf, rl, idle, stall = [out[i] for i in range(9)]
+    print("end game (hand-out empty): %.1f %% of the node steps, %.1f lanes enabled per step" % (100.0 * out[9] / ns, out[10] / max(out[9], 1)))
     print("node steps %d, lanes/step %.1f (idle %.1f, stalled on a leaf %.1f) | leaf steps %d, lanes/step %.1f | node:leaf steps %.2f | loop passes %d | refills %d, lanes/refill %.1f" % (
         ns, nl / ns, idle / ns, stall / ns, ls, ll / ls, ns / ls, loops, rf, rl / max(rf, 1)))
     st = ctx.stats()
