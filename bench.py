@@ -220,7 +220,11 @@ def main():
         pm = os.path.join(ROOT, "profiles", "pmc_extend_latest.json")
         if os.path.exists(pm):
             try:
-                traffic = json.load(open(pm)).get("hbm_bytes_per_launch")
+                # the PMC passes (scripts/profile_pmc.sh, separate rocprofv3 --pmc runs of this bench) give bytes
+                # per profiled launch; this run's launches differ in size, so carry the measured memory-side rate
+                # (bytes per microsecond of kernel time) over to this run's average launch
+                pj = json.load(open(pm))
+                traffic = pj["hbm_bytes_per_launch"] / pj["avg_us_profiled"] * (ext_ms / launches * 1e3)
             except Exception:
                 traffic = None
         out = {
