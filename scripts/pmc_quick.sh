@@ -15,7 +15,7 @@ for ps in ("a","b"):
         for r in csv.DictReader(open(f)):
             k=r["Kernel_Name"]
             if "k_trace" not in k: continue
-            name="extend" if "ExtendIO" in k else "connect"
+            name="fused" if "FusedIO" in k else "extend" if "ExtendIO" in k else "connect"
             agg[name][r["Counter_Name"]]+=float(r["Counter_Value"])
             if (r["Dispatch_Id"]) not in seen: seen.add(r["Dispatch_Id"]); cnt[name]+=1
     for n in agg:
