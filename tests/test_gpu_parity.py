@@ -446,3 +446,26 @@ def test_two_pipeline_lanes_give_the_same_image(oracle_mod, materials_scene, mon
     ref, st_o = oracle_mod.Oracle(materials_scene).render(W, H, spp=spp)
     assert np.array_equal(out["2"][0].reshape(-1, 4), ref)
     assert out["2"][1] == st_o["extension_rays"] and out["2"][2] == st_o["shadow_rays"]
+
+
+def test_cpp_cli_renders_the_reference_scene(tmp_path):
+    """`gsp_render scene.xml out.pfm W H spp` (the replacement of the reference's main.cpp loop): loader -> C ABI ->
+    PFM writer, compared with the committed Config-1 fixture."""
+    import os
+    import subprocess
+
+    from conftest import CORNELL_XML, ROOT
+
+    lib = os.path.join(ROOT, "gpuspectral_amd", "lib")
+    out = str(tmp_path / "cornell.pfm")
+    env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([os.path.join(lib, "gsp_render"), CORNELL_XML, out, "128", "128", "1"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    with open(out, "rb") as f:
+        assert f.readline() == b"PF\n"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0  # little endian
+        img = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]  # PFM rows run bottom-up
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "cornell_128_1spp.npy"))
+    assert np.array_equal(img.reshape(-1, 3), ref.reshape(-1, ref.shape[-1])[:, :3])
