@@ -1,0 +1,74 @@
+"""Randomised GPU-vs-oracle parity: small random scenes with every BSDF type at ordinary and extreme parameters
+(alpha -> 0, ior 1, zero / >1 reflectance, huge k), random transforms (mirrored, sheared scale), several lights,
+random cameras.  Usage: python scripts/fuzz_parity.py [n_scenes] [first_seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from gpuspectral_amd import scenes, abi
+
+
+def random_scene(seed):
+    rng = np.random.RandomState(seed)
+    b = scenes.SceneBuilder()
+    meshes = [b.add_mesh(*scenes.rect_mesh()), b.add_mesh(*scenes.box_mesh()), b.add_mesh(*scenes.sphere_mesh(12, 8)),
+              b.add_mesh(*scenes.torus_mesh(12, 8))]
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    ext = lambda choices: float(choices[rng.randint(len(choices))])
+
+    def material():
+        t = rng.randint(8)
+        rgb = tuple(rng.choice([0.0, 0.2, 0.8, 1.0, 1.5], 3))
+        if t == 0: return b.diffuse(rgb)
+        if t == 1: return b.dielectric(ext([1.0, 1.0001, 1.3, 1.5, 2.4]), ext([1.0, 1.33]))
+        if t == 2: return b.mirror(ext([0.0, 0.2, 1.5]))
+        if t == 3: return b.plastic(rgb, ext([1.0, 1.3, 1.9]))
+        if t == 4:
+            return b.rough_conductor(tuple(rng.choice([0.0, 0.14, 1.0, 3.0], 3)), tuple(rng.choice([0.0, 0.5, 4.0, 50.0], 3)),
+                                     ext([1e-4, 0.01, 0.1, 0.7, 3.0]), rgb)
+        if t == 5: return b.smooth_floor(rgb, ext([0.0, 0.04, 1.0]))
+        if t == 6: return b.rough_floor(rgb, ext([0.0, 0.04, 1.0]), ext([1e-4, 0.1, 1.0]))
+        return b.rough_plastic(rgb, ext([1e-4, 0.05, 0.5, 2.0]), ext([1.0, 1.3, 1.9]))
+
+    # a closed-ish room so paths bounce, then random clutter
+    room = b.add_mesh(*scenes.box_mesh())
+    b.add_object(room, scenes.trs((0, 1, 0), (2.5, 1.5, 2.5)), material(), twofaced=True)
+    for _ in range(rng.randint(3, 9)):
+        s = (u(0.1, 0.8) * ext([1, 1, -1]), u(0.1, 0.8), u(0.1, 0.8) * ext([1, 1, -1]))
+        b.add_object(meshes[rng.randint(len(meshes))], scenes.trs((u(-1.5, 1.5), u(0.1, 1.9), u(-1.5, 1.5)), s, u(0, 360)),
+                     material(), twofaced=bool(rng.randint(2)))
+    for _ in range(rng.randint(1, 4)):
+        b.add_object(meshes[0], scenes.trs((u(-1, 1), u(1.5, 2.4), u(-1, 1)), u(0.05, 0.6), u(0, 360)), b.diffuse((0, 0, 0)),
+                     twofaced=bool(rng.randint(2)), emission=tuple(rng.choice([0.5, 5.0, 40.0], 3)))
+    b.camera_lookat((u(-1.8, 1.8), u(0.3, 2.0), u(-1.8, 1.8)), (u(-0.5, 0.5), u(0.5, 1.5), u(-0.5, 0.5)), fov_deg=u(25, 90))
+    return b.build()
+
+
+def check(ctx, oracle_mod, seed, W=40, H=28, spp=3):
+    sc = random_scene(seed)
+    ctx.upload_scene(sc)
+    ctx.frame_begin(W, H)
+    ctx.reset_stats()
+    ctx.render(spp=spp)
+    st = ctx.stats()
+    img = ctx.download().reshape(-1, 4)
+    ref, so = oracle_mod.Oracle(sc).render(W, H, spp=spp)
+    same = np.array_equal(img, ref, equal_nan=True)
+    rays = st["extension_rays"] == so["extension_rays"] and st["shadow_rays"] == so["shadow_rays"]
+    return same and rays, int((img != ref).any(1).sum()), sc.num_triangles
+
+
+if __name__ == "__main__":
+    import gpuspectral_amd as g
+    import oracle as O
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    bad = []
+    with g.Context(0) as ctx:
+        for seed in range(s0, s0 + n):
+            ok, ndiff, tris = check(ctx, O, seed)
+            if not ok:
+                bad.append((seed, ndiff))
+                print("seed %d: MISMATCH (%d pixels, %d tris)" % (seed, ndiff, tris), flush=True)
+    print("%d scenes, %d mismatching: %s" % (n, len(bad), bad))

@@ -469,3 +469,20 @@ def test_cpp_cli_renders_the_reference_scene(tmp_path):
         img = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]  # PFM rows run bottom-up
     ref = np.load(os.path.join(ROOT, "tests", "golden", "cornell_128_1spp.npy"))
     assert np.array_equal(img.reshape(-1, 3), ref.reshape(-1, ref.shape[-1])[:, :3])
+
+
+def test_random_scene_fuzz_matches_oracle(ctx, oracle_mod):
+    """scripts/fuzz_parity.py: random small scenes with all eight BSDF types at ordinary and extreme parameters,
+    mirrored / non-uniformly scaled instances, several lights, random cameras: frames (NaN pixels included) and
+    ray counts equal the oracle's.  (3 300 seeds were run once by hand: 0 mismatches.)"""
+    import os
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_parity
+
+    for seed in range(5000, 5030):
+        ok, ndiff, tris = fuzz_parity.check(ctx, oracle_mod, seed)
+        assert ok, "seed %d: %d pixels differ (%d triangles)" % (seed, ndiff, tris)
