@@ -173,17 +173,26 @@ struct TestIO {  // gsp_trace
 };
 
 // ---- shade ----------------------------------------------------------------------
-// Block of 1024 threads = 16 waves (4 per SIMD, <= 128 VGPRs).  The two queue tails (next queue,
+// Four blocks of 256 threads per CU (4 waves per SIMD, <= 128 VGPRs).  The two queue tails (next queue,
 // shadow queue) are single words: with one atomic pair per WAVE the ~130k same-address atomics of
 // an 8M-path launch serialise at the ~88/us a single address sustains (MI355X_MICROARCH.md,
 // "dequeue" row) and cost half the kernel.  So survivors are counted per block through LDS and the
-// block reserves its ranges with ONE atomic pair per 1024 paths.
+// block reserves its ranges with ONE atomic pair per tile.  Tile = block = 256 paths (r01_j A/B with the
+// register budget pinned at 128: 1024 threads 77.7 ms, 512 76.2, 256 72.2, 128 104 per 48 spp): the waves of a
+// block cost differently after the BSDF-type sort and meet at five barriers per tile, so four small blocks per CU
+// overlap better than one large one, until the atomics per tile take over.
 #ifndef GSP_SHADE_BLOCK
-#define GSP_SHADE_BLOCK 1024
+#define GSP_SHADE_BLOCK 256
 #endif
 constexpr int kShadeBlock = GSP_SHADE_BLOCK;
 constexpr int kShadeWaves = kShadeBlock / 64;
-__global__ __launch_bounds__(kShadeBlock) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
+#ifndef GSP_SHADE_GRID_MULT
+#define GSP_SHADE_GRID_MULT 1  // grid = exactly the resident blocks, each loops over tiles
+#endif
+#ifndef GSP_SHADE_MINWAVES
+#define GSP_SHADE_MINWAVES 4  // 128 VGPRs: 4 blocks of 256 threads per CU
+#endif
+__global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
                                                         const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
                                                         q4* __restrict__ result, uint32_t* __restrict__ counters,
                                                         uint32_t slot_paths, DevStats* __restrict__ stats) {
@@ -849,7 +858,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   }
   if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[1], st));
   const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
-      1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * 2 * (1024 / kShadeBlock)));
+      1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (1024 / kShadeBlock)));
   hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], L.hits.p,
                      Q[cur ^ 1], SQ, L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
   if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[2], st));
