@@ -442,6 +442,7 @@ struct gsp_context {
     int cur = 0;
     uint32_t iteration = 0;
     uint32_t next_ts = 0, remaining = 0;
+    uint32_t folded_end = 0;  // one past the last timestamp folded into the accumulate buffer
   };
   // The owned pixels are dealt to kLanes independent pipelines (pixel lp belongs to lane lp % lanes), each
   // with its own pool, counters and stream.  While the host reads one lane's counters back and queues its
@@ -469,6 +470,7 @@ struct gsp_context {
   Lane lanes[kMaxLanes];
   uint32_t num_lanes = 1;  // GSP_LANES=2: +2-3 % with the 32 M-path pool, but per-kernel event times overlap
   gsp_render_params pipe_params{};  // integrator constants the lanes are running with
+  uint32_t folded_idle = 0;         // timestamps folded when no pipeline is running (gsp_peek)
   bool pipe_active = false;
 
   SceneView view() const {
@@ -742,6 +744,7 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uin
   CTX_TRY(ctx, ctx->accum.ensure(num_pixels, &ctx->bytes));
   CTX_TRY(ctx, hipMemsetAsync(ctx->accum.p, 0, std::max<uint64_t>(num_pixels, 1) * sizeof(q4), ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->folded_idle = 0;
   ctx->have_frame = true;
   return GSP_OK;
 }
@@ -917,6 +920,7 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
                        L.result.p + (uint64_t)b.slot * P.batch_paths, ctx->accum.p, L.index, ctx->num_lanes);
     CTX_TRY(ctx, hipGetLastError());
     P.slot_used[b.slot] = 0;
+    P.folded_end = b.t0 + b.kb;
     ctx->stats.samples += (uint64_t)b.kb * L.num_pixels;
   }
   if (P.n == 0 && P.remaining == 0 && !P.inflight.empty()) {
@@ -973,6 +977,8 @@ static int pipeline_run(gsp_context* ctx, bool drain) {
   }
   for (uint32_t l = 0; l < ctx->num_lanes; ++l) CTX_TRY(ctx, hipStreamSynchronize(ctx->lanes[l].stream));
   if (drain) {
+    for (uint32_t l = 0; l < ctx->num_lanes; ++l)
+      if (ctx->lanes[l].pipe.active) ctx->folded_idle = ctx->lanes[l].pipe.folded_end;
     ctx->pipe_active = false;
     for (uint32_t l = 0; l < ctx->num_lanes; ++l) ctx->lanes[l].pipe.active = false;
   }
@@ -1018,6 +1024,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       gsp_context::Lane& L = ctx->lanes[l];
       gsp_context::Pipeline& P = L.pipe;
       P = gsp_context::Pipeline{};
+      P.folded_end = ctx->folded_idle;
       const uint64_t npix = L.num_pixels;
       if (npix == 0) continue;  // fewer pixels than lanes
       uint64_t Kb = rp->timestamps_in_flight;
@@ -1077,6 +1084,23 @@ int gsp_download_compact(gsp_context* ctx, float* out) {
   }
   CTX_TRY(ctx, hipMemcpyAsync(out, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return GSP_OK;
+}
+
+int gsp_peek(gsp_context* ctx, float* out, uint32_t* samples_folded) {
+  if (!ctx || !out || !ctx->have_frame) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  // no drain: the folds queued so far finish, the paths in flight keep their state
+  uint32_t folded = 0xffffffffu;
+  for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
+    gsp_context::Lane& L = ctx->lanes[l];
+    if (L.num_pixels == 0) continue;
+    CTX_TRY(ctx, hipStreamSynchronize(L.stream));
+    folded = std::min(folded, ctx->pipe_active && L.pipe.active ? L.pipe.folded_end : ctx->folded_idle);
+  }
+  CTX_TRY(ctx, hipMemcpyAsync(out, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (samples_folded) *samples_folded = folded == 0xffffffffu ? 0u : folded;
   return GSP_OK;
 }
 

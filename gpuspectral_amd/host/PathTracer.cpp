@@ -63,6 +63,12 @@ std::vector<float> PathTracer::download() {
   return out;
 }
 
+std::vector<float> PathTracer::peek(uint32_t* samplesFolded) {
+  std::vector<float> out((pixelIds.empty() ? (size_t)width * height : pixelIds.size()) * 4);
+  check(gsp_peek(ctx, out.data(), samplesFolded), "gsp_peek");
+  return out;
+}
+
 gsp_stats PathTracer::stats() {
   gsp_stats s;
   check(gsp_get_stats(ctx, &s), "gsp_get_stats");

@@ -43,6 +43,9 @@ class PathTracer : public RenderPassCreator {
 
   // RGBA32F, row-major, width*height*4 floats (running mean, alpha 1)
   std::vector<float> download();
+  // The frame as it stands without waiting for paths still in flight (what the reference's blit pass shows every
+  // frame, PathTracer.cpp:41-55): compact RGBA32F over the owned pixels; *samplesFolded = timestamps in every pixel.
+  std::vector<float> peek(uint32_t* samplesFolded = nullptr);
   void reset();  // timestamp = 0, accumulate buffer cleared
   int getTimestamp() const { return timestamp; }
   gsp_stats stats();

@@ -26,6 +26,7 @@ EXPORTS = (
     "gsp_sync",
     "gsp_download",
     "gsp_download_compact",
+    "gsp_peek",
     "gsp_copy_accum_to_device",
     "gsp_upload_accum",
     "gsp_get_stats",
@@ -70,6 +71,7 @@ def load():
     L.gsp_sync.argtypes = [vp]
     L.gsp_download.argtypes = [vp, vp]
     L.gsp_download_compact.argtypes = [vp, vp]
+    L.gsp_peek.argtypes = [vp, vp, vp]
     L.gsp_copy_accum_to_device.argtypes = [vp, vp, u64]
     L.gsp_upload_accum.argtypes = [vp, vp, u64]
     L.gsp_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
@@ -151,6 +153,13 @@ class Context:
 
     def sync(self):
         self._check(self._L.gsp_sync(self._h), "gsp_sync")
+
+    def peek(self):
+        """(compact RGBA32F frame as it stands, timestamps folded into every pixel) without draining the pipeline."""
+        out = np.zeros((self.num_pixels, 4), np.float32)
+        folded = C.c_uint32(0)
+        self._check(self._L.gsp_peek(self._h, out.ctypes.data, C.byref(folded)), "gsp_peek")
+        return out, int(folded.value)
 
     def download(self):
         out = np.zeros((self.height, self.width, 4), np.float32)

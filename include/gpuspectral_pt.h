@@ -21,7 +21,7 @@
  *   gsp_render
  *        driver.traceRays(pipeline, W, H) once per sample      S/renderer/PathTracer.cpp:24-39,
  *        (raygen.rgen + rayhit.rchit + miss shaders)           S/backend/vulkan/VulkanDriver.cpp:319-347
- *   gsp_download / gsp_download_compact / gsp_copy_accum_to_device
+ *   gsp_download / gsp_download_compact / gsp_peek / gsp_copy_accum_to_device
  *        the RGBA32F accumulateBuffer the blit pass samples    S/renderer/PathTracer.cpp:41-55, raygen.rgen:84-108
  *   gsp_last_error
  *        std::runtime_error thrown by the driver               e.g. S/backend/vulkan/VulkanDevice.cpp:31,58,66
@@ -255,6 +255,13 @@ int gsp_sync(gsp_context* ctx);
 int gsp_download(gsp_context* ctx, float* out_rgba);
 /* Only the owned pixels, in pixel_ids order: num_pixels*4 floats. */
 int gsp_download_compact(gsp_context* ctx, float* out_rgba);
+/* The accumulate buffer as it stands, WITHOUT waiting for the paths still in
+ * flight (compact layout, num_pixels*4 floats): every pixel holds the running
+ * mean of its first *samples_folded timestamps.  This is what the reference's
+ * presentation pass shows each frame (DrawTexture blit of accumulateBuffer,
+ * S/renderer/PathTracer.cpp:41-55) while the next frames are already tracing;
+ * a viewer calls it once per displayed frame and gsp_download only at the end. */
+int gsp_peek(gsp_context* ctx, float* out_rgba, uint32_t* samples_folded);
 /* Device-to-device copy of the compact accumulate buffer into caller-owned
  * device memory (e.g. a tensor handed to an RCCL gather). */
 int gsp_copy_accum_to_device(gsp_context* ctx, void* device_dst, uint64_t bytes);

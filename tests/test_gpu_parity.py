@@ -486,3 +486,30 @@ def test_random_scene_fuzz_matches_oracle(ctx, oracle_mod):
     for seed in range(5000, 5030):
         ok, ndiff, tris = fuzz_parity.check(ctx, oracle_mod, seed)
         assert ok, "seed %d: %d pixels differ (%d triangles)" % (seed, ndiff, tris)
+
+
+def test_peek_shows_a_prefix_of_the_timestamps(oracle_mod, materials_scene):
+    """gsp_peek: the accumulate buffer without waiting for paths in flight = the running mean of the first k
+    timestamps of every pixel, for the k it reports (what the reference's blit pass would show that frame)."""
+    import gpuspectral_amd as g
+
+    W, H = 96, 64
+    o = oracle_mod.Oracle(materials_scene)
+    refs = {}
+    with g.Context(0) as c:
+        c.upload_scene(materials_scene)
+        c.frame_begin(W, H)
+        seen = []
+        for t in range(12):
+            c.render(spp=1, first_timestamp=t, timestamps_in_flight=1)
+            img, k = c.peek()
+            assert 0 <= k <= t + 1
+            seen.append(k)
+            if k not in refs:
+                refs[k] = o.render(W, H, spp=k)[0] if k else np.zeros((W * H, 4), np.float32)
+            assert np.array_equal(img, refs[k]), "peek after %d calls reports %d timestamps" % (t + 1, k)
+        assert seen == sorted(seen)
+        full = c.download().reshape(-1, 4)
+        img, k = c.peek()
+        assert k == 12 and np.array_equal(img, full)
+        assert np.array_equal(full, o.render(W, H, spp=12)[0])
