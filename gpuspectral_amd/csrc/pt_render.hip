@@ -59,9 +59,9 @@ struct ShadowQueue {
 // sample slot, then the ray hand-out counters of the extend and connect launches (kWorkShards
 // words each, on separate 128-B lines)
 constexpr int kMaxSlots = 64;
-enum { C_NEXT = 0, C_SHADOW = 1, C_LIVE = 2, C_WORK_EXT = 96, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
+enum { C_NEXT = 0, C_SHADOW = 1, C_LIVE = 2, C_TAIL_EXT = 66, C_TAIL_SH = 68, C_READBACK = 72, C_WORK_EXT = 96, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
        C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
-static_assert(C_LIVE + kMaxSlots <= C_WORK_EXT, "counter layout");
+static_assert(C_LIVE + kMaxSlots <= C_TAIL_EXT && C_READBACK <= C_WORK_EXT && (C_TAIL_EXT % 2) == 0, "counter layout");
 struct DevStats {
   unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays;
 };
@@ -342,6 +342,66 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   if (lane == 0 && shaded) atomicAdd(&stats->shaded, shaded);
 }
 
+// ---- finish ----------------------------------------------------------------------
+// The last few thousand paths of a drain, one path per lane from its current vertex to its end: extend, shade,
+// shadow ray, next bounce, with no queues and no launches in between.  A wavefront iteration over a few hundred
+// paths costs ~0.3 ms of launch, memset and read-back latency and a drain has ~45 of them; here every path pays
+// only its own chain of dependent loads.  Same stage functions (shade_vertex, connect_vertex, add_emitted) and the
+// same per-sample order of additions as k_shade / ConnectIO, so the arithmetic per path is unchanged.
+constexpr uint32_t kFinishPaths = 262144;  // scan 0 / 64 k / 256 k / 1 M: 8-spp call 62 / 56 / 54 / 56 ms, 500x500 1-spp frames 88 / 138 / 182 / 184 per s
+
+__global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc, uint32_t n, PathQueue q,
+                                                    q4* __restrict__ result, uint32_t* __restrict__ counters,
+                                                    uint32_t slot_paths, DevStats* __restrict__ stats) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long ext = 0, sh = 0, shaded = 0;
+  if (i < n) {
+    const q4 p0 = q.P0[i], p1 = q.P1[i], p2 = q.P2[i];
+    PathState in;
+    in.o = mk3(p0.x, p0.y, p0.z);
+    in.d = mk3(p0.w, p1.x, p1.y);
+    in.seed = fb(p1.z);
+    in.sid = fb(p1.w);
+    in.weight = mk3(p2.x, p2.y, p2.z);
+    in.directWeight = p2.w;
+    in.flags = q.FL[i];
+    const uint32_t sid = in.sid;
+    q4 res = result[sid];  // single owner of this sample slot from here on
+    for (;;) {
+      HitRec h;
+      uint32_t aux;
+      ++ext;
+      if (!trace_lane<false>(S.nodes, S.tri_isect, S.root, in.o, in.d, 0.0f, 1e10f, h, aux)) break;  // miss.rmiss:15-18
+      ShadeOut out;
+      shade_vertex(S, rc, in, h, out);
+      ++shaded;
+      if (!out.has_shadow) {
+        add_emitted(rc.clamp, out.emitted, res);
+      } else {
+        HitRec hs;
+        uint32_t aux2;
+        ++sh;
+        const bool occluded = trace_lane<true>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2);
+        bool nee_done;
+        connect_vertex(rc.clamp, out.shadow, occluded, res, nee_done);
+        if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;  // rayhit.rchit:785-787
+      }
+      if (!out.alive) break;
+      in = out.next;
+    }
+    result[sid] = res;
+    atomicSub(&counters[C_LIVE + sid / slot_paths], 1u);
+  }
+  ext = wave_sum(ext);
+  sh = wave_sum(sh);
+  shaded = wave_sum(shaded);
+  if ((threadIdx.x & 63) == 0) {
+    if (ext) atomicAdd((unsigned long long*)(counters + C_TAIL_EXT), ext);
+    if (sh) atomicAdd((unsigned long long*)(counters + C_TAIL_SH), sh);
+    if (shaded) atomicAdd(&stats->shaded, shaded);
+  }
+}
+
 // ---- resolve ----------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_t K, uint32_t first_timestamp,
                                                      const q4* __restrict__ result, q4* __restrict__ accum,
@@ -465,12 +525,14 @@ struct gsp_context {
     bool in_flight = false;   // an iteration is queued on `stream` and its counters have not been read back
     uint64_t it_n = 0;        // paths of that iteration
     bool it_timing = false;
+    bool it_finish = false;   // that iteration was k_finish: every remaining path ran to its end
   };
   static constexpr int kMaxLanes = 2;
   Lane lanes[kMaxLanes];
   uint32_t num_lanes = 1;  // GSP_LANES=2: +2-3 % with the 32 M-path pool, but per-kernel event times overlap
   gsp_render_params pipe_params{};  // integrator constants the lanes are running with
   uint32_t folded_idle = 0;         // timestamps folded when no pipeline is running (gsp_peek)
+  uint32_t finish_paths = 0;        // k_finish takes over below this many live paths (GSP_FINISH_PATHS, 0 = never)
   bool pipe_active = false;
 
   SceneView view() const {
@@ -587,6 +649,7 @@ int gsp_ctx_create(int device, gsp_context** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  c->finish_paths = getenv("GSP_FINISH_PATHS") ? (uint32_t)strtoul(getenv("GSP_FINISH_PATHS"), nullptr, 10) : kFinishPaths;
   if (const char* nl = getenv("GSP_LANES")) c->num_lanes = (uint32_t)std::min(std::max(atoi(nl), 1), (int)gsp_context::kMaxLanes);
   for (uint32_t l = 0; l < c->num_lanes && e == hipSuccess; ++l) {
     gsp_context::Lane& L = c->lanes[l];
@@ -842,6 +905,20 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   if (P.n == 0) return GSP_OK;
   const uint64_t n = P.n;
   const int cur = P.cur;
+  L.it_finish = false;
+  if (P.remaining == 0 && n <= ctx->finish_paths && !stats_mode && 3 * ctx->bvh.depth + 4 <= (uint32_t)kLaneStackDepth) {
+    // nothing left to inject and only stragglers alive: every path runs to its end on its own lane
+    CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, 2 * sizeof(uint32_t), st));
+    CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_TAIL_EXT, 0, 4 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_finish, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
+                       L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
+    CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, C_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    L.in_flight = true;
+    L.it_n = n;
+    L.it_timing = false;
+    L.it_finish = true;
+    return GSP_OK;
+  }
   const uint32_t chunk = n >= (1u << 20) ? kChunkLarge : kChunkSmall;
   const uint32_t grid = ctx->trace_grid(n, chunk);
   CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, 2 * sizeof(uint32_t), st));
@@ -878,7 +955,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
                          ctx->spill_stride, so_sh);
   }
   if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[3], st));
-  CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, (C_LIVE + kMaxSlots) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, C_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   L.in_flight = true;
   L.it_n = n;
   L.it_timing = timing;
@@ -894,8 +971,13 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
     CTX_TRY(ctx, hipStreamSynchronize(st));
     CTX_TRY(ctx, hipGetLastError());
     L.in_flight = false;
-    ctx->stats.extension_rays += L.it_n;
-    ctx->stats.shadow_rays += L.h_counters[C_SHADOW];
+    if (L.it_finish) {
+      ctx->stats.extension_rays += (uint64_t)L.h_counters[C_TAIL_EXT] | ((uint64_t)L.h_counters[C_TAIL_EXT + 1] << 32);
+      ctx->stats.shadow_rays += (uint64_t)L.h_counters[C_TAIL_SH] | ((uint64_t)L.h_counters[C_TAIL_SH + 1] << 32);
+    } else {
+      ctx->stats.extension_rays += L.it_n;
+      ctx->stats.shadow_rays += L.h_counters[C_SHADOW];
+    }
     const uint32_t bounce = P.iteration++;
     if (L.it_timing) {
       float ms = 0.0f, e_ms = 0.0f, s_ms = 0.0f;

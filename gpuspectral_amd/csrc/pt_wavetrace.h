@@ -134,6 +134,97 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
+// One ray on one lane, start to finish (no wave cooperation): the traversal of k_finish, which runs the last few
+// thousand paths of a drain to completion without the wavefront queues.  Same node decode, same triangle test and
+// the same min-t / min-id rule as the wave kernel, so the hit is the same; the visiting order is not (and need not be).
+constexpr int kLaneStackDepth = 96;
+template <bool ANY>
+__device__ __forceinline__ bool trace_lane(const q4* __restrict__ nodes, const q4* __restrict__ tris, int32_t root, f3 o, f3 d,
+                                           float tmin, float tmax, HitRec& h, uint32_t& aux) {
+  int32_t stack[kLaneStackDepth];
+  int sp = 0;
+  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
+  RayShear rs = make_shear(d);
+  rs.Sz = comp(inv, rs.kz);
+  h.t = tmax;
+  h.u = h.v = 0.0f;
+  h.slot = -1;
+  aux = 0;
+  uint32_t best_id = 0xffffffffu;
+  int32_t cur = root;
+  for (;;) {
+    if (cur >= 0) {
+      const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
+      const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+      const int32_t c[4] = {(int32_t)__float_as_uint(n2.z), (int32_t)__float_as_uint(n2.w), (int32_t)__float_as_uint(n3.x),
+                            (int32_t)__float_as_uint(n3.y)};
+      const float sx = n0.w, sy = n3.z, sz = n3.w;
+      const float dx = n0.x - o.x, dy = n0.y - o.y, dz = n0.z - o.z;
+      const uint32_t qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z),
+                     qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
+      const uint32_t qnx = negx ? qhx : qlx, qfx = negx ? qlx : qhx;
+      const uint32_t qny = negy ? qhy : qly, qfy = negy ? qly : qhy;
+      const uint32_t qnz = negz ? qhz : qlz, qfz = negz ? qlz : qhz;
+      uint32_t key[4];
+      int32_t e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float tnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), sx, dx) * inv.x,
+                    tfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), sx, dx) * inv.x;
+        const float tny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), sy, dy) * inv.y,
+                    tfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), sy, dy) * inv.y;
+        const float tnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), sz, dz) * inv.z,
+                    tfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), sz, dz) * inv.z;
+        const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));
+        const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, h.t));
+        key[k] = lo <= hi * 1.000001f ? __float_as_uint(lo) : 0xffffffffu;
+        e[k] = c[k];
+      }
+#define GSP_CSWAP(a, b)                                  \
+  if (key[b] < key[a]) {                                 \
+    const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk; \
+    const int32_t te = e[a]; e[a] = e[b]; e[b] = te;     \
+  }
+      GSP_CSWAP(0, 1) GSP_CSWAP(2, 3) GSP_CSWAP(0, 2) GSP_CSWAP(1, 3) GSP_CSWAP(1, 2)
+#undef GSP_CSWAP
+      for (int k = 3; k >= 1; --k)
+        if (key[k] != 0xffffffffu) stack[sp++] = e[k];
+      if (key[0] != 0xffffffffu) {
+        cur = e[0];
+        continue;
+      }
+    } else {
+      const uint32_t cc = (uint32_t)~cur;
+      const uint32_t first = cc >> 2, count = (cc & 3u) + 1u;
+      for (uint32_t k = 0; k < count; ++k) {
+        const q4* p = tris + 3ll * (first + k);
+        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
+        float t, u, v;
+        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u, v)) {
+          if (ANY) {
+            h.t = t;
+            h.slot = (int32_t)(first + k);
+            return true;
+          }
+          const uint32_t id = __float_as_uint(p0.w);
+          if (t < h.t || (t == h.t && id < best_id)) {
+            h.t = t;
+            h.u = u;
+            h.v = v;
+            h.slot = (int32_t)(first + k);
+            best_id = id;
+            aux = __float_as_uint(p1.w);
+          }
+        }
+      }
+    }
+    if (sp == 0) break;
+    cur = stack[--sp];
+  }
+  return h.slot >= 0;
+}
+
 // IO contract:
 //   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const;
 //   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux) const;   // h.slot < 0: miss / unoccluded;

@@ -15,11 +15,24 @@ pytestmark = pytest.mark.gpu
 TOL_RMSE = 1e-3  # BASELINE.json: "per-pixel RMSE vs reference < 1e-3"
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["default", "wavefront-only"])
+def ctx(request):
+    """Every test that takes `ctx` runs twice: with the defaults (frames this small finish in k_finish, one path per
+    lane) and with GSP_FINISH_PATHS=0, which keeps every bounce in the wavefront kernels the bench measures."""
+    import os
+
     import gpuspectral_amd as g
 
-    c = g.Context(0)
+    old = os.environ.get("GSP_FINISH_PATHS")
+    if request.param == "wavefront-only":
+        os.environ["GSP_FINISH_PATHS"] = "0"
+    try:
+        c = g.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("GSP_FINISH_PATHS", None)
+        else:
+            os.environ["GSP_FINISH_PATHS"] = old
     yield c
     c.close()
 
