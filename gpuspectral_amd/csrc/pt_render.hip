@@ -861,7 +861,7 @@ static RenderConsts render_consts(const gsp_context* ctx) {
 
 // Queues one iteration of a lane on its stream without waiting: new batches while there is room, then
 // extend / shade / connect over the lane's dense queues and the copy of its counters to the host.
-static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderConsts& rcst, const SceneView& view) {
+static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderConsts& rcst, const SceneView& view, bool drain) {
   gsp_context::Pipeline& P = L.pipe;
   hipStream_t st = L.stream;
   const gsp_render_params* rp = &ctx->pipe_params;
@@ -906,8 +906,9 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   const uint64_t n = P.n;
   const int cur = P.cur;
   L.it_finish = false;
-  if (P.remaining == 0 && n <= ctx->finish_paths && !stats_mode && 3 * ctx->bvh.depth + 4 <= (uint32_t)kLaneStackDepth) {
-    // nothing left to inject and only stragglers alive: every path runs to its end on its own lane
+  if (drain && P.remaining == 0 && n <= ctx->finish_paths && !stats_mode && 3 * ctx->bvh.depth + 4 <= (uint32_t)kLaneStackDepth) {
+    // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
+    // on its own lane (not when gsp_render merely queues work: those paths ride along with the next call's)
     CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, 2 * sizeof(uint32_t), st));
     CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_TAIL_EXT, 0, 4 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_finish, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
@@ -1031,7 +1032,7 @@ static int pipeline_run(gsp_context* ctx, bool drain) {
     for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
       gsp_context::Lane& L = ctx->lanes[l];
       if (!L.in_flight && has_work(L)) {
-        int rc = lane_enqueue(ctx, L, rcst, view);
+        int rc = lane_enqueue(ctx, L, rcst, view, drain);
         if (rc != GSP_OK) return rc;
         if (!L.in_flight) {  // nothing left to trace: only batches to fold
           rc = lane_collect(ctx, L);
