@@ -45,6 +45,9 @@ constexpr int kLdsStackDepth = GSP_LDS_LEVELS;  // LDS levels per lane (1 KB per
 #ifndef GSP_LEAF_BATCH_CLOSEST
 #define GSP_LEAF_BATCH_CLOSEST 32
 #endif
+#ifndef GSP_BATCH_COMMIT
+#define GSP_BATCH_COMMIT (ANY ? 32 : 24)
+#endif
 constexpr int kRefillLanes = GSP_REFILL_LANES;  // idle lanes that trigger a refill
 constexpr int kLeafBatch = GSP_LEAF_BATCH;      // pending leaves that trigger a leaf step
 #ifndef GSP_CHUNK_LARGE
@@ -276,9 +279,21 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
     ++wp[4];
 #endif
     // ---- commit finished rays ------------------------------------------------------------
-    if (ri != 0xffffffffu && cur == kSentinel && leaf == 0) {
-      io.store(ri, h, best_aux);
-      ri = 0xffffffffu;
+    // batched like the refill: the commit path (for shadow rays: three loads, the firefly test, two stores) is
+    // issued for the whole wave, so it waits until enough lanes are out of work (A/B: any-hit kernel -13 % at 32,
+    // closest-hit -1.6 % at 24; 40+ starves the wave)
+    {
+      const bool pending = ri != 0xffffffffu && cur == kSentinel && leaf == 0;
+      const uint64_t pend_m = __ballot(pending);
+      if (pend_m) {
+        const uint64_t out_m = pend_m | __ballot(ri == 0xffffffffu);
+        if (__popcll(out_m) >= GSP_BATCH_COMMIT || out_m == ~0ull) {
+          if (pending) {
+            io.store(ri, h, best_aux);
+            ri = 0xffffffffu;
+          }
+        }
+      }
     }
     // ---- refill idle lanes from the wave-local pool -----------------------------------------
     uint64_t idle_m = __ballot(ri == 0xffffffffu);
