@@ -9,4 +9,4 @@ hipcc $F -c pt_bvh.hip -o build/var_$1/pt_bvh.o &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/$1.so build/var_$1/pt_render.o build/var_$1/pt_bvh.o
 echo built $1
-rm -rf "$(dirname "$0")/../gpuspectral_amd/csrc/build/var_$1"
+rm -rf build/var_$1
