@@ -56,7 +56,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle_pt.so")
+        so = os.environ.get("ORACLE_LIB_PATH") or os.path.join(_HERE, "liboracle_pt.so")  # (override: the ASan/UBSan build)
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
