@@ -508,7 +508,7 @@ struct gsp_context {
   // with its own pool, counters and stream.  While the host reads one lane's counters back and queues its
   // next iteration, the other lane's kernels keep the GPU busy, and a latency-bound k_shade of one lane
   // overlaps a VALU-bound k_trace of the other.  Same arithmetic per pixel, so the image does not depend on
-  // the lane count.  Default 1 lane: with the large pool the second lane adds 2-3 %, and concurrent kernels
+  // the lane count.  Default 1 lane: with the large pool the second lane adds nothing, and concurrent kernels
   // make per-kernel durations (the roofline measurement) meaningless.
   struct Lane {
     uint32_t index = 0;
@@ -529,7 +529,7 @@ struct gsp_context {
   };
   static constexpr int kMaxLanes = 2;
   Lane lanes[kMaxLanes];
-  uint32_t num_lanes = 1;  // GSP_LANES=2: +2-3 % with the 32 M-path pool, but per-kernel event times overlap
+  uint32_t num_lanes = 1;  // GSP_LANES=2: +11 % with 8 M-path pools, +-0 with the 32 M-path pool and k_finish
   gsp_render_params pipe_params{};  // integrator constants the lanes are running with
   uint32_t folded_idle = 0;         // timestamps folded when no pipeline is running (gsp_peek)
   uint32_t finish_paths = 0;        // k_finish takes over below this many live paths (GSP_FINISH_PATHS, 0 = never)
