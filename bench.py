@@ -92,11 +92,16 @@ def cpu_baseline(sc, args, scene_name):
     ids = scenes.tile_pixel_ids(W, H, 0, parts, tile=16)
     _, st = o.render(W, H, spp=spp_c, pixel_ids=ids, threads=threads)
     rays = st["extension_rays"] + st["shadow_rays"]
+    # one thread on ~2 s of the same work (SURVEY 8d asks for the 1-thread figure next to the all-cores one)
+    ids1 = scenes.tile_pixel_ids(W, H, 0, max(1, int(round(W * H * per_px / max(2.0 * rate / max(threads, 1), 1.0)))), tile=16)
+    _, st1 = o.render(W, H, spp=1, pixel_ids=ids1, threads=1)
+    rate1 = (st1["extension_rays"] + st1["shadow_rays"]) / max(st1["seconds"], 1e-9) / 1e6
     return {
         "value": rays / st["seconds"] / 1e6,
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
+        "single_thread_value": rate1,
         "msamples_per_s": st["samples"] / st["seconds"] / 1e6,
         "sample": "%s, %dx%d, %d spp on %d pixels (every %d-th 16x16 tile), %.1f s, scalar C++ oracle with %d std::threads (= the CPUs the cgroup grants); BVH build %.2f s excluded"
         % (scene_name, W, H, spp_c, len(ids), parts, st["seconds"], threads, o.build_seconds),
