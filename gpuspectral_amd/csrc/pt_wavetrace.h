@@ -131,6 +131,12 @@ struct TraceStatsOut {
   unsigned long long* rays;
 };
 
+// lanes set in a ballot, as a 32-bit scalar: comparing the 64-bit result of __popcll with a constant is compiled
+// to a VALU v_cmp_*_u64 on broadcast values (five of them per loop pass)
+__device__ __forceinline__ int wave_count(uint64_t m) {
+  return __builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32));
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       const uint64_t pend_m = __ballot(pending);
       if (pend_m) {
         const uint64_t out_m = pend_m | __ballot(ri == 0xffffffffu);
-        if (__popcll(out_m) >= GSP_BATCH_COMMIT || out_m == ~0ull) {
+        if (wave_count(out_m) >= GSP_BATCH_COMMIT || out_m == ~0ull) {
           if (pending) {
             io.store(ri, h, best_aux);
             ri = 0xffffffffu;
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
     }
     // ---- refill idle lanes from the wave-local pool -----------------------------------------
     uint64_t idle_m = __ballot(ri == 0xffffffffu);
-    if (!exhausted && __popcll(idle_m) >= kRefillLanes) {
+    if (!exhausted && wave_count(idle_m) >= kRefillLanes) {
 #ifdef GSP_WAVE_PROFILE
       ++wp[5];
       wp[6] += __popcll(idle_m);
@@ -359,8 +365,8 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
     // closest hit: lanes that cannot advance without a leaf step (leaf pending, no inner node to work on)
     // trigger it early; lanes that still descend can wait for a fuller batch
     const uint64_t stall_m = leaf_m & ~node_m;
-    const bool leaf_step = (!ANY && __popcll(stall_m) >= GSP_STALL_BATCH) ||
-                           __popcll(leaf_m) >= (ANY ? kLeafBatch : GSP_LEAF_BATCH_CLOSEST) || node_m == 0;
+    const bool leaf_step = (!ANY && wave_count(stall_m) >= GSP_STALL_BATCH) ||
+                           wave_count(leaf_m) >= (ANY ? kLeafBatch : GSP_LEAF_BATCH_CLOSEST) || node_m == 0;
     if (node_m != 0 && !leaf_step) {
       // measured on the 1M-triangle bench scene (scripts/ab_variants.sh): closest-hit 3 steps while >= 32 lanes
       // are on inner nodes, any-hit 4 steps while >= 24 are (+3.6 % Mrays/s over 2 steps / 40 lanes)
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       // lanes are still on inner nodes
       for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
         const bool on = (uint32_t)cur < (uint32_t)kSentinel;
-        if (rep > 0 && __popcll(__ballot(on)) < GSP_REP_LANES) break;
+        if (rep > 0 && wave_count(__ballot(on)) < GSP_REP_LANES) break;
 #ifdef GSP_WAVE_PROFILE
         ++wp[0];
         wp[1] += __popcll(__ballot(on));
