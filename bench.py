@@ -66,9 +66,12 @@ def make_scene(args):
         return scenes.cornell_materials(96), "Cornell + full BSDF set: scenes.cornell_materials(96)"
     if args.scene == "caustics":
         return scenes.caustics(args.tris, seed=11), "dielectric caustics: scenes.caustics(%d, seed=11)" % args.tris
-    from oracle import mitsuba_loader as ml  # tiny fixture scene only
+    # the reference's Cornell box through the product's own C++ loader (the oracle package is imported by the
+    # cpu_baseline leg only)
+    from gpuspectral_amd import host
 
-    return ml.load_scene(os.path.join(ROOT, "tests", "golden", "cornell-box", "scene.xml")), "Cornell box (reference scene.xml)"
+    xml = os.path.join(ROOT, "tests", "golden", "cornell-box", "scene.xml")
+    return host.Scene(xml, os.path.dirname(os.path.dirname(xml))).arrays(), "Cornell box (reference scene.xml)"
 
 
 def cpu_baseline(sc, args, scene_name):

@@ -90,6 +90,25 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
                 assert not re.search(r'#include\s+"[^"]*oracle', txt), f  # comments may cite it, code may not use it
+    # scripts/ (measurement helpers) never touch it either; checkers that need it live under tests/tools/
+    for f in os.listdir(os.path.join(ROOT, "scripts")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "scripts", f), errors="replace").read()
+            assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+    # bench.py: only inside cpu_baseline(); __graft_entry__.py: only inside smoke()
+    import ast
+
+    for fname, allowed in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        tree = ast.parse(open(os.path.join(ROOT, fname)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef):
+                uses = [n for n in ast.walk(node) if isinstance(n, (ast.Import, ast.ImportFrom)) and
+                        any("oracle" in (a.name or "") for a in n.names) or
+                        (isinstance(n, ast.ImportFrom) and n.module and "oracle" in n.module)]
+                assert not uses or node.name == allowed, "%s: %s imports the oracle" % (fname, node.name)
+        top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and
+               (any("oracle" in a.name for a in n.names) or (isinstance(n, ast.ImportFrom) and n.module and "oracle" in n.module))]
+        assert not top, fname
     code = "import sys; import gpuspectral_amd, gpuspectral_amd.host, gpuspectral_amd.scenes, gpuspectral_amd.multigpu; " \
            "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]"
     subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)

@@ -485,7 +485,7 @@ def test_cpp_cli_renders_the_reference_scene(tmp_path):
 
 
 def test_random_scene_fuzz_matches_oracle(ctx, oracle_mod):
-    """scripts/fuzz_parity.py: random small scenes with all eight BSDF types at ordinary and extreme parameters,
+    """tests/tools/fuzz_parity.py: random small scenes with all eight BSDF types at ordinary and extreme parameters,
     mirrored / non-uniformly scaled instances, several lights, random cameras: frames (NaN pixels included) and
     ray counts equal the oracle's.  (3 300 seeds were run once by hand: 0 mismatches.)"""
     import os
@@ -493,7 +493,7 @@ def test_random_scene_fuzz_matches_oracle(ctx, oracle_mod):
 
     from conftest import ROOT
 
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import fuzz_parity
 
     for seed in range(5000, 5030):

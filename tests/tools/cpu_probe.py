@@ -1,6 +1,6 @@
 """How many host cores does this box really give us?  (cpu_baseline.cores must be what was actually used.)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 print("os.cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
     try: print(f, open(f).read().strip())

@@ -3,7 +3,7 @@ share one rank of the 8-GPU job owns).  For each: throughput, and -- at the full
 subset against the oracle (the seed is a function of (pixel, timestamp) only, so a subset reproduces the frame)."""
 import os, sys, time, json, zlib
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import gpuspectral_amd as g
 from gpuspectral_amd import scenes, abi

@@ -1,9 +1,9 @@
 """Randomised GPU-vs-oracle parity: small random scenes with every BSDF type at ordinary and extreme parameters
 (alpha -> 0, ior 1, zero / >1 reflectance, huge k), random transforms (mirrored, sheared scale), several lights,
-random cameras.  Usage: python scripts/fuzz_parity.py [n_scenes] [first_seed]"""
+random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from gpuspectral_amd import scenes, abi

@@ -2,7 +2,7 @@
 scene_cache/) on the GPU: rate, bit-parity against the oracle on a tile subset, and a tone-mapped PNG."""
 import os, sys, time, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import gpuspectral_amd as g
 from gpuspectral_amd import abi, host

@@ -2,7 +2,7 @@
 each with a sparse oracle parity check."""
 import os, sys, time, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import gpuspectral_amd as g
 from gpuspectral_amd import scenes, abi
