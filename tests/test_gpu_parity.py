@@ -526,3 +526,18 @@ def test_peek_shows_a_prefix_of_the_timestamps(oracle_mod, materials_scene):
         img, k = c.peek()
         assert k == 12 and np.array_equal(img, full)
         assert np.array_equal(full, o.render(W, H, spp=12)[0])
+
+
+def test_tiny_frames_with_many_samples(ctx, oracle_mod):
+    """Batches of thousands of timestamps per slot (1x1 x 20 000 spp, 8x8 x 3 000 spp): the running mean over a long
+    timestamp range stays bit-identical to the oracle's."""
+    from gpuspectral_amd import scenes
+
+    sc = scenes.cornell_materials(8)
+    o = oracle_mod.Oracle(sc)
+    ctx.upload_scene(sc)
+    for W, H, spp in ((1, 1, 20000), (8, 8, 3000)):
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        ref, _ = o.render(W, H, spp=spp)
+        assert np.array_equal(ctx.download().reshape(-1, 4), ref), (W, H, spp)
