@@ -406,53 +406,6 @@ __global__ __launch_bounds__(kBlock) void k_flag_even(int n_int, const int32_t* 
   flag[i] = (depth & 1u) ? 0u : 1u;
 }
 
-struct Entry4 {
-  q4 lo, hi;
-  int32_t code;
-};
-
-// Writes one compressed 4-wide node (64 B, layout in pt_trace.h) from up to four child entries.
-__device__ void write_node4(q4* __restrict__ o, Entry4 (&e)[4], int cnt, uint32_t dummy_slot) {
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int k = 0; k < cnt; ++k) {
-    lo[0] = fminf(lo[0], e[k].lo.x); lo[1] = fminf(lo[1], e[k].lo.y); lo[2] = fminf(lo[2], e[k].lo.z);
-    hi[0] = fmaxf(hi[0], e[k].hi.x); hi[1] = fmaxf(hi[1], e[k].hi.y); hi[2] = fmaxf(hi[2], e[k].hi.z);
-  }
-  float scale[3];
-  for (int a = 0; a < 3; ++a) {
-    const float ext = hi[a] - lo[a];
-    int ex = -100;
-    if (ext > 0.0f) (void)frexpf(ext / 255.0f, &ex);  // 2^ex >= ext / 255
-    int eb = min(max(ex + 127, 1), 254);
-    // the largest code must reach the far side of the node
-    while (eb < 254 && fmaf(255.0f, __uint_as_float((uint32_t)eb << 23), lo[a]) < hi[a]) ++eb;
-    scale[a] = __uint_as_float((uint32_t)eb << 23);
-  }
-  uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // qlo.x, qlo.y, qlo.z, qhi.x, qhi.y, qhi.z : one byte per child
-  for (int k = 0; k < cnt; ++k) {
-    const float cl[3] = {e[k].lo.x, e[k].lo.y, e[k].lo.z}, ch[3] = {e[k].hi.x, e[k].hi.y, e[k].hi.z};
-    for (int a = 0; a < 3; ++a) {
-      float ql = fminf(fmaxf(floorf((cl[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
-      while (ql > 0.0f && fmaf(ql, scale[a], lo[a]) > cl[a]) ql -= 1.0f;  // decoded plane must not exceed the box
-      float qh = fminf(fmaxf(ceilf((ch[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
-      while (qh < 255.0f && fmaf(qh, scale[a], lo[a]) < ch[a]) qh += 1.0f;
-      q[a] |= (uint32_t)ql << (8 * k);
-      q[3 + a] |= (uint32_t)qh << (8 * k);
-    }
-  }
-  // unused slots: inverted box (near plane beyond the far plane: misses) that leads to the degenerate
-  // triangle, so the traversal needs no empty-slot test and a rounding fluke costs one triangle test
-  for (int k = cnt; k < 4; ++k)
-    for (int a = 0; a < 3; ++a) q[a] |= 255u << (8 * k);
-  int32_t code[4];
-  for (int k = 0; k < 4; ++k) code[k] = k < cnt ? e[k].code : make_leaf(dummy_slot, 1);
-  o[0] = mkq(lo[0], lo[1], lo[2], scale[0]);
-  o[1] = mkq(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
-  o[2] = mkq(__uint_as_float(q[4]), __uint_as_float(q[5]), __uint_as_float((uint32_t)code[0]),
-             __uint_as_float((uint32_t)code[1]));
-  o[3] = mkq(__uint_as_float((uint32_t)code[2]), __uint_as_float((uint32_t)code[3]), scale[1], scale[2]);
-}
-
 // parity collapse: one thread per even-depth binary node
 __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restrict__ nodes2,
                                                   const uint32_t* __restrict__ flag,
@@ -486,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restric
   const q4 a = me[0], b = me[1], d = me[2], k = me[3];
   expand((int32_t)__float_as_uint(k.x), mkq(a.x, a.y, a.z, 0.0f), mkq(a.w, b.x, b.y, 0.0f));
   expand((int32_t)__float_as_uint(k.y), mkq(b.z, b.w, d.x, 0.0f), mkq(d.y, d.z, d.w, 0.0f));
-  write_node4(nodes4 + 4ll * idx4[i], e, cnt, dummy_slot);
+  encode_node4(nodes4 + 4ll * idx4[i], e, cnt, dummy_slot);
 }
 
 // Greedy 4-wide collapse, one thread per output node of the current level.
@@ -543,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_collapse4(int count, const int2* __r
       e[k].code = (int32_t)(id0++ * 64u);
     }
   }
-  write_node4(nodes4 + 4ll * w.y, e, cnt, dummy_slot);
+  encode_node4(nodes4 + 4ll * w.y, e, cnt, dummy_slot);
 }
 
 struct Scratch {

@@ -4,12 +4,13 @@
 // One render pass handles K consecutive timestamps of every owned pixel
 // (K * num_pixels paths).  Per bounce, three kernels run over dense queues in HBM:
 //
-//   extend  : one ray per lane, stack-based BVH2 traversal (LDS stack), writes a
-//             16-B hit record                    (traceRayEXT, raygen.rgen:53-58)
+//   extend  : persistent wave64 state machine over the compressed 4-wide BVH (pt_wavetrace.h; per-lane
+//             stack in LDS), writes a 16-B hit record  (traceRayEXT, raygen.rgen:53-58)
 //   shade   : one shading vertex per lane (rayhit.rchit:666-797 + the raygen
-//             bookkeeping of raygen.rgen:59-80); survivors are compacted into
-//             the next queue with a wave64 ballot + one atomic per wave; paths
-//             that need next-event estimation emit a 64-B shadow-queue record
+//             bookkeeping of raygen.rgen:59-80); each 256-path tile is counting-sorted by BSDF type in
+//             LDS, survivors are compacted into the next queue with a wave64 ballot + an LDS scan +
+//             one atomic pair per tile; paths that need next-event estimation emit a 64-B
+//             shadow-queue record
 //   connect : any-hit traversal of the shadow queue, adds the bounce's emitted
 //             radiance to the sample and sets the continuing path's MIS weight
 //                                                (rayhit.rchit:737-757)
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
       HitRec h;
       uint32_t aux;
       ++ext;
-      if (!trace_lane<false>(S.nodes, S.tri_isect, S.root, in.o, in.d, 0.0f, 1e10f, h, aux)) break;  // miss.rmiss:15-18
+      if (!trace_ray4<false>(S.nodes, S.tri_isect, S.root, in.o, in.d, 0.0f, 1e10f, h, aux)) break;  // miss.rmiss:15-18
       ShadeOut out;
       shade_vertex(S, rc, in, h, out);
       ++shaded;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
         HitRec hs;
         uint32_t aux2;
         ++sh;
-        const bool occluded = trace_lane<true>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2);
+        const bool occluded = trace_ray4<true>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2);
         bool nee_done;
         connect_vertex(rc.clamp, out.shadow, occluded, res, nee_done);
         if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;  // rayhit.rchit:785-787
@@ -692,6 +693,11 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   }
   ctx->have_scene = false;
   // ---- validate ----
+  if ((sc->num_instances && !sc->instances) || (sc->num_vertices && (!sc->positions || !sc->normals)) ||
+      (sc->num_lights && !sc->lights)) {
+    ctx->err = "null array with non-zero count";
+    return GSP_ERR_SCENE;
+  }
   uint64_t total_tris = 0;
   for (uint32_t i = 0; i < sc->num_instances; ++i) {
     const gsp_instance& in = sc->instances[i];
@@ -708,11 +714,6 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   }
   if (total_tris >= (1ull << 28)) {
     ctx->err = "too many triangles (limit 2^28)";
-    return GSP_ERR_SCENE;
-  }
-  if ((sc->num_instances && !sc->instances) || (sc->num_vertices && (!sc->positions || !sc->normals)) ||
-      (sc->num_lights && !sc->lights)) {
-    ctx->err = "null array with non-zero count";
     return GSP_ERR_SCENE;
   }
   auto t0 = std::chrono::steady_clock::now();
@@ -894,6 +895,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
     hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
                        ctx->subset ? ctx->pixel_ids.p : nullptr, Q[P.cur], (uint32_t)P.n, (uint32_t)(slot * batch_paths),
                        L.result.p, L.index, ctx->num_lanes);
+    CTX_TRY(ctx, hipGetLastError());
     CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(L.counters.p + C_LIVE + slot), (int)paths, 1, st));
     L.h_counters[C_LIVE + slot] = (uint32_t)paths;  // not resolvable before the next read-back
     P.slot_used[slot] = 1;
@@ -913,6 +915,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
     CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_TAIL_EXT, 0, 4 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_finish, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
                        L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
+    CTX_TRY(ctx, hipGetLastError());
     CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, C_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     L.in_flight = true;
     L.it_n = n;
@@ -936,12 +939,14 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
                          view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, L.spill.p, ctx->spill_stride,
                          so_ext);
+    CTX_TRY(ctx, hipGetLastError());
   }
   if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[1], st));
   const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
       1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (1024 / kShadeBlock)));
   hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], L.hits.p,
                      Q[cur ^ 1], SQ, L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
+  CTX_TRY(ctx, hipGetLastError());
   if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[2], st));
   {
     const ConnectIO io{SQ, Q[cur ^ 1].P2, L.result.p, rcst.clamp};
@@ -954,6 +959,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
                          view.root, (const uint32_t*)(L.counters.p + C_SHADOW), 0u, chunk, io, work, L.spill.p,
                          ctx->spill_stride, so_sh);
+    CTX_TRY(ctx, hipGetLastError());
   }
   if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[3], st));
   CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, C_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1201,6 +1207,7 @@ int gsp_download(gsp_context* ctx, float* out) {
 
 int gsp_copy_accum_to_device(gsp_context* ctx, void* dst, uint64_t bytes) {
   if (!ctx || !dst || !ctx->have_frame) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
   {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
@@ -1209,7 +1216,6 @@ int gsp_copy_accum_to_device(gsp_context* ctx, void* dst, uint64_t bytes) {
     ctx->err = "destination too small";
     return GSP_ERR_INVALID;
   }
-  CTX_TRY(ctx, hipSetDevice(ctx->device));
   CTX_TRY(ctx, hipMemcpyAsync(dst, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToDevice, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GSP_OK;
@@ -1217,11 +1223,11 @@ int gsp_copy_accum_to_device(gsp_context* ctx, void* dst, uint64_t bytes) {
 
 int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels) {
   if (!ctx || !rgba || !ctx->have_frame || num_pixels != ctx->num_pixels) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
   {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
-  CTX_TRY(ctx, hipSetDevice(ctx->device));
   CTX_TRY(ctx, hipMemcpyAsync(ctx->accum.p, rgba, num_pixels * sizeof(q4), hipMemcpyHostToDevice, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return GSP_OK;
@@ -1229,11 +1235,11 @@ int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels) {
 
 int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
   if (!ctx || !out) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
   {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
-  CTX_TRY(ctx, hipSetDevice(ctx->device));
   if (ctx->dstats.p) {
     DevStats d;
     CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1256,11 +1262,11 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
 
 int gsp_reset_stats(gsp_context* ctx) {
   if (!ctx) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
   {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
-  CTX_TRY(ctx, hipSetDevice(ctx->device));
   ctx->stats = gsp_stats{};
   if (ctx->dstats.p) {
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));

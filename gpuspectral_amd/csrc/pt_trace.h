@@ -1,5 +1,5 @@
-// pt_trace.h -- BVH node / triangle packet layouts in HBM and the per-ray
-// traversal loop of the extend (closest hit) and connect (any hit) kernels.
+// pt_trace.h -- BVH node / triangle packet layouts in HBM, the node encoder, the 4-wide node step and the
+// triangle test every traversal shares (wave kernel pt_wavetrace.h, k_finish, host test harness tests/emu).
 //
 // Replaces the driver's acceleration-structure traversal behind traceRayEXT
 // (S/assets/shaders/raygen.rgen:58, rayhit.rchit:738-748; build call sites
@@ -19,8 +19,6 @@
 //           unused slot: inverted box (qlo = 255, qhi = 0) + the leaf of the degenerate triangle kept
 //                        in slot num_tris, so the traversal has no empty-slot test
 //           child <  0 : leaf, c = ~child, first slot = c >> 2, count = (c & 3) + 1
-//   (the host-side test harness tests/emu keeps an uncompressed binary layout of its own:
-//    q0 = {lmin.xyz, lmax.x} q1 = {lmax.yz, rmin.xy} q2 = {rmin.z, rmax.xyz} q3 = {left, right, -, -})
 //   triangle packet (48 B, in BVH leaf order):
 //                  p0 = {v0.x, v0.y, v0.z, bits(global triangle id)}
 //                  p1 = {v1.x, v1.y, v1.z, bits(BSDF type of the owning instance)}
@@ -102,93 +100,217 @@ GSP_HD bool intersect_tri(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t
   return t > tmin && t < tmax;
 }
 
-// Slab test.  min/max here are the NaN-dropping IEEE forms, so a NaN from
-// 0*inf (origin on a slab plane, zero direction component) leaves that slab
-// unconstrained: conservative.  The far bound is relaxed by 8 ulp.
+// min/max here are the NaN-dropping IEEE forms, so a NaN from 0*inf (origin on a slab plane, zero direction
+// component) leaves that slab unconstrained: conservative.
 GSP_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 GSP_HD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
-GSP_HD bool slab(float bx0, float by0, float bz0, float bx1, float by1, float bz1, f3 o, f3 inv, float tmin,
-                 float tmax, float& tnear) {
-  float t0x = (bx0 - o.x) * inv.x, t1x = (bx1 - o.x) * inv.x;
-  float t0y = (by0 - o.y) * inv.y, t1y = (by1 - o.y) * inv.y;
-  float t0z = (bz0 - o.z) * inv.z, t1z = (bz1 - o.z) * inv.z;
-  float lo = fmax_(fmax_(fmin_(t0x, t1x), fmin_(t0y, t1y)), fmax_(fmin_(t0z, t1z), tmin));
-  float hi = fmin_(fmin_(fmax_(t0x, t1x), fmax_(t0y, t1y)), fmin_(fmax_(t0z, t1z), tmax));
-  tnear = lo;
-  return lo <= hi * 1.000001f;  // 8 ulp of slack on top of the padded boxes
+
+// ---- compressed 4-wide node: encoder (device BVH build, pt_bvh.hip; host test harness, tests/emu) --------------
+struct Entry4 {
+  q4 lo, hi;
+  int32_t code;
+};
+GSP_HD q4 make_q4(float x, float y, float z, float w) {
+  q4 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  r.w = w;
+  return r;
+}
+// Writes one compressed 4-wide node (64 B, layout at the top of this file) from up to four child entries.
+// Child boxes are quantised outward and checked against the decode (plane = fma(q, scale, origin)).
+GSP_HD void encode_node4(q4* __restrict__ o, const Entry4* e, int cnt, uint32_t dummy_slot) {
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = 0; k < cnt; ++k) {
+    lo[0] = fmin_(lo[0], e[k].lo.x); lo[1] = fmin_(lo[1], e[k].lo.y); lo[2] = fmin_(lo[2], e[k].lo.z);
+    hi[0] = fmax_(hi[0], e[k].hi.x); hi[1] = fmax_(hi[1], e[k].hi.y); hi[2] = fmax_(hi[2], e[k].hi.z);
+  }
+  float scale[3];
+  for (int a = 0; a < 3; ++a) {
+    const float ext = hi[a] - lo[a];
+    int ex = -100;
+    if (ext > 0.0f) (void)frexpf(ext / 255.0f, &ex);  // 2^ex >= ext / 255
+    int eb = ex + 127;
+    eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+    // the largest code must reach the far side of the node
+    while (eb < 254 && __builtin_fmaf(255.0f, u2f((uint32_t)eb << 23), lo[a]) < hi[a]) ++eb;
+    scale[a] = u2f((uint32_t)eb << 23);
+  }
+  uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // qlo.x, qlo.y, qlo.z, qhi.x, qhi.y, qhi.z : one byte per child
+  for (int k = 0; k < cnt; ++k) {
+    const float cl[3] = {e[k].lo.x, e[k].lo.y, e[k].lo.z}, ch[3] = {e[k].hi.x, e[k].hi.y, e[k].hi.z};
+    for (int a = 0; a < 3; ++a) {
+      float ql = fmin_(fmax_(__builtin_floorf((cl[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
+      while (ql > 0.0f && __builtin_fmaf(ql, scale[a], lo[a]) > cl[a]) ql -= 1.0f;  // decoded plane must not exceed the box
+      float qh = fmin_(fmax_(__builtin_ceilf((ch[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
+      while (qh < 255.0f && __builtin_fmaf(qh, scale[a], lo[a]) < ch[a]) qh += 1.0f;
+      q[a] |= (uint32_t)ql << (8 * k);
+      q[3 + a] |= (uint32_t)qh << (8 * k);
+    }
+  }
+  // unused slots: inverted box (near plane beyond the far plane: misses) that leads to the degenerate
+  // triangle, so the traversal needs no empty-slot test and a rounding fluke costs one triangle test
+  for (int k = cnt; k < 4; ++k)
+    for (int a = 0; a < 3; ++a) q[a] |= 255u << (8 * k);
+  int32_t code[4];
+  for (int k = 0; k < 4; ++k) code[k] = k < cnt ? e[k].code : make_leaf(dummy_slot, 1);
+  o[0] = make_q4(lo[0], lo[1], lo[2], scale[0]);
+  o[1] = make_q4(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
+  o[2] = make_q4(u2f(q[4]), u2f(q[5]), u2f((uint32_t)code[0]), u2f((uint32_t)code[1]));
+  o[3] = make_q4(u2f((uint32_t)code[2]), u2f((uint32_t)code[3]), scale[1], scale[2]);
 }
 
-struct TraceCounters {
-  uint32_t nodes, tris;
+// ---- compressed 4-wide node: one traversal step (the ONE decode + slab test + ordering every traversal uses:
+// k_trace and k_finish on the device, tests/emu on the host) ------------------------------------------------------
+// Per-ray constants of the step.
+struct RayBox {
+  f3 o, inv;               // origin, 1 / direction
+  bool negx, negy, negz;   // sign of 1/d per axis: which plane of a slab is the near one
 };
+GSP_HD RayBox make_raybox(f3 o, f3 d) {
+  RayBox r;
+  r.o = o;
+  r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  r.negx = r.inv.x < 0.0f;
+  r.negy = r.inv.y < 0.0f;
+  r.negz = r.inv.z < 0.0f;
+  return r;
+}
+// Tests the four child boxes of the node {n0..n3} against the ray segment [tmin, tfar] and returns the children
+// ordered by entry distance: e0 nearest .. e3, of which the first `hits` are hit (the rest are unspecified).
+// The return value is hits * UNIT (the wave kernel keeps the count in stack-offset units).
+//   decode: plane = origin + q * scale (per-axis power of two, stored as a float), taken relative to the ray origin
+//   as fma(q, scale, origin - o) (same rounding class as an uncompressed (b - o)), then * 1/d.  (Folding 1/d into
+//   per-node constants, t = fma(q, scale/d, (origin-o)/d), is one multiply per plane cheaper but overflows for rays
+//   with a tiny direction component: those rays lose their culling, run far longer than the rest and stretch every
+//   launch -- measured +13 % / +47 % kernel time at unchanged mean nodes per ray.)
+//   Near / far planes are picked by the sign of 1/d instead of min / max per child: for inv > 0
+//   (lo - o) * inv <= (hi - o) * inv by monotonic rounding, so the values are the ones min / max would return; a
+//   NaN (0 * inf) is dropped by max / min and leaves that side unconstrained.  The far bound is relaxed by 8 ulp on
+//   top of the padded boxes.  Unused slots carry an inverted box and the degenerate triangle's leaf: no test needed.
+template <uint32_t UNIT>
+GSP_HD uint32_t node4_step(const q4& n0, const q4& n1, const q4& n2, const q4& n3, const RayBox& rb, float tmin, float tfar,
+                           int32_t& e0, int32_t& e1, int32_t& e2, int32_t& e3) {
+  const float sx = n0.w, sy = n3.z, sz = n3.w;
+  const float dx = n0.x - rb.o.x, dy = n0.y - rb.o.y, dz = n0.z - rb.o.z;
+  const uint32_t qlx = f2u(n1.x), qly = f2u(n1.y), qlz = f2u(n1.z), qhx = f2u(n1.w), qhy = f2u(n2.x), qhz = f2u(n2.y);
+  const uint32_t qnx = rb.negx ? qhx : qlx, qfx = rb.negx ? qlx : qhx;
+  const uint32_t qny = rb.negy ? qhy : qly, qfy = rb.negy ? qly : qhy;
+  const uint32_t qnz = rb.negz ? qhz : qlz, qfz = rb.negz ? qlz : qhz;
+  float lo4[4];
+  bool hit4[4];
+// (float)((q >> 8k) & 0xff) compiles to v_cvt_f32_ubyteK
+#define GSP_UB0(q) ((float)((q) & 0xffu))
+#define GSP_UB1(q) ((float)(((q) >> 8) & 0xffu))
+#define GSP_UB2(q) ((float)(((q) >> 16) & 0xffu))
+#define GSP_UB3(q) ((float)((q) >> 24))
+#define GSP_CHILD(K, CVT)                                                                                         \
+  {                                                                                                               \
+    const float tnx = __builtin_fmaf(CVT(qnx), sx, dx) * rb.inv.x, tfx = __builtin_fmaf(CVT(qfx), sx, dx) * rb.inv.x; \
+    const float tny = __builtin_fmaf(CVT(qny), sy, dy) * rb.inv.y, tfy = __builtin_fmaf(CVT(qfy), sy, dy) * rb.inv.y; \
+    const float tnz = __builtin_fmaf(CVT(qnz), sz, dz) * rb.inv.z, tfz = __builtin_fmaf(CVT(qfz), sz, dz) * rb.inv.z; \
+    const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));                                                    \
+    const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, tfar));                                                    \
+    lo4[K] = lo;                                                                                                  \
+    hit4[K] = lo <= hi * 1.000001f;                                                                               \
+  }
+  GSP_CHILD(0, GSP_UB0)
+  GSP_CHILD(1, GSP_UB1)
+  GSP_CHILD(2, GSP_UB2)
+  GSP_CHILD(3, GSP_UB3)
+#undef GSP_CHILD
+#undef GSP_UB0
+#undef GSP_UB1
+#undef GSP_UB2
+#undef GSP_UB3
+  const bool h0 = hit4[0], h1 = hit4[1], h2 = hit4[2], h3 = hit4[3];
+  // order the hit children by entry distance: 5-comparator network on {distance bits, child}
+  // (entry distances are >= tmin >= 0, so their bit patterns order like unsigned integers; a miss sorts last)
+  uint32_t k0 = h0 ? f2u(lo4[0]) : 0xffffffffu, k1 = h1 ? f2u(lo4[1]) : 0xffffffffu;
+  uint32_t k2 = h2 ? f2u(lo4[2]) : 0xffffffffu, k3 = h3 ? f2u(lo4[3]) : 0xffffffffu;
+  e0 = (int32_t)f2u(n2.z);
+  e1 = (int32_t)f2u(n2.w);
+  e2 = (int32_t)f2u(n3.x);
+  e3 = (int32_t)f2u(n3.y);
+#define GSP_CSWAP(ka, kb, ea, eb)   \
+  {                                 \
+    const bool sw = kb < ka;        \
+    const uint32_t tk = sw ? kb : ka; \
+    kb = sw ? ka : kb;              \
+    ka = tk;                        \
+    const int32_t te = sw ? eb : ea; \
+    eb = sw ? ea : eb;              \
+    ea = te;                        \
+  }
+  GSP_CSWAP(k0, k1, e0, e1)
+  GSP_CSWAP(k2, k3, e2, e3)
+  GSP_CSWAP(k0, k2, e0, e2)
+  GSP_CSWAP(k1, k3, e1, e3)
+  GSP_CSWAP(k1, k2, e1, e2)
+#undef GSP_CSWAP
+  return (h0 ? UNIT : 0u) + (h1 ? UNIT : 0u) + (h2 ? UNIT : 0u) + (h3 ? UNIT : 0u);
+}
 
-// One ray against the BVH.  ANY = true: return at the first accepted triangle
-// (TerminateOnFirstHit | SkipClosestHitShader).  `Stack` supplies push/pop/empty.
-template <bool ANY, bool STATS, class Stack>
-GSP_HD bool traverse(const q4* __restrict__ nodes, const q4* __restrict__ tris, int32_t root, f3 o, f3 d, float tmin,
-                     float tmax, Stack& stk, HitRec& hit, TraceCounters& cnt) {
-  hit.t = tmax;
-  hit.u = 0.0f;
-  hit.v = 0.0f;
-  hit.slot = -1;
+// One ray against the 4-wide BVH on one thread, start to finish: the traversal of k_finish (which runs the last few
+// thousand paths of a drain to completion without the wavefront queues) and of the host test harness.  Same node
+// step, same triangle test and the same min-t / min-id rule as the wave kernel (pt_wavetrace.h), so the hit is the
+// same; the visiting order is not (and need not be).  ANY = true: return at the first accepted triangle
+// (TerminateOnFirstHit | SkipClosestHitShader).  aux = p1.w of the accepted triangle (BSDF type).
+constexpr int kLaneStackDepth = 96;
+template <bool ANY>
+GSP_HD bool trace_ray4(const q4* __restrict__ nodes, const q4* __restrict__ tris, int32_t root, f3 o, f3 d, float tmin,
+                       float tmax, HitRec& h, uint32_t& aux) {
+  int32_t stack[kLaneStackDepth];
+  int sp = 0;
+  const RayBox rb = make_raybox(o, d);
+  RayShear rs = make_shear(d);
+  rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
+  h.t = tmax;
+  h.u = h.v = 0.0f;
+  h.slot = -1;
+  aux = 0;
   uint32_t best_id = 0xffffffffu;
-  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const RayShear rs = make_shear(d);
   int32_t cur = root;
-  bool found = false;
   for (;;) {
     if (cur >= 0) {
-      const q4* n = nodes + 4ll * cur;
-      const q4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-      if (STATS) cnt.nodes++;
-      float tl, tr;
-      const bool hl = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, hit.t, tl);
-      const bool hr = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, hit.t, tr);
-      const int32_t cl = (int32_t)f2u(q3.x), cr = (int32_t)f2u(q3.y);
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        stk.push(left_first ? cr : cl);
-        cur = left_first ? cl : cr;
-        continue;
-      } else if (hl) {
-        cur = cl;
-        continue;
-      } else if (hr) {
-        cur = cr;
+      const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
+      int32_t e[4];
+      const uint32_t hits = node4_step<1u>(nd[0], nd[1], nd[2], nd[3], rb, tmin, h.t, e[0], e[1], e[2], e[3]);
+      for (uint32_t k = hits; k-- > 1u;) stack[sp++] = e[k];  // farthest first
+      if (hits != 0u) {
+        cur = e[0];
         continue;
       }
     } else {
-      const uint32_t c = (uint32_t)~cur;
-      const uint32_t first = c >> 2, count = (c & 3u) + 1u;
+      const uint32_t cc = (uint32_t)~cur;
+      const uint32_t first = cc >> 2, count = (cc & 3u) + 1u;
       for (uint32_t k = 0; k < count; ++k) {
         const q4* p = tris + 3ll * (first + k);
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
-        if (STATS) cnt.tris++;
         float t, u, v;
-        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u,
-                          v)) {
+        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u, v)) {
           if (ANY) {
-            hit.t = t;
-            hit.slot = (int32_t)(first + k);
-            found = true;
-            break;
+            h.t = t;
+            h.slot = (int32_t)(first + k);
+            return true;
           }
           const uint32_t id = f2u(p0.w);
-          if (t < hit.t || (t == hit.t && id < best_id)) {
-            hit.t = t;
-            hit.u = u;
-            hit.v = v;
-            hit.slot = (int32_t)(first + k);
+          if (t < h.t || (t == h.t && id < best_id)) {
+            h.t = t;
+            h.u = u;
+            h.v = v;
+            h.slot = (int32_t)(first + k);
             best_id = id;
+            aux = f2u(p1.w);
           }
         }
       }
-      if (ANY && found) break;
     }
-    if (stk.empty()) break;
-    cur = stk.pop();
+    if (sp == 0) break;
+    cur = stack[--sp];
   }
-  return hit.slot >= 0;
+  return h.slot >= 0;
 }
 
 }  // namespace gsp

@@ -143,97 +143,6 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
-// One ray on one lane, start to finish (no wave cooperation): the traversal of k_finish, which runs the last few
-// thousand paths of a drain to completion without the wavefront queues.  Same node decode, same triangle test and
-// the same min-t / min-id rule as the wave kernel, so the hit is the same; the visiting order is not (and need not be).
-constexpr int kLaneStackDepth = 96;
-template <bool ANY>
-__device__ __forceinline__ bool trace_lane(const q4* __restrict__ nodes, const q4* __restrict__ tris, int32_t root, f3 o, f3 d,
-                                           float tmin, float tmax, HitRec& h, uint32_t& aux) {
-  int32_t stack[kLaneStackDepth];
-  int sp = 0;
-  const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
-  RayShear rs = make_shear(d);
-  rs.Sz = comp(inv, rs.kz);
-  h.t = tmax;
-  h.u = h.v = 0.0f;
-  h.slot = -1;
-  aux = 0;
-  uint32_t best_id = 0xffffffffu;
-  int32_t cur = root;
-  for (;;) {
-    if (cur >= 0) {
-      const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
-      const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-      const int32_t c[4] = {(int32_t)__float_as_uint(n2.z), (int32_t)__float_as_uint(n2.w), (int32_t)__float_as_uint(n3.x),
-                            (int32_t)__float_as_uint(n3.y)};
-      const float sx = n0.w, sy = n3.z, sz = n3.w;
-      const float dx = n0.x - o.x, dy = n0.y - o.y, dz = n0.z - o.z;
-      const uint32_t qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z),
-                     qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
-      const uint32_t qnx = negx ? qhx : qlx, qfx = negx ? qlx : qhx;
-      const uint32_t qny = negy ? qhy : qly, qfy = negy ? qly : qhy;
-      const uint32_t qnz = negz ? qhz : qlz, qfz = negz ? qlz : qhz;
-      uint32_t key[4];
-      int32_t e[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float tnx = __builtin_fmaf((float)((qnx >> (8 * k)) & 0xffu), sx, dx) * inv.x,
-                    tfx = __builtin_fmaf((float)((qfx >> (8 * k)) & 0xffu), sx, dx) * inv.x;
-        const float tny = __builtin_fmaf((float)((qny >> (8 * k)) & 0xffu), sy, dy) * inv.y,
-                    tfy = __builtin_fmaf((float)((qfy >> (8 * k)) & 0xffu), sy, dy) * inv.y;
-        const float tnz = __builtin_fmaf((float)((qnz >> (8 * k)) & 0xffu), sz, dz) * inv.z,
-                    tfz = __builtin_fmaf((float)((qfz >> (8 * k)) & 0xffu), sz, dz) * inv.z;
-        const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));
-        const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, h.t));
-        key[k] = lo <= hi * 1.000001f ? __float_as_uint(lo) : 0xffffffffu;
-        e[k] = c[k];
-      }
-#define GSP_CSWAP(a, b)                                  \
-  if (key[b] < key[a]) {                                 \
-    const uint32_t tk = key[a]; key[a] = key[b]; key[b] = tk; \
-    const int32_t te = e[a]; e[a] = e[b]; e[b] = te;     \
-  }
-      GSP_CSWAP(0, 1) GSP_CSWAP(2, 3) GSP_CSWAP(0, 2) GSP_CSWAP(1, 3) GSP_CSWAP(1, 2)
-#undef GSP_CSWAP
-      for (int k = 3; k >= 1; --k)
-        if (key[k] != 0xffffffffu) stack[sp++] = e[k];
-      if (key[0] != 0xffffffffu) {
-        cur = e[0];
-        continue;
-      }
-    } else {
-      const uint32_t cc = (uint32_t)~cur;
-      const uint32_t first = cc >> 2, count = (cc & 3u) + 1u;
-      for (uint32_t k = 0; k < count; ++k) {
-        const q4* p = tris + 3ll * (first + k);
-        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
-        float t, u, v;
-        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u, v)) {
-          if (ANY) {
-            h.t = t;
-            h.slot = (int32_t)(first + k);
-            return true;
-          }
-          const uint32_t id = __float_as_uint(p0.w);
-          if (t < h.t || (t == h.t && id < best_id)) {
-            h.t = t;
-            h.u = u;
-            h.v = v;
-            h.slot = (int32_t)(first + k);
-            best_id = id;
-            aux = __float_as_uint(p1.w);
-          }
-        }
-      }
-    }
-    if (sp == 0) break;
-    cur = stack[--sp];
-  }
-  return h.slot >= 0;
-}
-
 // IO contract:
 //   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const;
 //   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux) const;   // h.slot < 0: miss / unoccluded;
@@ -265,8 +174,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
   // per-lane ray state
   int32_t cur = kSentinel, leaf = 0;
   uint32_t ri = 0xffffffffu, best_id = 0xffffffffu, best_aux = 0;
-  f3 o = mk3(0, 0, 0), inv = mk3(0, 0, 0);
-  bool negx = false, negy = false, negz = false;  // sign of 1/d per axis: which plane of a slab is the near one
+  RayBox rb = make_raybox(mk3(0, 0, 0), mk3(1, 1, 1));
   RayShear rs;
   rs.kx = rs.ky = rs.kz = 0;
   rs.Sx = rs.Sy = rs.Sz = 0.0f;
@@ -326,13 +234,11 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
         if (((idle_m >> lane) & 1ull) && rank < avail) {
           ri = pool_next + rank;
           f3 d;
+          f3 o;
           io.load(ri, o, d, tmin, tmax);
-          inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-          negx = inv.x < 0.0f;
-          negy = inv.y < 0.0f;
-          negz = inv.z < 0.0f;
+          rb = make_raybox(o, d);
           rs = make_shear(d);
-          rs.Sz = comp(inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
+          rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
           h.t = tmax;
           h.u = h.v = 0.0f;
           h.slot = -1;
@@ -392,76 +298,14 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
         }
 #endif
       if (on) {
-          // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip write_node4)
+          // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip through encode_node4)
           // (`cur` is the node's byte offset: 32-bit offset + uniform base, no 64-bit address arithmetic)
           const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
           const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
           if (STATS) ++c_nodes;
-          const int32_t c0 = (int32_t)__float_as_uint(n2.z), c1 = (int32_t)__float_as_uint(n2.w),
-                        c2 = (int32_t)__float_as_uint(n3.x), c3 = (int32_t)__float_as_uint(n3.y);
-          // decode: plane = origin + q * scale (per-axis power of two, stored as a float), taken relative to
-          // the ray origin as fma(q, scale, origin - o) (same rounding class as the uncompressed (b - o)),
-          // then * 1/d.  (Folding 1/d into per-node constants, t = fma(q, scale/d, (origin-o)/d), is one
-          // multiply per plane cheaper but cancels catastrophically for rays with a tiny direction component:
-          // those rays lose their culling, run far longer than the rest and stretch every launch -- measured
-          // +13 % / +47 % kernel time at unchanged mean nodes per ray.)
-          const float sx = n0.w, sy = n3.z, sz = n3.w;
-          const float dx = n0.x - o.x, dy = n0.y - o.y, dz = n0.z - o.z;
-          const uint32_t qlx = __float_as_uint(n1.x), qly = __float_as_uint(n1.y), qlz = __float_as_uint(n1.z),
-                         qhx = __float_as_uint(n1.w), qhy = __float_as_uint(n2.x), qhz = __float_as_uint(n2.y);
-          // Near / far planes picked by the sign of 1/d instead of min / max per child: for inv > 0
-          // (lo - o) * inv <= (hi - o) * inv by monotonic rounding, so the values are the ones min / max
-          // would return; a NaN (0 * inf) is dropped by max3 / min3 and leaves that side unconstrained.
-          const uint32_t qnx = negx ? qhx : qlx, qfx = negx ? qlx : qhx;
-          const uint32_t qny = negy ? qhy : qly, qfy = negy ? qly : qhy;
-          const uint32_t qnz = negz ? qhz : qlz, qfz = negz ? qlz : qhz;
-          float lo4[4];
-          bool hit4[4];
-// (float)((q >> 8k) & 0xff) compiles to v_cvt_f32_ubyteK
-#define GSP_UB0(q) ((float)((q) & 0xffu))
-#define GSP_UB1(q) ((float)(((q) >> 8) & 0xffu))
-#define GSP_UB2(q) ((float)(((q) >> 16) & 0xffu))
-#define GSP_UB3(q) ((float)((q) >> 24))
-#define GSP_CHILD(K, CVT)                                                                               \
-  {                                                                                                     \
-    const float tnx = __builtin_fmaf(CVT(qnx), sx, dx) * inv.x, tfx = __builtin_fmaf(CVT(qfx), sx, dx) * inv.x; \
-    const float tny = __builtin_fmaf(CVT(qny), sy, dy) * inv.y, tfy = __builtin_fmaf(CVT(qfy), sy, dy) * inv.y; \
-    const float tnz = __builtin_fmaf(CVT(qnz), sz, dz) * inv.z, tfz = __builtin_fmaf(CVT(qfz), sz, dz) * inv.z; \
-    const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));                                            \
-    const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, h.t));                                             \
-    lo4[K] = lo;                                                                                        \
-    hit4[K] = lo <= hi * 1.000001f;                                                                     \
-  }
-          GSP_CHILD(0, GSP_UB0)
-          GSP_CHILD(1, GSP_UB1)
-          GSP_CHILD(2, GSP_UB2)
-          GSP_CHILD(3, GSP_UB3)
-#undef GSP_CHILD
-          // (unused slots carry an inverted box and the degenerate triangle's leaf: no test needed)
-          const bool h0 = hit4[0], h1 = hit4[1], h2 = hit4[2], h3 = hit4[3];
-          // order the hit children by entry distance: 5-comparator network on {distance bits, child}
-          // (entry distances are >= tmin >= 0, so their bit patterns order like unsigned integers)
-          uint32_t k0 = h0 ? __float_as_uint(lo4[0]) : 0xffffffffu, k1 = h1 ? __float_as_uint(lo4[1]) : 0xffffffffu;
-          uint32_t k2 = h2 ? __float_as_uint(lo4[2]) : 0xffffffffu, k3 = h3 ? __float_as_uint(lo4[3]) : 0xffffffffu;
-          int32_t e0 = c0, e1 = c1, e2 = c2, e3 = c3;
-  #define GSP_CSWAP(ka, kb, ea, eb)                 \
-    {                                               \
-      const bool sw = kb < ka;                      \
-      const uint32_t tk = sw ? kb : ka;             \
-      kb = sw ? ka : kb;                            \
-      ka = tk;                                      \
-      const int32_t te = sw ? eb : ea;              \
-      eb = sw ? ea : eb;                            \
-      ea = te;                                      \
-    }
-          GSP_CSWAP(k0, k1, e0, e1)
-          GSP_CSWAP(k2, k3, e2, e3)
-          GSP_CSWAP(k0, k2, e0, e2)
-          GSP_CSWAP(k1, k3, e1, e3)
-          GSP_CSWAP(k1, k2, e1, e2)
-  #undef GSP_CSWAP
           constexpr uint32_t L = WaveStack::kLevelBytes;  // hit count kept in stack-offset units
-          const uint32_t nb = (h0 ? L : 0u) + (h1 ? L : 0u) + (h2 ? L : 0u) + (h3 ? L : 0u);
+          int32_t e0, e1, e2, e3;
+          const uint32_t nb = node4_step<L>(n0, n1, n2, n3, rb, tmin, h.t, e0, e1, e2, e3);
           stk.push_sorted(nb > 0u ? nb - L : 0u, e1, e2, e3);
           if (nb > 0u) cur = e0;
           else cur = stk.pop();
@@ -489,7 +333,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
         if (STATS) ++c_tris;
         float t, u, v;
-        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u,
+        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u,
                           v)) {
           if (ANY) {
             h.t = t;

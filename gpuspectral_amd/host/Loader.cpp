@@ -13,6 +13,7 @@
 // (number 0, colour 0, bool default), fan triangulation, relative OBJ indices.
 #include "Loader.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -229,7 +230,20 @@ bool isObjectTag(const std::string& t) {
   return false;
 }
 
-std::shared_ptr<Object> parseObject(const XmlNode& el, std::unordered_map<std::string, std::shared_ptr<Object>>& ids) {
+// <ref id="x"/> that names an object defined later in the file: the slot in the parent's child list is kept and
+// patched once the whole document has been read (resolveRefs).
+struct PendingRef {
+  std::shared_ptr<Object> parent;
+  size_t slot;
+  std::string id;
+};
+struct ParseState {
+  std::unordered_map<std::string, std::shared_ptr<Object>> ids;
+  std::vector<PendingRef> pending;
+};
+
+std::shared_ptr<Object> parseObject(const XmlNode& el, ParseState& ps) {
+  auto& ids = ps.ids;
   auto o = std::make_shared<Object>();
   o->kind = el.tag;
   o->plugin = el.get("type");
@@ -279,15 +293,35 @@ std::shared_ptr<Object> parseObject(const XmlNode& el, std::unordered_map<std::s
       o->props[nm] = pr;
     } else if (ch.tag == "ref") {
       auto it = ids.find(ch.get("id"));
-      if (it != ids.end()) o->children.push_back(it->second);
+      if (it != ids.end()) {
+        o->children.push_back(it->second);
+      } else {  // forward (or dangling) reference
+        ps.pending.push_back(PendingRef{o, o->children.size(), ch.get("id")});
+        o->children.push_back(nullptr);
+      }
     } else if (isObjectTag(ch.tag)) {
-      auto child = parseObject(ch, ids);
+      auto child = parseObject(ch, ps);
       if (ch.attr("id")) ids[ch.get("id")] = child;
       if (ch.attr("name")) o->named.emplace_back(nm, child);
       else o->children.push_back(child);
     }
   }
   return o;
+}
+
+// Second pass over the references that pointed forward; what is still unknown is dropped with a warning (the shape
+// then keeps the default BSDF, as with the reference's parser).
+void resolveRefs(ParseState& ps, std::vector<std::string>& warnings) {
+  for (auto& pr : ps.pending) {
+    auto it = ps.ids.find(pr.id);
+    if (it != ps.ids.end()) pr.parent->children[pr.slot] = it->second;
+    else warnings.push_back("unresolved <ref id=\"" + pr.id + "\"> dropped");
+  }
+  for (auto& pr : ps.pending) {
+    auto& ch = pr.parent->children;
+    ch.erase(std::remove(ch.begin(), ch.end(), nullptr), ch.end());
+  }
+  ps.pending.clear();
 }
 
 std::string dirOf(const std::string& path) {
@@ -418,27 +452,29 @@ MeshPtr loadMesh(const std::string& path, uint32_t id) {
   while (std::getline(in, line)) {
     const char* c = line.c_str();
     while (*c == ' ' || *c == '\t') ++c;
-    if (c[0] == 'v' && (c[1] == ' ' || c[1] == '\t')) {
-      char* e;
-      c += 2;
-      for (int k = 0; k < 3; ++k) {
-        v.push_back((float)std::strtod(c, &e));
-        c = e;
+    // `c` stays inside the line: every component is one whitespace-delimited token; a missing or unparsable one
+    // reads as 0 (what tinyobjloader's parseReal does with its default), never past the terminating NUL
+    auto reals = [&](const char* p, int count, std::vector<float>& dst) {
+      for (int k = 0; k < count; ++k) {
+        while (*p == ' ' || *p == '\t') ++p;
+        float val = 0.0f;
+        if (*p && *p != '\r' && *p != '\n') {
+          char* e = nullptr;
+          const double d = std::strtod(p, &e);
+          if (e != p) val = (float)d;
+          while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') ++p;  // skip the whole token
+        }
+        dst.push_back(val);
       }
-    } else if (c[0] == 'v' && c[1] == 'n') {
-      char* e;
-      c += 3;
-      for (int k = 0; k < 3; ++k) {
-        vn.push_back((float)std::strtod(c, &e));
-        c = e;
-      }
-    } else if (c[0] == 'v' && c[1] == 't') {
-      char* e;
-      c += 3;
-      for (int k = 0; k < 2; ++k) {
-        vt.push_back((float)std::strtod(c, &e));
-        c = e;
-      }
+    };
+    const bool ws2 = c[0] && (c[1] == ' ' || c[1] == '\t');
+    const bool ws3 = c[0] && c[1] && (c[2] == ' ' || c[2] == '\t' || c[2] == '\0' || c[2] == '\r');
+    if (c[0] == 'v' && ws2) {
+      reals(c + 2, 3, v);
+    } else if (c[0] == 'v' && c[1] == 'n' && ws3) {
+      reals(c + 2, 3, vn);
+    } else if (c[0] == 'v' && c[1] == 't' && ws3) {
+      reals(c + 2, 2, vt);
     } else if (c[0] == 'f' && (c[1] == ' ' || c[1] == '\t')) {
       corners.clear();
       c += 2;
@@ -508,12 +544,13 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg) {
   const std::string parentPath = dirOf(path);
   const std::string assetDir = !assetDirArg.empty() ? assetDirArg : (!g_defaultAssetDir.empty() ? g_defaultAssetDir : parentPath);
 
-  std::unordered_map<std::string, std::shared_ptr<Object>> ids;
-  auto top = parseObject(*root, ids);
+  ParseState ps;
+  auto top = parseObject(*root, ps);
 
   std::unordered_map<std::string, MeshPtr> meshCache;
   uint32_t nextMeshId = 1;
   Scene outScene;
+  resolveRefs(ps, outScene.warnings);
   auto loadOrGetMesh = [&](const std::string& objPath, int builtin) -> MeshPtr {
     auto it = meshCache.find(objPath);
     if (it != meshCache.end()) return it->second;

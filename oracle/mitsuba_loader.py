@@ -144,7 +144,9 @@ def _floats(text):
     return [float(t) for t in re.split(r"[\s,]+", text.strip()) if t]
 
 
-def _parse_object(el, ids):
+def _parse_object(el, ids, pending=None):
+    """`pending` collects forward <ref>s as (parent, slot, id); _resolve_refs patches them after the whole
+    document has been read (same two passes as the C++ loader, gpuspectral_amd/host/Loader.cpp)."""
     o = Obj(el.tag, el.get("type", ""))
     for ch in el:
         tag = ch.tag
@@ -177,8 +179,11 @@ def _parse_object(el, ids):
             target = ids.get(ch.get("id"))
             if target is not None:
                 o.children.append(target)
+            elif pending is not None:
+                pending.append((o, len(o.children), ch.get("id")))
+                o.children.append(None)
         elif tag in _OBJECT_TAGS:
-            child = _parse_object(ch, ids)
+            child = _parse_object(ch, ids, pending)
             if ch.get("id"):
                 ids[ch.get("id")] = child
             if ch.get("name"):
@@ -186,6 +191,16 @@ def _parse_object(el, ids):
             else:
                 o.children.append(child)
     return o
+
+
+def _resolve_refs(ids, pending, warnings):
+    for parent, slot, rid in pending:
+        if rid in ids:
+            parent.children[slot] = ids[rid]
+        else:
+            warnings.append('unresolved <ref id="%s"> dropped' % rid)
+    for parent, _, _ in pending:
+        parent.children[:] = [c for c in parent.children if c is not None]
 
 
 def glm_mul_point(m, p):
@@ -284,8 +299,10 @@ def load_scene(path, asset_dir=None):
     asset_dir = asset_dir or parent
     root = ET.parse(path).getroot()
     ids = {}
-    top = _parse_object(root, ids)
+    pending = []
+    top = _parse_object(root, ids, pending)
     b = _Builder(asset_dir)
+    _resolve_refs(ids, pending, b.warnings)
     sc = b.sc
     for obj in top.children:
         if obj.kind == "shape":

@@ -18,6 +18,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a box without a GPU skips the gpu-marked tests instead of failing them (the GPU box and
+    `-m gpu` runs are unaffected: there the device exists and a missing library still fails loudly)."""
+    if not any("gpu" in it.keywords for it in items):
+        return
+    try:
+        import gpuspectral_amd as g
+
+        if g.device_count() > 0:
+            return
+    except Exception:
+        return  # library missing / not loadable: do NOT skip -- the gpu tests must fail loudly
+    skip = pytest.mark.skip(reason="no HIP device visible (gsp_device_count() == 0)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 def has_gpu():
     try:
         import gpuspectral_amd as g

@@ -8,9 +8,10 @@
 // and is never imported by the gpuspectral_amd package, bench.py's timed path
 // or anything shipped: the product renders on the GPU only.
 //
-// The BVH here is a plain median-split tree written in the device node format;
-// closest-hit results do not depend on the BVH topology (pt_trace.h), so this
-// exercises the same traversal loop the extend/connect kernels instantiate.
+// The BVH here is a plain median-split 4-wide tree written with the product's own node
+// encoder (encode_node4, pt_trace.h) and walked with the product's own per-ray traversal
+// (trace_ray4: the node step node4_step + intersect_tri that k_trace and k_finish run);
+// closest-hit results do not depend on the BVH topology (pt_trace.h).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -23,14 +24,6 @@
 using namespace gsp;
 
 namespace {
-
-struct VecStack {
-  int32_t s[256];
-  int sp = 0;
-  void push(int32_t v) { s[sp++] = v; }
-  int32_t pop() { return s[--sp]; }
-  bool empty() const { return sp == 0; }
-};
 
 q4 mkq(float x, float y, float z, float w) {
   q4 r;
@@ -102,25 +95,14 @@ struct Emu {
     const uint32_t n = g;
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    // median split, one triangle per leaf; emits nodes in the device format
+    // median split into a 4-wide tree, leaves of 1-2 triangles; nodes written by the product's encoder
     nodes.clear();
     struct Rec {
       int32_t code;
       float lo[3], hi[3];
     };
     std::vector<uint32_t> slots;  // final slot order
-    std::function<Rec(uint32_t, uint32_t)> build = [&](uint32_t first, uint32_t count) -> Rec {
-      Rec r;
-      if (count == 1) {
-        uint32_t slot = (uint32_t)slots.size();
-        slots.push_back(order[first]);
-        r.code = make_leaf(slot, 1);
-        for (int c = 0; c < 3; ++c) {
-          r.lo[c] = glo[3ull * order[first] + c];
-          r.hi[c] = ghi[3ull * order[first] + c];
-        }
-        return r;
-      }
+    auto split = [&](uint32_t first, uint32_t count) -> uint32_t {  // returns the size of the left part
       float cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
       for (uint32_t i = first; i < first + count; ++i)
         for (int c = 0; c < 3; ++c) {
@@ -136,18 +118,59 @@ struct Emu {
                        [&](uint32_t a, uint32_t b) {
                          return glo[3ull * a + ax] + ghi[3ull * a + ax] < glo[3ull * b + ax] + ghi[3ull * b + ax];
                        });
-      int32_t me = (int32_t)(nodes.size() / 4);
-      nodes.resize(nodes.size() + 4);
-      Rec L = build(first, mid - first), R = build(mid, first + count - mid);
-      nodes[4ull * me + 0] = mkq(L.lo[0], L.lo[1], L.lo[2], L.hi[0]);
-      nodes[4ull * me + 1] = mkq(L.hi[1], L.hi[2], R.lo[0], R.lo[1]);
-      nodes[4ull * me + 2] = mkq(R.lo[2], R.hi[0], R.hi[1], R.hi[2]);
-      nodes[4ull * me + 3] = mkq(u2f((uint32_t)L.code), u2f((uint32_t)R.code), 0, 0);
-      r.code = me;
-      for (int c = 0; c < 3; ++c) {
-        r.lo[c] = std::min(L.lo[c], R.lo[c]);
-        r.hi[c] = std::max(L.hi[c], R.hi[c]);
+      return mid - first;
+    };
+    std::function<Rec(uint32_t, uint32_t)> build = [&](uint32_t first, uint32_t count) -> Rec {
+      Rec r;
+      if (count <= 2) {
+        uint32_t slot = (uint32_t)slots.size();
+        for (int c = 0; c < 3; ++c) {
+          r.lo[c] = 3e38f;
+          r.hi[c] = -3e38f;
+        }
+        for (uint32_t i = first; i < first + count; ++i) {
+          slots.push_back(order[i]);
+          for (int c = 0; c < 3; ++c) {
+            r.lo[c] = std::min(r.lo[c], glo[3ull * order[i] + c]);
+            r.hi[c] = std::max(r.hi[c], ghi[3ull * order[i] + c]);
+          }
+        }
+        r.code = make_leaf(slot, count);
+        return r;
       }
+      // up to four ranges: halves of halves
+      uint32_t rf[4], rc[4];
+      int nr = 0;
+      const uint32_t l = split(first, count);
+      const uint32_t halves[2][2] = {{first, l}, {first + l, count - l}};
+      for (int hh = 0; hh < 2; ++hh) {
+        if (halves[hh][1] >= 3) {
+          const uint32_t ll = split(halves[hh][0], halves[hh][1]);
+          rf[nr] = halves[hh][0]; rc[nr++] = ll;
+          rf[nr] = halves[hh][0] + ll; rc[nr++] = halves[hh][1] - ll;
+        } else {
+          rf[nr] = halves[hh][0]; rc[nr++] = halves[hh][1];
+        }
+      }
+      const int32_t me = (int32_t)(nodes.size() / 4);
+      nodes.resize(nodes.size() + 4);
+      Entry4 e[4];
+      for (int c = 0; c < 3; ++c) {
+        r.lo[c] = 3e38f;
+        r.hi[c] = -3e38f;
+      }
+      for (int k = 0; k < nr; ++k) {
+        const Rec ch = build(rf[k], rc[k]);
+        e[k].lo = mkq(ch.lo[0], ch.lo[1], ch.lo[2], 0);
+        e[k].hi = mkq(ch.hi[0], ch.hi[1], ch.hi[2], 0);
+        e[k].code = ch.code;
+        for (int c = 0; c < 3; ++c) {
+          r.lo[c] = std::min(r.lo[c], ch.lo[c]);
+          r.hi[c] = std::max(r.hi[c], ch.hi[c]);
+        }
+      }
+      encode_node4(&nodes[4ull * me], e, nr, n);  // unused slots lead to the degenerate triangle in slot n
+      r.code = me * 64;                             // inner child = byte offset of its node
       return r;
     };
     if (n == 0) {
@@ -159,9 +182,9 @@ struct Emu {
     } else {
       Rec r = build(0, n);
       root = r.code;
-      isect.resize(3ull * n);
-      shade.resize(4ull * n);
-      slot_to_global.resize(n);
+      isect.assign(3ull * (n + 1), mkq(0, 0, 0, 0));  // slot n: the all-zero triangle (det == 0: never hit)
+      shade.assign(4ull * (n + 1), mkq(0, 0, 0, 0));
+      slot_to_global.assign(n + 1, 0);
       for (uint32_t s = 0; s < n; ++s) {
         uint32_t gg = slots[s];
         slot_to_global[s] = gg;
@@ -249,18 +272,16 @@ int emu_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixel_i
       q4 result = mkq(0, 0, 0, 0);
       bool alive = true;
       while (alive) {
-        VecStack stk;
         HitRec hit;
-        TraceCounters cnt{0, 0};
-        traverse<false, false>(S.nodes, S.tri_isect, S.root, p.o, p.d, 0.0f, 1e10f, stk, hit, cnt);
+        uint32_t aux;
+        trace_ray4<false>(S.nodes, S.tri_isect, S.root, p.o, p.d, 0.0f, 1e10f, hit, aux);
         if (hit.slot < 0 || e->sc.num_vertices == 0) break;  // miss
         ShadeOut out;
         shade_vertex(S, rc, p, hit, out);
         if (out.has_shadow) {
-          VecStack st2;
           HitRec sh;
-          bool occ = traverse<true, false>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f,
-                                           out.shadow.tmax, st2, sh, cnt);
+          uint32_t aux2;
+          bool occ = trace_ray4<true>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, sh, aux2);
           bool nee_done;
           connect_vertex(rc.clamp, out.shadow, occ, result, nee_done);
           if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;
@@ -291,16 +312,13 @@ int emu_trace(void* h, const float* rays, uint64_t n, int any_hit, void* hits_ou
   const bool empty = e->sc.num_vertices == 0;
   for (uint64_t i = 0; i < n; ++i) {
     const float* r = rays + 8 * i;
-    VecStack stk;
     HitRec hh;
-    TraceCounters cnt{0, 0};
+    uint32_t aux;
     bool hit;
     if (any_hit)
-      hit = traverse<true, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7],
-                                  stk, hh, cnt);
+      hit = trace_ray4<true>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], hh, aux);
     else
-      hit = traverse<false, false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3],
-                                   r[7], stk, hh, cnt);
+      hit = trace_ray4<false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], hh, aux);
     if (empty) hit = false;
     if (any_hit) out[i] = HR{0, 0, 0, hit ? 0 : -1};
     else out[i] = hit ? HR{hh.t, hh.u, hh.v, (int32_t)e->slot_to_global[hh.slot]} : HR{0, 0, 0, -1};
