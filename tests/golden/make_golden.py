@@ -3,10 +3,10 @@
 
 The reference has no tests, golden vectors or runnable build, so
 these fixtures are produced by this repository's CPU oracle and frozen here as
-regression pins; `tungsten_cornell_128.npy` is the one fixture that comes from the
-reference tree itself (a third-party ground-truth render the author shipped).
+regression pins; the fixtures that come from the reference tree itself (third-party
+ground-truth renders the author shipped) are made by tests/golden/make_tungsten.py.
 
-  python tests/golden/make_golden.py            # needs /root/reference only for the Tungsten image
+  python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -69,15 +69,7 @@ def main():
     # full-material render (config 2 at test size)
     img2, _ = om.render(64, 64, spp=4)
     np.save(os.path.join(HERE, "materials_64_4spp.npy"), img2[:, :3].reshape(64, 64, 3).astype(np.float32))
-    # the reference tree's only image fixture: Tungsten ground truth of the classic Cornell box
-    png = "/root/reference/src/GPUSpectral/assets/scenes/cornell-box/TungstenRender.png"
-    if os.path.exists(png):
-        from PIL import Image
-
-        im = np.asarray(Image.open(png).convert("RGB"), np.float64) / 255.0
-        lin = im ** 2.2  # ldrfilm gamma 2.2 (scene.xml:21)
-        lin = lin.reshape(128, 8, 128, 8, 3).mean(axis=(1, 3))
-        np.save(os.path.join(HERE, "tungsten_cornell_128.npy"), lin.astype(np.float32))
+    # (the reference-held Tungsten images are linearised by tests/golden/make_tungsten.py)
     print("golden fixtures written to", HERE)
 
 

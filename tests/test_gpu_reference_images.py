@@ -1,0 +1,125 @@
+"""The HIP path against the only expected OUTPUTS the reference tree holds: the third-party Tungsten ground-truth
+renders shipped beside its scenes (tests/golden/ref_scenes/tungsten_*.npz, linearised by tests/golden/make_tungsten.py).
+
+This is independent of the CPU oracle: nothing under oracle/ is used here.  It cannot be a bit-parity test -- Tungsten
+is an unbiased path tracer with a tent pixel filter, the reference integrator has its documented MIS quirks and a
+firefly clamp, and the PNGs are 8-bit tone-mapped -- so every check states the band it allows and where
+the numbers it was chosen from are (profiles/r02_tungsten_*.txt, measured at 1024 spp).
+
+Frames are rendered at the scene's own film size, then box-filtered 8x8 like the fixtures and compared on cells of
+16x16 such blocks (128x128 pixels); a cell takes part per channel when at least a quarter of its blocks are
+recoverable from the PNG (not clipped, not in the tone map's toe) and brighter than 0.02.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CORNELL_XML, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+REF = os.path.join(GOLDEN, "ref_scenes")
+SPP = 1024
+CELL = 16
+
+
+def _render(sc, W, H, spp=SPP):
+    import gpuspectral_amd as g
+
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        img = ctx.download()
+    assert np.isfinite(img).all()
+    return img[..., :3].astype(np.float64).reshape(H // 8, 8, W // 8, 8, 3).mean(axis=(1, 3))
+
+
+def _cells(ours, fix):
+    """Per-cell, per-channel ratio ours / Tungsten over the recoverable blocks (NaN where too few)."""
+    t = fix["lin"].astype(np.float64)
+    ok = ~fix["sat"] & (t > 0.02)
+    h, w = t.shape[:2]
+    hc, wc = h // CELL, w // CELL
+    cut = (slice(0, hc * CELL), slice(0, wc * CELL))
+    shp = (hc, CELL, wc, CELL, 3)
+    ts = np.where(ok, t, 0.0)[cut].reshape(shp).sum(axis=(1, 3))
+    os_ = np.where(ok, ours, 0.0)[cut].reshape(shp).sum(axis=(1, 3))
+    n = ok[cut].reshape(shp).sum(axis=(1, 3))
+    return np.where(n >= CELL * CELL // 4, os_ / np.maximum(ts, 1e-12), np.nan), ok
+
+
+def test_cornell_box_against_tungsten():
+    """Diffuse-only scene, square film, level camera: every recoverable cell of the image takes part.
+    Measured (1024 spp): 146 cell-channels, ratio 1.011 .. 1.299, median 1.031; the lit walls (rows 1-2) 1.011 .. 1.028.
+    The excess over 1 is the reference integrator's own bias (NEE weighted with the pdf of the *sampled* direction,
+    rayhit.rchit:751; largest on the tall box and in its shadow, 1.09 .. 1.30) and is reproduced, not corrected.
+    Excluded by the fixture's mask: the light source (clipped in the PNG) and the near-black short box front."""
+    from gpuspectral_amd import host
+
+    sc = host.Scene(CORNELL_XML, os.path.dirname(os.path.dirname(CORNELL_XML))).arrays()
+    ours = _render(sc, 1024, 1024)
+    fix = np.load(os.path.join(REF, "tungsten_cornell-box.npz"))
+    r, _ = _cells(ours, fix)
+    valid = np.isfinite(r)
+    assert valid.sum() >= 140
+    assert 0.98 < np.nanmin(r) and np.nanmax(r) < 1.35, (np.nanmin(r), np.nanmax(r))
+    assert 1.00 < np.nanmedian(r) < 1.06, np.nanmedian(r)
+    walls = r[1:3, 1:7]  # back wall + side walls at mid height: direct light dominates
+    assert np.isfinite(walls).sum() >= 30
+    assert 0.995 < np.nanmin(walls) and np.nanmax(walls) < 1.04, (np.nanmin(walls), np.nanmax(walls))
+    # hue of the walls: red left, green right (absolute radiance, both images)
+    t = fix["lin"]
+    for img in (ours, t):
+        assert img[64, 4, 0] > 5 * img[64, 4, 1] and img[64, 123, 1] > 2 * img[64, 123, 0]
+
+
+def test_staircase2_against_tungsten():
+    """'Modern Hall' (30 927 triangles, 16 emitters, <ref>/twosided/roughplastic materials).  Its floor and stair treads
+    are *textured* in Tungsten; the reference never sets hasTexture (rayhit.rchit:716,729; Loader.cpp:122-143 is dead
+    code), so they render with the default colour and everything lit through them (the left corridor, the lower half
+    of the frame) is expected to differ and is excluded.  Compared: the plain right-hand wall, rows 0-3 x columns 4-7
+    of the cell grid.  Measured (1024 spp): ratio 0.88 .. 1.40, median 1.13 (the missing floor bounce and the clamp
+    move light around), wall chromaticity (0.45, 0.36, 0.19) vs Tungsten's (0.46, 0.35, 0.18)."""
+    from gpuspectral_amd import abi
+
+    sc = abi.SceneArrays.load(os.path.join(REF, "staircase2.npz"))
+    ours = _render(sc, 1024, 1024)
+    fix = np.load(os.path.join(REF, "tungsten_staircase2.npz"))
+    r, ok = _cells(ours, fix)
+    wall = r[0:4, 4:8]
+    assert np.isfinite(wall).all()
+    assert 0.75 < wall.min() and wall.max() < 1.55, (wall.min(), wall.max())
+    assert 1.0 < np.median(wall) < 1.25, np.median(wall)
+    t = fix["lin"].astype(np.float64)
+    region = (slice(0, 64), slice(64, 128))
+    ct = np.where(ok, t, 0.0)[region].sum(axis=(0, 1))
+    co = np.where(ok, ours, 0.0)[region].sum(axis=(0, 1))
+    assert np.abs(ct / ct.sum() - co / co.sum()).max() < 0.03
+
+
+def test_coffee_against_tungsten():
+    """'Coffee Maker' (168 199 triangles; smooth/rough plastic, dielectric glass, rough conductor).  The camera is pitched
+    and the reference flips the ray's *world-space* y (raygen.rgen:25: d = toWorld * d; d.y *= -1), which displaces
+    the image vertically against Tungsten's (measured: ~14 of 125 block rows), and the film is portrait while the
+    reference scales by max(W, H) (raygen.rgen:22).  So positions do not line up and the comparison is by material,
+    not by place: mean radiance of the orange plastic body (mask: r > 2 b + 0.05, 0.15 < r < 0.95) and of the grey
+    backdrop beside it.  Measured (1024 spp): body (0.640, 0.137, 0.031) vs Tungsten (0.620, 0.150, 0.039); backdrop
+    0.045 / 0.034 vs 0.056 / 0.041 (left / right edge, mid height)."""
+    from gpuspectral_amd import abi
+
+    sc = abi.SceneArrays.load(os.path.join(REF, "coffee.npz"))
+    ours = _render(sc, 800, 1000)
+    t = np.load(os.path.join(REF, "tungsten_coffee.npz"))["lin"].astype(np.float64)
+
+    def body(a):
+        m = (a[..., 0] > 2.0 * a[..., 2] + 0.05) & (a[..., 0] > 0.15) & (a[..., 0] < 0.95)
+        assert m.sum() > 800
+        return a[m].mean(axis=0)
+
+    bo, bt = body(ours), body(t)
+    assert 0.9 < bo[0] / bt[0] < 1.15 and 0.75 < bo[1] / bt[1] < 1.15 and 0.6 < bo[2] / bt[2] < 1.2, (bo, bt)
+    for cols in (slice(2, 8), slice(92, 98)):
+        ro = ours[60:70, cols].mean() / t[60:70, cols].mean()
+        assert 0.65 < ro < 1.1, ro

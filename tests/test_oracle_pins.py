@@ -140,15 +140,24 @@ def test_golden_materials_image(oracle_mod, materials_scene):
     assert np.array_equal(img[:, :3], gold)
 
 
-def test_tungsten_ground_truth_coarse(oracle_mod, cornell):
-    """The only image fixture in the reference tree (cornell-box/TungstenRender.png, a third-party
-    ground truth of the classic Cornell box).  The reference integrator is biased (MIS quirks,
-    firefly clamp: SURVEY 8a13), so this is a coarse sanity bound, not a parity pin."""
-    t = np.load(os.path.join(GOLDEN, "tungsten_cornell_128.npy")).astype(np.float64)
+def test_tungsten_ground_truth(oracle_mod, cornell):
+    """The reference-held image fixture for the Cornell box (cornell-box/TungstenRender.png, a third-party ground truth
+    linearised by tests/golden/make_tungsten.py) against the CPU oracle, cell by cell like the GPU test
+    (tests/test_gpu_reference_images.py, which renders 1024 x 1024 x 1024 spp).  Here 128 x 128 x 64 spp (one ray
+    direction per pixel, no filter: the cells carry ~3 % of noise and aliasing).  Measured: 146 cell-channels, ratio
+    0.947 .. 1.323, median 1.029; lit walls 0.964 .. 1.033.  The reference integrator is biased (MIS quirks, firefly
+    clamp: SURVEY 8a13), so this pins the oracle to ~5 %, not to the bit."""
+    from test_gpu_reference_images import REF, _cells
+
+    fix = np.load(os.path.join(REF, "tungsten_cornell-box.npz"))
     img, _ = oracle_mod.Oracle(cornell).render(128, 128, spp=64)
-    ours = np.clip(img[:, :3].reshape(128, 128, 3).astype(np.float64), 0, 1)
-    assert 0.8 < ours.mean() / t.mean() < 1.2
-    assert np.corrcoef(ours.ravel(), t.ravel())[0, 1] > 0.75
+    ours = img[:, :3].reshape(128, 128, 3).astype(np.float64)
+    r, _ = _cells(ours, fix)
+    assert np.isfinite(r).sum() >= 140
+    assert 0.90 < np.nanmin(r) and np.nanmax(r) < 1.40, (np.nanmin(r), np.nanmax(r))
+    assert 0.99 < np.nanmedian(r) < 1.07
+    walls = r[1:3, 1:7]
+    assert 0.93 < np.nanmin(walls) and np.nanmax(walls) < 1.07
     # red wall left, green wall right
     assert ours[64, 4, 0] > 3 * ours[64, 4, 1] and ours[64, 123, 1] > 2 * ours[64, 123, 0]
 
