@@ -111,8 +111,26 @@ def cpu_baseline(sc, args, scene_name):
     }
 
 
+def _launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has
+    not touched the GPU and never replaces itself) and return its exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching\n  %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -127,8 +145,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE %d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     import gpuspectral_amd as g
     from gpuspectral_amd import multigpu, scenes  # noqa: F401

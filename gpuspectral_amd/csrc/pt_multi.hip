@@ -1,0 +1,316 @@
+// pt_multi.hip -- one frame over several GPUs of one node, behind the C ABI (gsp_multi_*, include/gpuspectral_pt.h).
+//
+// SURVEY 8(e) / BASELINE north_star: pixels are independent (the seed is a function of the global pixel index and the
+// timestamp only, raygen.rgen:37; no pixel filter), so the frame is partitioned by interleaved 32x32 tiles, the scene
+// and its BVH are replicated on every GPU, every GPU renders all samples of its own tiles with the single-GPU
+// pipeline (pt_render.hip), and the ONLY exchange is one gather of the HDR tiles into GPU 0 at read-back: each
+// share's compact RGBA32F buffer is copied device-to-device into a staging buffer on GPU 0 (peer access over
+// xGMI), a scatter kernel there places the tiles in the frame, and one copy brings the frame to the host.
+//
+// A C++ caller (the reference's host is C++: S/main.cpp:15-30, S/renderer/Renderer.h:22-25,44) gets N GPUs through
+// this file without Python or torch; bench.py's one-process-per-GPU path (torch.distributed, RCCL gather) uses the
+// same tile partition (gsp_tile_partition) and the same per-GPU pipeline.
+//
+// Host threading: gsp_render drives its pipeline from the calling thread until every sample is injected, so each
+// share's context gets its own host thread for the duration of a call (one std::thread per share per call; the
+// calls last milliseconds to minutes).  The same device may appear more than once in `devices` (several shares on
+// one GPU): that is how the single-GPU test box exercises partition + gather + scatter.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pt_internal.h"
+
+namespace gsp {
+namespace {
+
+// frame[ids[i]] = compact[i]: the tiles of one share into the full frame (16-B records, coalesced reads; writes are
+// runs of 32 pixels = 512 B)
+__global__ __launch_bounds__(256) void k_scatter_tiles(const q4* __restrict__ compact, const uint32_t* __restrict__ ids,
+                                                       uint64_t n, q4* __restrict__ frame) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) frame[ids[i]] = compact[i];
+}
+
+}  // namespace
+}  // namespace gsp
+
+using namespace gsp;
+
+struct gsp_multi {
+  std::vector<int> devices;
+  std::vector<gsp_context*> ctx;
+  std::vector<std::vector<uint32_t>> ids;  // per share: owned pixels, increasing
+  std::vector<uint64_t> offset;            // per share: first record in the staging buffer
+  uint32_t width = 0, height = 0, tile = 32;
+  bool have_frame = false;
+  // on devices[0]
+  hipStream_t stream = nullptr;
+  q4* staging = nullptr;     // all shares' compact buffers back to back
+  q4* frame = nullptr;       // width * height
+  uint32_t* d_ids = nullptr; // all shares' pixel ids back to back
+  size_t frame_pixels = 0;
+  std::string err;
+};
+
+namespace {
+
+std::string g_multi_create_error;
+
+// Runs fn(share) on one host thread per share and returns the first failing status (GSP_OK if none).
+template <class F>
+int for_each_share(gsp_multi* m, F fn) {
+  const size_t n = m->ctx.size();
+  std::vector<int> rc(n, GSP_OK);
+  if (n == 1) {
+    rc[0] = fn(0);
+  } else {
+    std::vector<std::thread> th;
+    th.reserve(n);
+    for (size_t r = 0; r < n; ++r) th.emplace_back([&, r] { rc[r] = fn(r); });
+    for (auto& t : th) t.join();
+  }
+  for (size_t r = 0; r < n; ++r)
+    if (rc[r] != GSP_OK) {
+      m->err = "share " + std::to_string(r) + " (device " + std::to_string(m->devices[r]) + "): " + gsp_last_error(m->ctx[r]);
+      return rc[r];
+    }
+  return GSP_OK;
+}
+
+#define MULTI_TRY(m, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      (m)->err = std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"; \
+      return e_ == hipErrorOutOfMemory ? GSP_ERR_NOMEM : GSP_ERR_DEVICE;                        \
+    }                                                                                           \
+  } while (0)
+
+void free_frame(gsp_multi* m) {
+  if (m->devices.empty()) return;
+  (void)hipSetDevice(m->devices[0]);
+  if (m->staging) (void)hipFree(m->staging);
+  if (m->frame) (void)hipFree(m->frame);
+  if (m->d_ids) (void)hipFree(m->d_ids);
+  m->staging = m->frame = nullptr;
+  m->d_ids = nullptr;
+  m->have_frame = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Tile (tx, ty) of a frame cut into tile x tile blocks belongs to share (ty * tiles_x + tx + ty) % world: round-robin
+// along a row, staggered by one from row to row so that the shares interleave in both axes (load balance).
+uint64_t gsp_tile_partition(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t tile, uint32_t* out_ids) {
+  if (world == 0 || tile == 0 || rank >= world) return 0;
+  const uint32_t tiles_x = (width + tile - 1) / tile;
+  uint64_t n = 0;
+  for (uint32_t y = 0; y < height; ++y) {
+    const uint32_t ty = y / tile;
+    for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+      if (((uint64_t)ty * tiles_x + tx + ty) % world != rank) continue;
+      const uint32_t x0 = tx * tile, x1 = std::min(width, x0 + tile);
+      if (out_ids)
+        for (uint32_t x = x0; x < x1; ++x) out_ids[n + (x - x0)] = y * width + x;
+      n += x1 - x0;
+    }
+  }
+  return n;
+}
+
+const char* gsp_multi_last_error(const gsp_multi* m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+
+void gsp_multi_destroy(gsp_multi* m) {
+  if (!m) return;
+  for (gsp_context* c : m->ctx) gsp_ctx_destroy(c);
+  free_frame(m);
+  if (m->stream) {
+    (void)hipSetDevice(m->devices[0]);
+    (void)hipStreamDestroy(m->stream);
+  }
+  delete m;
+}
+
+int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
+  if (!out) return GSP_ERR_INVALID;
+  *out = nullptr;
+  if (!devices || n <= 0 || n > 64) {
+    g_multi_create_error = "gsp_multi_create: need 1..64 devices";
+    return GSP_ERR_INVALID;
+  }
+  gsp_multi* m = new gsp_multi();
+  m->devices.assign(devices, devices + n);
+  for (int r = 0; r < n; ++r) {
+    gsp_context* c = nullptr;
+    int rc = gsp_ctx_create(devices[r], &c);
+    if (rc != GSP_OK) {
+      g_multi_create_error = std::string("share ") + std::to_string(r) + ": " + gsp_last_error(nullptr);
+      gsp_multi_destroy(m);
+      return rc;
+    }
+    m->ctx.push_back(c);
+  }
+  // peer access towards the gathering device (xGMI); a share on the gathering device itself needs none
+  for (int r = 1; r < n; ++r) {
+    if (devices[r] == devices[0]) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) == hipSuccess && can) {
+      (void)hipSetDevice(devices[r]);
+      hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // copies fall back to staging through the host
+      else (void)hipGetLastError();
+    }
+  }
+  hipError_t e = hipSetDevice(devices[0]);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    g_multi_create_error = std::string("gsp_multi_create: ") + hipGetErrorString(e);
+    gsp_multi_destroy(m);
+    return GSP_ERR_DEVICE;
+  }
+  *out = m;
+  return GSP_OK;
+}
+
+int gsp_multi_num_shares(const gsp_multi* m) { return m ? (int)m->ctx.size() : 0; }
+
+int gsp_multi_upload_scene(gsp_multi* m, const gsp_scene_desc* scene) {
+  if (!m || !scene) return GSP_ERR_INVALID;
+  return for_each_share(m, [&](size_t r) { return gsp_upload_scene(m->ctx[r], scene); });
+}
+
+int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height) {
+  if (!m || width == 0 || height == 0) return GSP_ERR_INVALID;
+  const uint32_t world = (uint32_t)m->ctx.size();
+  free_frame(m);
+  m->width = width;
+  m->height = height;
+  m->ids.assign(world, {});
+  m->offset.assign(world, 0);
+  uint64_t total = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    const uint64_t cnt = gsp_tile_partition(width, height, r, world, m->tile, nullptr);
+    m->ids[r].resize(cnt);
+    gsp_tile_partition(width, height, r, world, m->tile, m->ids[r].data());
+    m->offset[r] = total;
+    total += cnt;
+  }
+  m->frame_pixels = (size_t)width * height;
+  if (total != m->frame_pixels) {
+    m->err = "internal error: tile partition does not cover the frame";
+    return GSP_ERR_INVALID;
+  }
+  if (world > 1) {
+    MULTI_TRY(m, hipSetDevice(m->devices[0]));
+    MULTI_TRY(m, hipMalloc((void**)&m->staging, total * sizeof(q4)));
+    MULTI_TRY(m, hipMalloc((void**)&m->frame, total * sizeof(q4)));
+    MULTI_TRY(m, hipMalloc((void**)&m->d_ids, total * sizeof(uint32_t)));
+    for (uint32_t r = 0; r < world; ++r)
+      MULTI_TRY(m, hipMemcpyAsync(m->d_ids + m->offset[r], m->ids[r].data(), m->ids[r].size() * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, m->stream));
+    MULTI_TRY(m, hipStreamSynchronize(m->stream));
+  }
+  int rc = for_each_share(m, [&](size_t r) {
+    // a single share owns the whole frame: no subset, no gather
+    return world == 1 ? gsp_frame_begin(m->ctx[r], width, height, nullptr, 0)
+                      : gsp_frame_begin(m->ctx[r], width, height, m->ids[r].data(), m->ids[r].size());
+  });
+  m->have_frame = rc == GSP_OK;
+  return rc;
+}
+
+int gsp_multi_render(gsp_multi* m, const gsp_render_params* params) {
+  if (!m || !params) return GSP_ERR_INVALID;
+  return for_each_share(m, [&](size_t r) { return gsp_render(m->ctx[r], params); });
+}
+
+int gsp_multi_sync(gsp_multi* m) {
+  if (!m) return GSP_ERR_INVALID;
+  return for_each_share(m, [&](size_t r) { return gsp_sync(m->ctx[r]); });
+}
+
+// Completes all queued samples, gathers the HDR tiles into devices[0] and leaves the assembled frame there;
+// *device_frame (optional) receives the device pointer (width*height RGBA32F on devices[0], valid until the next
+// gsp_multi_frame_begin / destroy).
+int gsp_multi_gather(gsp_multi* m, void** device_frame) {
+  if (!m || !m->have_frame) return GSP_ERR_INVALID;
+  const uint32_t world = (uint32_t)m->ctx.size();
+  if (world == 1) {
+    if (device_frame) *device_frame = nullptr;  // (single share: the frame lives in the context's accumulate buffer)
+    return gsp_sync(m->ctx[0]);
+  }
+  // the one exchange of the job: every share copies its compact buffer into the staging buffer on devices[0]
+  int rc = for_each_share(m, [&](size_t r) {
+    return gsp_copy_accum_to_device(m->ctx[r], m->staging + m->offset[r], m->ids[r].size() * sizeof(q4));
+  });
+  if (rc != GSP_OK) return rc;
+  MULTI_TRY(m, hipSetDevice(m->devices[0]));
+  const uint64_t total = m->frame_pixels;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(k_scatter_tiles, dim3(grid), dim3(256), 0, m->stream, m->staging, m->d_ids, total, m->frame);
+  MULTI_TRY(m, hipGetLastError());
+  MULTI_TRY(m, hipStreamSynchronize(m->stream));
+  if (device_frame) *device_frame = m->frame;
+  return GSP_OK;
+}
+
+int gsp_multi_download(gsp_multi* m, float* out_rgba) {
+  if (!m || !out_rgba || !m->have_frame) return GSP_ERR_INVALID;
+  if (m->ctx.size() == 1) {
+    int rc = gsp_download(m->ctx[0], out_rgba);
+    if (rc != GSP_OK) m->err = gsp_last_error(m->ctx[0]);
+    return rc;
+  }
+  int rc = gsp_multi_gather(m, nullptr);
+  if (rc != GSP_OK) return rc;
+  MULTI_TRY(m, hipSetDevice(m->devices[0]));
+  MULTI_TRY(m, hipMemcpyAsync(out_rgba, m->frame, m->frame_pixels * sizeof(q4), hipMemcpyDeviceToHost, m->stream));
+  MULTI_TRY(m, hipStreamSynchronize(m->stream));
+  return GSP_OK;
+}
+
+// total (optional): counters summed over the shares, times = the slowest share's (they run concurrently);
+// per_share (optional): gsp_multi_num_shares() records.
+int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
+  if (!m) return GSP_ERR_INVALID;
+  std::vector<gsp_stats> st(m->ctx.size());
+  int rc = for_each_share(m, [&](size_t r) { return gsp_get_stats(m->ctx[r], &st[r]); });
+  if (rc != GSP_OK) return rc;
+  if (per_share) std::memcpy(per_share, st.data(), st.size() * sizeof(gsp_stats));
+  if (total) {
+    gsp_stats t = st[0];
+    for (size_t r = 1; r < st.size(); ++r) {
+      const gsp_stats& s = st[r];
+      t.extension_rays += s.extension_rays;
+      t.shadow_rays += s.shadow_rays;
+      t.shaded_vertices += s.shaded_vertices;
+      t.samples += s.samples;
+      t.nodes_visited += s.nodes_visited;
+      t.tris_tested += s.tris_tested;
+      t.stat_rays += s.stat_rays;
+      t.shadow_nodes_visited += s.shadow_nodes_visited;
+      t.shadow_tris_tested += s.shadow_tris_tested;
+      t.shadow_stat_rays += s.shadow_stat_rays;
+      t.extend_launches += s.extend_launches;
+      t.device_bytes += s.device_bytes;
+      t.render_seconds = std::max(t.render_seconds, s.render_seconds);
+      t.extend_kernel_ms = std::max(t.extend_kernel_ms, s.extend_kernel_ms);
+      t.shade_kernel_ms = std::max(t.shade_kernel_ms, s.shade_kernel_ms);
+      t.connect_kernel_ms = std::max(t.connect_kernel_ms, s.connect_kernel_ms);
+      t.bvh_build_ms = std::max(t.bvh_build_ms, s.bvh_build_ms);
+    }
+    *total = t;
+  }
+  return GSP_OK;
+}
+
+int gsp_multi_reset_stats(gsp_multi* m) {
+  if (!m) return GSP_ERR_INVALID;
+  return for_each_share(m, [&](size_t r) { return gsp_reset_stats(m->ctx[r]); });
+}
+
+}  // extern "C"

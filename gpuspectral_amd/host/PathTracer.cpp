@@ -75,6 +75,59 @@ gsp_stats PathTracer::stats() {
   return s;
 }
 
+// ---- several GPUs ---------------------------------------------------------------------------------------------
+MultiGpuPathTracer::MultiGpuPathTracer(uint32_t width, uint32_t height, const std::vector<int>& devices)
+    : width(width), height(height), devices(devices) {
+  gsp_default_render_params(&params);
+  int rc = gsp_multi_create(devices.data(), (int)devices.size(), &multi);
+  if (rc != GSP_OK) throw std::runtime_error(std::string("gsp_multi_create: ") + gsp_multi_last_error(nullptr));
+  check(gsp_multi_frame_begin(multi, width, height), "gsp_multi_frame_begin");
+}
+
+MultiGpuPathTracer::~MultiGpuPathTracer() { gsp_multi_destroy(multi); }
+
+void MultiGpuPathTracer::check(int rc, const char* what) {
+  if (rc != GSP_OK) throw std::runtime_error(std::string(what) + ": " + gsp_multi_last_error(multi));
+}
+
+void MultiGpuPathTracer::reset() {
+  timestamp = 0;
+  check(gsp_multi_frame_begin(multi, width, height), "gsp_multi_frame_begin");
+}
+
+void MultiGpuPathTracer::prepareScene(const Scene& scene) {
+  if (uploaded == &scene && uploadedObjects == scene.renderObjects.size()) return;
+  FlatScene flat;
+  flattenScene(scene, flat);
+  check(gsp_multi_upload_scene(multi, &flat.desc), "gsp_multi_upload_scene");
+  uploaded = &scene;
+  uploadedObjects = scene.renderObjects.size();
+}
+
+void MultiGpuPathTracer::render(const Scene& scene, uint32_t spp) {
+  prepareScene(scene);
+  gsp_render_params p = params;
+  p.spp = spp;
+  p.first_timestamp = (uint32_t)timestamp;
+  check(gsp_multi_render(multi, &p), "gsp_multi_render");
+  timestamp += (int)spp;
+}
+
+void MultiGpuPathTracer::createRenderPass(const Scene& scene) { render(scene, 1); }
+
+std::vector<float> MultiGpuPathTracer::download() {
+  std::vector<float> out((size_t)width * height * 4);
+  check(gsp_multi_download(multi, out.data()), "gsp_multi_download");
+  return out;
+}
+
+gsp_stats MultiGpuPathTracer::stats(std::vector<gsp_stats>* perShare) {
+  gsp_stats s;
+  if (perShare) perShare->resize(devices.size());
+  check(gsp_multi_get_stats(multi, &s, perShare ? perShare->data() : nullptr), "gsp_multi_get_stats");
+  return s;
+}
+
 void writePfm(const std::string& path, const float* rgba, uint32_t width, uint32_t height) {
   FILE* f = std::fopen(path.c_str(), "wb");
   if (!f) throw std::runtime_error("cannot write " + path);

@@ -62,6 +62,38 @@ class PathTracer : public RenderPassCreator {
   int timestamp{0};
 };
 
+// The same pass over several GPUs of one node: the frame is cut into interleaved 32x32 tiles (one share per entry of
+// `devices`; an index may repeat), the scene is replicated, every GPU renders all samples of its tiles and download()
+// gathers the HDR tiles into the first GPU (device-to-device over xGMI) before the one copy to the host
+// (gsp_multi_*, include/gpuspectral_pt.h).  Same two-phase shape and the same image, bit for bit, as
+// PathTracer on one GPU.
+class MultiGpuPathTracer : public RenderPassCreator {
+ public:
+  MultiGpuPathTracer(uint32_t width, uint32_t height, const std::vector<int>& devices);
+  ~MultiGpuPathTracer() override;
+  MultiGpuPathTracer(const MultiGpuPathTracer&) = delete;
+  MultiGpuPathTracer& operator=(const MultiGpuPathTracer&) = delete;
+
+  void createRenderPass(const Scene& scene) override;  // +1 spp on every GPU's share
+  void render(const Scene& scene, uint32_t spp);
+  void prepareScene(const Scene& scene);
+  std::vector<float> download();  // RGBA32F, row-major, width*height*4 floats
+  void reset();
+  int getTimestamp() const { return timestamp; }
+  int numShares() const { return (int)devices.size(); }
+  gsp_stats stats(std::vector<gsp_stats>* perShare = nullptr);  // totals over the shares
+  gsp_render_params params;
+
+ private:
+  void check(int rc, const char* what);
+  gsp_multi* multi = nullptr;
+  uint32_t width, height;
+  std::vector<int> devices;
+  const Scene* uploaded = nullptr;
+  size_t uploadedObjects = 0;
+  int timestamp{0};
+};
+
 // Headless output step: little-endian PFM ("PF", bottom-to-top rows) of the RGB channels.
 void writePfm(const std::string& path, const float* rgba, uint32_t width, uint32_t height);
 

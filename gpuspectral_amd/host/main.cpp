@@ -1,12 +1,14 @@
 // main.cpp -- headless counterpart of the reference's S/main.cpp:15-30:
 //   Engine + PathTracer + loadScene + Window::run(frame loop)
 // becomes: load the Mitsuba XML, render N samples per pixel, write the HDR framebuffer.
-//   gsp_render <scene.xml> <out.pfm> [width height spp [device]]
+//   gsp_render <scene.xml> <out.pfm> [width height spp [devices]]     devices: "0" (default) or a list "0,1,2,3":
+//   the frame is then tiled over those GPUs (MultiGpuPathTracer); an index may repeat
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "Loader.h"
 #include "PathTracer.h"
@@ -15,22 +17,41 @@ using namespace GPUSpectral;
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s scene.xml out.pfm [width height spp [device]]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s scene.xml out.pfm [width height spp [device | d0,d1,...]]\n", argv[0]);
     return 2;
   }
   const uint32_t width = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 500;  // S/main.cpp:17: 500x500 window
   const uint32_t height = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 500;
   const uint32_t spp = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 64;
-  const int device = argc > 6 ? std::atoi(argv[6]) : 0;
+  std::vector<int> devices;
+  for (const char* p = argc > 6 ? argv[6] : "0"; *p;) {
+    char* e;
+    devices.push_back((int)std::strtol(p, &e, 10));
+    p = (*e == ',') ? e + 1 : e;
+    if (e == p && *p) break;
+  }
   try {
     Scene scene = loadScene(argv[1]);
     for (auto& w : scene.warnings) std::fprintf(stderr, "WARN: %s\n", w.c_str());
-    PathTracer pt(width, height, device);
-    auto t0 = std::chrono::steady_clock::now();
-    pt.render(scene, spp);
-    auto img = pt.download();
-    double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    gsp_stats st = pt.stats();
+    std::vector<float> img;
+    gsp_stats st;
+    double s;
+    if (devices.size() == 1) {
+      PathTracer pt(width, height, devices[0]);
+      auto t0 = std::chrono::steady_clock::now();
+      pt.render(scene, spp);
+      img = pt.download();
+      s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      st = pt.stats();
+    } else {
+      MultiGpuPathTracer pt(width, height, devices);
+      auto t0 = std::chrono::steady_clock::now();
+      pt.render(scene, spp);
+      img = pt.download();
+      s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      st = pt.stats();
+      std::printf("%zu shares (32x32 tiles), gathered on device %d\n", devices.size(), devices[0]);
+    }
     writePfm(argv[2], img.data(), width, height);
     writePpm(std::string(argv[2]) + ".ppm", img.data(), width, height, false);  // LDR preview, gamma 2.2
     std::printf("%llu triangles, %ux%u x %u spp in %.3f s: %.1f Mrays/s, %.2f Msamples/s (BVH build %.1f ms)\n",

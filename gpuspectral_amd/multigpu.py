@@ -7,11 +7,25 @@ TILE x TILE pixels are dealt round-robin for load balance.  The only collective
 of a render is one gather of the ranks' compact RGBA32F buffers to rank 0
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 """
+import functools
+
 import numpy as np
 
-from .scenes import tile_pixel_ids
+from . import pt
 
 TILE = 32
+
+
+@functools.lru_cache(maxsize=64)
+def _ids(width, height, rank, world, tile):
+    ids = pt.tile_partition(width, height, rank, world, tile)  # the C++ partition (gsp_tile_partition)
+    ids.setflags(write=False)
+    return ids
+
+
+def tile_pixel_ids(width, height, rank, world, tile=TILE):
+    """Pixels of the tiles owned by `rank`: the C ABI's gsp_tile_partition, cached and read-only."""
+    return _ids(int(width), int(height), int(rank), int(world), int(tile))
 
 
 def partition(width, height, rank, world, tile=TILE):

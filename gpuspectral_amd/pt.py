@@ -33,6 +33,19 @@ EXPORTS = (
     "gsp_reset_stats",
     "gsp_trace",
     "gsp_last_error",
+    "gsp_tile_partition",
+    "gsp_multi_create",
+    "gsp_multi_destroy",
+    "gsp_multi_num_shares",
+    "gsp_multi_upload_scene",
+    "gsp_multi_frame_begin",
+    "gsp_multi_render",
+    "gsp_multi_sync",
+    "gsp_multi_gather",
+    "gsp_multi_download",
+    "gsp_multi_get_stats",
+    "gsp_multi_reset_stats",
+    "gsp_multi_last_error",
 )
 
 
@@ -79,6 +92,22 @@ def load():
     L.gsp_trace.argtypes = [vp, vp, u64, C.c_int, vp]
     L.gsp_last_error.argtypes = [vp]
     L.gsp_last_error.restype = C.c_char_p
+    L.gsp_tile_partition.argtypes = [u32, u32, u32, u32, u32, vp]
+    L.gsp_tile_partition.restype = u64
+    L.gsp_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.gsp_multi_destroy.argtypes = [vp]
+    L.gsp_multi_destroy.restype = None
+    L.gsp_multi_num_shares.argtypes = [vp]
+    L.gsp_multi_upload_scene.argtypes = [vp, C.POINTER(abi.SceneDesc)]
+    L.gsp_multi_frame_begin.argtypes = [vp, u32, u32]
+    L.gsp_multi_render.argtypes = [vp, C.POINTER(abi.RenderParams)]
+    L.gsp_multi_sync.argtypes = [vp]
+    L.gsp_multi_gather.argtypes = [vp, C.POINTER(vp)]
+    L.gsp_multi_download.argtypes = [vp, vp]
+    L.gsp_multi_get_stats.argtypes = [vp, C.POINTER(abi.Stats), C.POINTER(abi.Stats)]
+    L.gsp_multi_reset_stats.argtypes = [vp]
+    L.gsp_multi_last_error.argtypes = [vp]
+    L.gsp_multi_last_error.restype = C.c_char_p
     if L.gsp_abi_version() != abi.GSP_ABI_VERSION:
         raise GspError("ABI version mismatch between abi.py and %s" % path)
     _LIB = L
@@ -192,3 +221,90 @@ class Context:
         self._check(self._L.gsp_trace(self._h, rays.ctypes.data, len(rays), 1 if any_hit else 0, hits.ctypes.data),
                     "gsp_trace")
         return hits
+
+
+def tile_partition(width, height, rank, world, tile=32):
+    """Pixel ids of share `rank` of `world` (gsp_tile_partition: the C++ partition every multi-GPU path uses)."""
+    L = load()
+    n = L.gsp_tile_partition(width, height, rank, world, tile, None)
+    ids = np.empty(n, np.uint32)
+    if n:
+        L.gsp_tile_partition(width, height, rank, world, tile, ids.ctypes.data)
+    return ids
+
+
+class MultiContext:
+    """One frame over several GPUs of one node in ONE process (gsp_multi): tile partition, one host thread per share,
+    device-to-device gather into the first device.  `devices` may repeat an index (several shares on one GPU)."""
+
+    def __init__(self, devices):
+        self._L = load()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self._L.gsp_multi_create(devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise GspError("gsp_multi_create: %s" % self._L.gsp_multi_last_error(None).decode())
+        self._h = h
+        self._scene = None
+        self.width = self.height = 0
+        self.num_shares = len(devices)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise GspError("%s failed (%d): %s" % (what, rc, self._L.gsp_multi_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsp_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload_scene(self, scene):
+        d = scene.desc()
+        self._scene = scene
+        self._check(self._L.gsp_multi_upload_scene(self._h, C.byref(d)), "gsp_multi_upload_scene")
+
+    def frame_begin(self, width, height):
+        self._check(self._L.gsp_multi_frame_begin(self._h, width, height), "gsp_multi_frame_begin")
+        self.width, self.height = width, height
+
+    def render(self, spp=1, first_timestamp=0, params=None, **overrides):
+        p = params or abi.default_render_params()
+        p.spp, p.first_timestamp = spp, first_timestamp
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        self._check(self._L.gsp_multi_render(self._h, C.byref(p)), "gsp_multi_render")
+
+    def sync(self):
+        self._check(self._L.gsp_multi_sync(self._h), "gsp_multi_sync")
+
+    def gather(self):
+        """Assemble the frame on the first device; returns its device pointer (0 for a single share)."""
+        p = C.c_void_p()
+        self._check(self._L.gsp_multi_gather(self._h, C.byref(p)), "gsp_multi_gather")
+        return p.value or 0
+
+    def download(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        self._check(self._L.gsp_multi_download(self._h, out.ctypes.data), "gsp_multi_download")
+        return out
+
+    def stats(self, per_share=False):
+        tot = abi.Stats()
+        each = (abi.Stats * self.num_shares)()
+        self._check(self._L.gsp_multi_get_stats(self._h, C.byref(tot), each), "gsp_multi_get_stats")
+        return (tot.as_dict(), [e.as_dict() for e in each]) if per_share else tot.as_dict()
+
+    def reset_stats(self):
+        self._check(self._L.gsp_multi_reset_stats(self._h), "gsp_multi_reset_stats")

@@ -25,6 +25,10 @@
  *        the RGBA32F accumulateBuffer the blit pass samples    S/renderer/PathTracer.cpp:41-55, raygen.rgen:84-108
  *   gsp_last_error
  *        std::runtime_error thrown by the driver               e.g. S/backend/vulkan/VulkanDevice.cpp:31,58,66
+ *   gsp_multi_* (one frame over the N GPUs of a node; the reference has one VkDevice: Renderer.cpp:19-45)
+ *        the same calls as above, applied to every GPU's share of the frame: the image is cut into interleaved
+ *        32x32 tiles (gsp_tile_partition), the scene is replicated, and gsp_multi_download gathers the HDR tiles
+ *        into GPU 0 over xGMI before the one copy to the host                                SURVEY.md 8(e)
  *
  * All structs are POD with the reference's scalar layouts
  * (S/renderer/Scene.h:29-109) so the reference's std::vectors can be passed
@@ -283,6 +287,39 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
 /* Last error message of this context (or of the failed gsp_ctx_create when
  * ctx == NULL).  Never NULL. */
 const char* gsp_last_error(const gsp_context* ctx);
+
+/* ---- several GPUs of one node --------------------------------------------------------------------------------
+ * Pixels are independent (the seed depends on the global pixel index and the timestamp only, raygen.rgen:37), so a
+ * frame is partitioned by image tile: tile (tx, ty) of the tile x tile grid belongs to share
+ * (ty * tiles_x + tx + ty) % world.  gsp_tile_partition writes the pixel ids of one share in increasing order
+ * (out_ids may be NULL) and returns their number; it needs no GPU.  bench.py's one-process-per-GPU path hands these
+ * lists to gsp_frame_begin; a C++ host uses the gsp_multi_* calls below, which do the same inside one process. */
+uint64_t gsp_tile_partition(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t tile,
+                            uint32_t* out_ids);
+
+typedef struct gsp_multi gsp_multi;
+
+/* One context per entry of `devices` (HIP device indices; an index may repeat: several shares on one GPU).  The
+ * first device gathers.  Same error convention as gsp_ctx_create (gsp_multi_last_error(NULL) after a failure). */
+int gsp_multi_create(const int* devices, int n, gsp_multi** out);
+void gsp_multi_destroy(gsp_multi* m);
+int gsp_multi_num_shares(const gsp_multi* m);
+/* gsp_upload_scene / gsp_frame_begin (32x32 tiles) / gsp_render / gsp_sync on every share, one host thread each. */
+int gsp_multi_upload_scene(gsp_multi* m, const gsp_scene_desc* scene);
+int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height);
+int gsp_multi_render(gsp_multi* m, const gsp_render_params* params);
+int gsp_multi_sync(gsp_multi* m);
+/* The one exchange of a render: completes the queued samples, copies every share's HDR tiles device-to-device into
+ * devices[0] and assembles the frame there.  *device_frame (optional) = the RGBA32F frame on devices[0] (NULL for a
+ * single share, whose frame is its context's accumulate buffer). */
+int gsp_multi_gather(gsp_multi* m, void** device_frame);
+/* gsp_multi_gather + one copy to the host: width*height*4 floats, identical to a single-GPU gsp_download. */
+int gsp_multi_download(gsp_multi* m, float* out_rgba);
+/* total (optional): counters summed over the shares, times of the slowest share (they run concurrently);
+ * per_share (optional): gsp_multi_num_shares() records. */
+int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share);
+int gsp_multi_reset_stats(gsp_multi* m);
+const char* gsp_multi_last_error(const gsp_multi* m);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,18 @@ def cornell(oracle_mod):
 
 
 @pytest.fixture(scope="session")
+def staircase2_xml(tmp_path_factory):
+    """The reference's 'Modern Hall' scene (scene.xml + 31 OBJ meshes, CC-BY, tests/golden/ref_scenes/README.md),
+    unpacked from the committed archive: a real Mitsuba scene for the loader tests on boxes without /root/reference."""
+    import tarfile
+
+    d = tmp_path_factory.mktemp("ref_scenes")
+    with tarfile.open(os.path.join(GOLDEN, "ref_scenes", "staircase2.tar.xz")) as t:
+        t.extractall(str(d))
+    return os.path.join(str(d), "staircase2", "scene.xml")
+
+
+@pytest.fixture(scope="session")
 def materials_scene():
     from gpuspectral_amd import scenes
 

@@ -1,0 +1,120 @@
+"""Several GPUs' worth of shares on the ONE GPU of the test box: tile partition + per-share pipelines + the gather
+into the first device + the scatter kernel, through the C ABI (gsp_multi_*), through the C++ host class
+(MultiGpuPathTracer, via the gsp_render CLI) and through bench.py's one-process-per-rank path (gloo stands in for RCCL,
+two processes share the GPU).  Any partition must reproduce the single-GPU frame bit for bit (the seed depends on the
+global pixel index and the timestamp only, raygen.rgen:37) -- BASELINE config 4 minus the xGMI links."""
+import json
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import CORNELL_XML, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_shares_on_one_gpu_reproduce_the_single_gpu_frame(materials_scene, world):
+    import gpuspectral_amd as g
+    from gpuspectral_amd import pt
+
+    W, H, spp = 136, 100, 6  # 5 x 4 tiles, the last column / row partial
+    with g.Context(0) as ctx:
+        ctx.upload_scene(materials_scene)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        ref = ctx.download()
+        st1 = ctx.stats()
+    with pt.MultiContext([0] * world) as m:
+        m.upload_scene(materials_scene)
+        m.frame_begin(W, H)
+        m.render(spp=2)
+        m.render(spp=spp - 2, first_timestamp=2)  # (calls pipeline across shares as they do on one context)
+        img = m.download()
+        tot, each = m.stats(per_share=True)
+        assert np.array_equal(img, ref)
+        for k in ("extension_rays", "shadow_rays", "shaded_vertices", "samples"):
+            assert tot[k] == st1[k], k
+        assert len(each) == world and sum(e["samples"] for e in each) == W * H * spp
+        sizes = [e["samples"] // spp for e in each]
+        assert sizes == [len(pt.tile_partition(W, H, r, world)) for r in range(world)]
+        # a second frame on the same object (frame_begin re-partitions, accumulate buffers are cleared)
+        m.frame_begin(W, H)
+        m.render(spp=spp)
+        assert np.array_equal(m.download(), ref)
+
+
+def test_config4_partition_at_full_resolution():
+    """BASELINE config 4 (bathroom2 stand-in, 1920x1080, tiled over 8 GPUs) with the eight shares on one GPU: the
+    gathered frame equals the single-context frame.  8 spp here; the full 4096 spp of the same frame are checked
+    against the oracle in tests/test_gpu_full_configs.py."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import pt, scenes
+
+    sc = scenes.interior(600_000, seed=7)
+    W, H, spp = 1920, 1080, 8
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        ref = ctx.download()
+        st1 = ctx.stats()
+    with pt.MultiContext([0] * 8) as m:
+        m.upload_scene(sc)
+        m.frame_begin(W, H)
+        m.render(spp=spp)
+        img = m.download()
+        tot = m.stats()
+    assert zlib.crc32(img.tobytes()) == zlib.crc32(ref.tobytes())
+    assert tot["extension_rays"] == st1["extension_rays"] and tot["shadow_rays"] == st1["shadow_rays"]
+
+
+def _read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline() == b"PF\n"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0
+        return np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
+
+
+def test_cpp_host_multi_gpu_tracer_via_cli(tmp_path):
+    """The C++ host class MultiGpuPathTracer (gsp_render ... 0,0,0: three shares on device 0) against PathTracer."""
+    lib = os.path.join(ROOT, "gpuspectral_amd", "lib")
+    env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outs = []
+    for devs in ("0", "0,0,0"):
+        out = str(tmp_path / ("c_%d.pfm" % len(devs)))
+        r = subprocess.run([os.path.join(lib, "gsp_render"), CORNELL_XML, out, "200", "120", "5", devs], env=env,
+                           capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        if devs != "0":
+            assert "3 shares" in r.stdout
+        outs.append(_read_pfm(out))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path end to end on hardware: two processes (torch.distributed.run, gloo instead of RCCL because
+    both ranks sit on the one GPU), the real GPU renderer, C++ tile partition, gather, assembly -- against bench.py's
+    own single-rank frame."""
+    env = dict(os.environ)
+    common = ["--steps", "1", "--warmup", "1", "--spp-per-step", "4", "--tris", "60000", "--width", "416", "--height", "240",
+              "--no-cpu-baseline"]
+    f1, f2 = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump", f1] + common, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dump", f2] + common,
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2
+    assert j1["config"]["extension_rays"] == j2["config"]["extension_rays"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]
+    a, b = np.load(f1), np.load(f2)
+    assert a.shape == b.shape == (240, 416, 4) and np.array_equal(a, b)

@@ -66,3 +66,14 @@ def test_partition_is_a_disjoint_cover():
         sizes = [len(p) for p in parts]
         assert max(sizes) - min(sizes) <= 3 * 32 * 32  # balanced to a few tiles
     assert multigpu.partition(64, 64, 0, 1) is None
+
+
+def test_cpp_partition_equals_numpy_statement():
+    """gsp_tile_partition (C ABI, what every multi-GPU path uses) against the numpy statement of the same rule
+    (scenes.tile_pixel_ids, used by the oracle-side tools): identical lists for every share."""
+    from gpuspectral_amd import pt, scenes
+
+    for (W, H, world, tile) in [(1920, 1080, 8, 32), (100, 37, 3, 32), (4096, 4096, 8, 32), (65, 31, 2, 16), (5, 5, 7, 32), (1, 1, 1, 32)]:
+        for r in range(world):
+            assert np.array_equal(pt.tile_partition(W, H, r, world, tile), scenes.tile_pixel_ids(W, H, r, world, tile)), (W, H, world, r)
+    assert len(pt.tile_partition(64, 64, 5, 4)) == 0  # rank outside the world: empty

@@ -9,12 +9,12 @@ from conftest import CORNELL_XML, ROOT
 REF_ASSETS = "/root/reference/src/GPUSpectral/assets"
 
 
-def test_cpp_loader_under_asan_ubsan(tmp_path):
+def test_cpp_loader_under_asan_ubsan(tmp_path, staircase2_xml):
     host = os.path.join(ROOT, "gpuspectral_amd", "host")
     exe = str(tmp_path / "asan_loader")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-I", host, "-o", exe,
                            os.path.join(ROOT, "tests", "emu", "asan_loader.cpp"), os.path.join(host, "Loader.cpp")])
-    scenes = [CORNELL_XML]
+    scenes = [CORNELL_XML, staircase2_xml]
     assets = os.path.dirname(os.path.dirname(CORNELL_XML))
     if os.path.isdir(REF_ASSETS):  # the reference's large scenes, where the tree is mounted
         assets = REF_ASSETS
