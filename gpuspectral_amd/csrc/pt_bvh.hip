@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restric
   if (i >= n_int || !flag[i]) return;
   Entry4 e[4];
   int cnt = 0;
-  auto conv = [&](int32_t g) { return g < 0 ? g : (int32_t)(idx4[g] * 64u); };  // inner child = byte offset of its node
+  auto conv = [&](int32_t g) { return g < 0 ? g : (int32_t)((idx4[g] + kTopNodes) * 64u); };  // inner child = byte offset of its node
   auto expand = [&](int32_t c, q4 lo, q4 hi) {
     if (c < 0) {
       e[cnt].lo = lo;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restric
   const q4 a = me[0], b = me[1], d = me[2], k = me[3];
   expand((int32_t)__float_as_uint(k.x), mkq(a.x, a.y, a.z, 0.0f), mkq(a.w, b.x, b.y, 0.0f));
   expand((int32_t)__float_as_uint(k.y), mkq(b.z, b.w, d.x, 0.0f), mkq(d.y, d.z, d.w, 0.0f));
-  encode_node4(nodes4 + 4ll * idx4[i], e, cnt, dummy_slot);
+  encode_node4(nodes4 + 4ll * (idx4[i] + kTopNodes), e, cnt, dummy_slot);
 }
 
 // Greedy 4-wide collapse, one thread per output node of the current level.
@@ -668,19 +668,45 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       GSP_HIP_TRY(hipMemcpyAsync(&n4, idx4 + n_int, sizeof(n4), hipMemcpyDeviceToHost, stream));
       GSP_HIP_TRY(hipStreamSynchronize(stream));
       out.num_nodes = n4;
-      if ((uint64_t)n4 * 64ull >= 0x7fffff00ull) {
+      if (((uint64_t)n4 + kTopNodes) * 64ull >= 0x7fffff00ull) {
         err = "scene too large: BVH node offsets exceed 31 bits";
         return GSP_ERR_INVALID;
       }
-      const size_t b_nodes = (size_t)std::max<uint32_t>(n4, 1) * 64;
+      const size_t b_nodes = (size_t)(std::max<uint32_t>(n4, 1) + kTopNodes) * 64;
       GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
+      if (kTopNodes) GSP_HIP_TRY(hipMemsetAsync(out.nodes, 0, (size_t)kTopNodes * 64, stream));
       out.bytes += b_nodes;
       hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes, n);
       uint32_t root4 = 0;  // the binary root has depth 0, so it owns a 4-wide node
       GSP_HIP_TRY(hipMemcpyAsync(&root4, idx4 + root2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       GSP_HIP_TRY(hipStreamSynchronize(stream));
-      out.root = (int32_t)(root4 * 64u);
+      out.root = (int32_t)((root4 + kTopNodes) * 64u);
       collapse_levels = 0;
+      if (kTopNodes) {
+        // breadth-first copy of the top of the tree into slots [0, kTopNodes): child links that stay inside the copy
+        // are rewritten, the others keep pointing at the original nodes (which stay in place)
+        std::vector<q4> top(4ull * kTopNodes);
+        std::vector<int32_t> orig(kTopNodes);
+        orig[0] = out.root;
+        uint32_t count = 1;
+        for (uint32_t i = 0; i < count; ++i) {
+          q4* nd = &top[4ull * i];
+          GSP_HIP_TRY(hipMemcpyAsync(nd, (const char*)out.nodes + (uint32_t)orig[i], 64, hipMemcpyDeviceToHost, stream));
+          GSP_HIP_TRY(hipStreamSynchronize(stream));
+          float* link[4] = {&nd[2].z, &nd[2].w, &nd[3].x, &nd[3].y};
+          for (int k = 0; k < 4; ++k) {
+            const int32_t c = (int32_t)f2u(*link[k]);
+            if (c >= 0 && count < kTopNodes) {
+              orig[count] = c;
+              *link[k] = u2f(count * 64u);
+              ++count;
+            }
+          }
+        }
+        GSP_HIP_TRY(hipMemcpyAsync(out.nodes, top.data(), (size_t)count * 64, hipMemcpyHostToDevice, stream));
+        GSP_HIP_TRY(hipStreamSynchronize(stream));
+        out.root = 0;
+      }
     } else {
       // greedy SAH collapse, breadth-first; at most n - 1 output nodes
       q4* all4 = nullptr;

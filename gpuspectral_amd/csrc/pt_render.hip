@@ -55,14 +55,18 @@ struct ShadowQueue {
   q4* S3;
 };
 
-// device counters
-// device counter words: [0] next-queue size, [1] shadow-queue size, [2, 2+kMaxSlots) live paths per
-// sample slot, then the ray hand-out counters of the extend and connect launches (kWorkShards
-// words each, on separate 128-B lines)
-constexpr int kMaxSlots = 64;
-enum { C_NEXT = 0, C_SHADOW = 1, C_LIVE = 2, C_TAIL_EXT = 66, C_TAIL_SH = 68, C_READBACK = 72, C_WORK_EXT = 96, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
+// device counter words: [0] next-queue size, [1] shadow-queue size, k_finish's ray totals, [C_LIVE, C_LIVE + kMaxSlots)
+// live paths per sample slot, then the ray hand-out counters of the extend and connect launches (kWorkShards words
+// each, on separate 128-B lines).  Words [0, C_READBACK) travel to the host once per iteration.
+// kMaxSlots: a slot of the sample-result ring is held from the injection of its batch until the batch's LAST path has
+// ended (up to 52 bounces later) although ~95 % of its paths end within a few bounces, so the number of slots -- not
+// the path pool -- bounds the paths in flight on scenes with short paths: with 64 slots the reference's coffee scene
+// (4.2 rays per sample) ran 3 M-path launches in a 32 M-path pool (profiles/r02_scene_probe.txt).
+constexpr int kMaxSlots = 1024;
+enum { C_NEXT = 0, C_SHADOW = 1, C_TAIL_EXT = 2, C_TAIL_SH = 4, C_LIVE = 8, C_READBACK = C_LIVE + kMaxSlots,
+       C_WORK_EXT = ((C_READBACK + 31) / 32) * 32, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
        C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
-static_assert(C_LIVE + kMaxSlots <= C_TAIL_EXT && C_READBACK <= C_WORK_EXT && (C_TAIL_EXT % 2) == 0, "counter layout");
+static_assert((C_TAIL_EXT % 2) == 0 && (C_TAIL_SH % 2) == 0 && C_TAIL_SH + 2 <= C_LIVE, "counter layout");
 struct DevStats {
   unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays;
 };
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave start in the global queues
   __shared__ q4 s_hq[kShadeBlock], s_p0[kShadeBlock], s_p1[kShadeBlock], s_p2[kShadeBlock];
   __shared__ uint32_t s_fl[kShadeBlock];
-  if (threadIdx.x < kMaxSlots) s_dead[threadIdx.x] = 0;
+  for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxSlots; k += kShadeBlock) s_dead[k] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
@@ -338,7 +342,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     }
   }
   __syncthreads();
-  if (threadIdx.x < kMaxSlots && s_dead[threadIdx.x]) atomicSub(&counters[C_LIVE + threadIdx.x], s_dead[threadIdx.x]);
+  for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxSlots; k += kShadeBlock)
+    if (s_dead[k]) atomicSub(&counters[C_LIVE + k], s_dead[k]);
   shaded = wave_sum(shaded);
   if (lane == 0 && shaded) atomicAdd(&stats->shaded, shaded);
 }
@@ -656,8 +661,8 @@ int gsp_ctx_create(int device, gsp_context** out) {
     gsp_context::Lane& L = c->lanes[l];
     L.index = l;
     e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&L.h_counters, 1024, hipHostMallocDefault);
-    if (e == hipSuccess) std::memset(L.h_counters, 0, 1024);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&L.h_counters, C_READBACK * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) std::memset(L.h_counters, 0, C_READBACK * sizeof(uint32_t));
   }
   if (e != hipSuccess) {
     set_create_error(std::string("context setup: ") + hipGetErrorString(e));
@@ -912,7 +917,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
     // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
     // on its own lane (not when gsp_render merely queues work: those paths ride along with the next call's)
     CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, 2 * sizeof(uint32_t), st));
-    CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_TAIL_EXT, 0, 4 * sizeof(uint32_t), st));
+    CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_TAIL_EXT, 0, (C_LIVE - C_TAIL_EXT) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_finish, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
                        L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
     CTX_TRY(ctx, hipGetLastError());
@@ -1121,11 +1126,19 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
       P.Kb = Kb;
       P.batch_paths = Kb * npix;
-      // (at most 64 samples per pixel in flight: small frames do not allocate gigabytes)
-      P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 64 * npix), 2 * P.batch_paths);
+      // (at most 128 samples per pixel in flight: tiny frames do not allocate gigabytes; a 1/8 tile share of a
+      // 1080p frame, 259 k pixels, still fills the whole pool)
+      P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 128 * npix), 2 * P.batch_paths);
       P.cap = P.pool_target + P.batch_paths;
-      P.num_slots = (uint32_t)std::min<uint64_t>(
-          kMaxSlots, std::max<uint64_t>(4, 8 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths)));
+      // Slots of the sample-result ring: a batch holds its slot until its last path has ended, so with paths of
+      // ~3 bounces on average and a tail of 52 the alive share of the batches in flight is only a few percent and
+      // the ring must hold ~24 x the pool for the pool to fill (coffee: 4.2 rays per sample).  16 B per entry, most
+      // of it never touched on scenes with long paths; bounded by GSP_RING_BYTES (default 16 GiB of the 288).
+      uint64_t ring_bytes = 16ull << 30;
+      if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
+      const uint64_t want_slots = 24 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths);
+      const uint64_t fit_slots = ring_bytes / ctx->num_lanes / (P.batch_paths * sizeof(q4));
+      P.num_slots = (uint32_t)std::min<uint64_t>(kMaxSlots, std::max<uint64_t>(4, std::min(want_slots, fit_slots)));
       if (P.cap >= (1ull << 32) || (uint64_t)P.num_slots * P.batch_paths >= (1ull << 32)) {
         ctx->err = "frame too large for 32-bit path indices";
         return GSP_ERR_INVALID;

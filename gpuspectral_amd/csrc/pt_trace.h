@@ -40,6 +40,13 @@ struct HitRec {
 };
 
 constexpr int kLeafMaxTris = 4;
+// A/B variant ("BVH top levels through LDS"): the first GSP_LDS_TOP slots of the node array hold a
+// breadth-first copy of the top of the tree (root = slot 0; 21 = three levels, 85 = four), which k_trace stages into
+// LDS once per block and reads with ds_read_b128 instead of global loads.  0 = off.
+#ifndef GSP_LDS_TOP
+#define GSP_LDS_TOP 0
+#endif
+constexpr uint32_t kTopNodes = GSP_LDS_TOP;
 constexpr int32_t kEmptyChild = 0x7ffffffe;  // unused slot of a 4-wide node
 GSP_HD int32_t make_leaf(uint32_t first_slot, uint32_t count) { return ~(int32_t)((first_slot << 2) | (count - 1u)); }
 
@@ -166,6 +173,7 @@ GSP_HD void encode_node4(q4* __restrict__ o, const Entry4* e, int cnt, uint32_t 
 // Per-ray constants of the step.
 struct RayBox {
   f3 o, inv;               // origin, 1 / direction
+  f3 invc;                 // inv clamped to +-2^64 (box tests only; the triangle test uses the exact ray)
   bool negx, negy, negz;   // sign of 1/d per axis: which plane of a slab is the near one
 };
 GSP_HD RayBox make_raybox(f3 o, f3 d) {
@@ -175,16 +183,25 @@ GSP_HD RayBox make_raybox(f3 o, f3 d) {
   r.negx = r.inv.x < 0.0f;
   r.negy = r.inv.y < 0.0f;
   r.negz = r.inv.z < 0.0f;
+  const float big = 18446744073709551616.0f;  // 2^64
+  r.invc = mk3(fmin_(fmax_(r.inv.x, -big), big), fmin_(fmax_(r.inv.y, -big), big), fmin_(fmax_(r.inv.z, -big), big));
   return r;
 }
 // Tests the four child boxes of the node {n0..n3} against the ray segment [tmin, tfar] and returns the children
 // ordered by entry distance: e0 nearest .. e3, of which the first `hits` are hit (the rest are unspecified).
 // The return value is hits * UNIT (the wave kernel keeps the count in stack-offset units).
-//   decode: plane = origin + q * scale (per-axis power of two, stored as a float), taken relative to the ray origin
-//   as fma(q, scale, origin - o) (same rounding class as an uncompressed (b - o)), then * 1/d.  (Folding 1/d into
-//   per-node constants, t = fma(q, scale/d, (origin-o)/d), is one multiply per plane cheaper but overflows for rays
-//   with a tiny direction component: those rays lose their culling, run far longer than the rest and stretch every
-//   launch -- measured +13 % / +47 % kernel time at unchanged mean nodes per ray.)
+//   decode: plane = origin + q * scale (per-axis power of two, stored as a float); its ray parameter is
+//   t = fma(q, scale / d, (origin - o) / d): one fma per plane after six multiplies per node (scale / d is exact up to
+//   the rounding of 1/d: scale is a power of two).  1/d is CLAMPED to +-2^64 for this: with an infinite 1/d (a zero
+//   direction component) every plane of that axis would be fma(q, inf, +-inf) = NaN, the slab would stop
+//   constraining and axis-parallel rays would lose their culling (measured in round 1 without the clamp: +13 % / +47 %
+//   kernel time).  With the clamp such a ray sees t = (plane - o) * 2^64: both planes of a slab it is outside of land
+//   far beyond tmax <= 1e10 on the same side (culled, correctly: the ray never enters), a slab it is inside of gives
+//   -huge / +huge (unconstrained), and no product can overflow (|scale|, |origin - o| < 2^40).  The rounding error of
+//   t is of the same order as with an uncompressed (b - o) * (1/d) test -- 2^-24 |origin - o| / |d| -- and is covered
+//   by the outward quantisation, the padded leaf boxes and the 8-ulp slack on the far bound.  r02 A/B against
+//   (fma(q, scale, origin - o)) * (1/d): closest-hit kernel -3.4 %, any-hit -1.4 %, bit-identical images
+//   (profiles/r02_ab_fold_ldstop.txt).
 //   Near / far planes are picked by the sign of 1/d instead of min / max per child: for inv > 0
 //   (lo - o) * inv <= (hi - o) * inv by monotonic rounding, so the values are the ones min / max would return; a
 //   NaN (0 * inf) is dropped by max / min and leaves that side unconstrained.  The far bound is relaxed by 8 ulp on
@@ -192,8 +209,9 @@ GSP_HD RayBox make_raybox(f3 o, f3 d) {
 template <uint32_t UNIT>
 GSP_HD uint32_t node4_step(const q4& n0, const q4& n1, const q4& n2, const q4& n3, const RayBox& rb, float tmin, float tfar,
                            int32_t& e0, int32_t& e1, int32_t& e2, int32_t& e3) {
-  const float sx = n0.w, sy = n3.z, sz = n3.w;
-  const float dx = n0.x - rb.o.x, dy = n0.y - rb.o.y, dz = n0.z - rb.o.z;
+  // per-node constants of the decode: scale / d and (origin - o) / d per axis (6 multiplies), then ONE fma per plane
+  const float sx = n0.w * rb.invc.x, sy = n3.z * rb.invc.y, sz = n3.w * rb.invc.z;
+  const float dx = (n0.x - rb.o.x) * rb.invc.x, dy = (n0.y - rb.o.y) * rb.invc.y, dz = (n0.z - rb.o.z) * rb.invc.z;
   const uint32_t qlx = f2u(n1.x), qly = f2u(n1.y), qlz = f2u(n1.z), qhx = f2u(n1.w), qhy = f2u(n2.x), qhz = f2u(n2.y);
   const uint32_t qnx = rb.negx ? qhx : qlx, qfx = rb.negx ? qlx : qhx;
   const uint32_t qny = rb.negy ? qhy : qly, qfy = rb.negy ? qly : qhy;
@@ -207,9 +225,9 @@ GSP_HD uint32_t node4_step(const q4& n0, const q4& n1, const q4& n2, const q4& n
 #define GSP_UB3(q) ((float)((q) >> 24))
 #define GSP_CHILD(K, CVT)                                                                                         \
   {                                                                                                               \
-    const float tnx = __builtin_fmaf(CVT(qnx), sx, dx) * rb.inv.x, tfx = __builtin_fmaf(CVT(qfx), sx, dx) * rb.inv.x; \
-    const float tny = __builtin_fmaf(CVT(qny), sy, dy) * rb.inv.y, tfy = __builtin_fmaf(CVT(qfy), sy, dy) * rb.inv.y; \
-    const float tnz = __builtin_fmaf(CVT(qnz), sz, dz) * rb.inv.z, tfz = __builtin_fmaf(CVT(qfz), sz, dz) * rb.inv.z; \
+    const float tnx = __builtin_fmaf(CVT(qnx), sx, dx), tfx = __builtin_fmaf(CVT(qfx), sx, dx);                   \
+    const float tny = __builtin_fmaf(CVT(qny), sy, dy), tfy = __builtin_fmaf(CVT(qfy), sy, dy);                   \
+    const float tnz = __builtin_fmaf(CVT(qnz), sz, dz), tfz = __builtin_fmaf(CVT(qfz), sz, dz);                   \
     const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));                                                    \
     const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, tfar));                                                    \
     lo4[K] = lo;                                                                                                  \

@@ -155,6 +155,11 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
                                                         int32_t* __restrict__ spill, uint32_t spill_stride,
                                                         TraceStatsOut so) {
   __shared__ int32_t lds_stack[kLdsStackDepth * kTraceBlock];
+#if GSP_LDS_TOP && !defined(GSP_TOP_GLOBAL_ONLY)
+  __shared__ q4 lds_top[4 * kTopNodes];
+  for (uint32_t i = threadIdx.x; i < 4 * kTopNodes; i += kTraceBlock) lds_top[i] = nodes[i];
+  __syncthreads();
+#endif
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -300,8 +305,19 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       if (on) {
           // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip through encode_node4)
           // (`cur` is the node's byte offset: 32-bit offset + uniform base, no 64-bit address arithmetic)
+#if GSP_LDS_TOP && !defined(GSP_TOP_GLOBAL_ONLY)
+          q4 n0, n1, n2, n3;
+          if ((uint32_t)cur < kTopNodes * 64u) {  // top of the tree: the block's LDS copy
+            const q4* nd = (const q4*)((const char*)lds_top + (uint32_t)cur);
+            n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+          } else {
+            const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
+            n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+          }
+#else
           const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
           const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+#endif
           if (STATS) ++c_nodes;
           constexpr uint32_t L = WaveStack::kLevelBytes;  // hit count kept in stack-offset units
           int32_t e0, e1, e2, e3;

@@ -6,7 +6,8 @@ mkdir -p build/var_$1 ../lib/variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $2"
 hipcc $F -c pt_render.hip -o build/var_$1/pt_render.o &
 hipcc $F -c pt_bvh.hip -o build/var_$1/pt_bvh.o &
+hipcc $F -c pt_multi.hip -o build/var_$1/pt_multi.o &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/$1.so build/var_$1/pt_render.o build/var_$1/pt_bvh.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/$1.so build/var_$1/pt_render.o build/var_$1/pt_bvh.o build/var_$1/pt_multi.o
 echo built $1
 rm -rf build/var_$1

@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc CSVs (one directory per pass) by kernel: per-launch averages.
+"""Aggregate rocprofv3 --pmc CSVs (one directory per pass, scripts/pmc_bench.sh) by kernel.
 
-FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB... (gfx950: FETCH_SIZE counts 64 B per
-128-B request for wide coalesced reads -- MI355X_MICROARCH.md, HBM section; the raw and the
-doubled figure are both printed)."""
+Writes, next to the passes:
+  summary.txt (stdout)   per-kernel per-launch averages of every counter, L2 hit rate, wave-cycle split, lane use
+  pmc_bench.json         for the three render kernels the PER-DISPATCH counter values in dispatch order -- bench.py takes
+                         the last K dispatches (K = its own timed launches: the timed region is the tail of the run) so
+                         that counters and HIP-event times cover exactly the same launches -- plus the FETCH_SIZE
+                         calibration of scripts/microbench/fetch_calib.hip
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads
+(MI355X_MICROARCH.md, HBM section); whether that also holds for the traversal's divergent 16-B gathers is what the
+calibration measures (known bytes / counter bytes).
+"""
 import csv
 import glob
 import json
@@ -15,70 +22,91 @@ from collections import defaultdict
 
 def short(name):
     if "k_trace" in name:
-        io = "fused" if "FusedIO" in name else "extend" if "ExtendIO" in name else "connect" if "ConnectIO" in name else "test"
+        io = "extend" if "ExtendIO" in name else "connect" if "ConnectIO" in name else "test"
         stats = "_stats" if re.search(r"k_trace<(false|true|\d), true", name) else ""
         return "k_trace_" + io + stats
     m = re.search(r"(k_[a-z_0-9]+)(<[a-z]+>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else name[:40]
 
 
+KEEP = ("k_trace_extend", "k_trace_connect", "k_shade")
+
+
+def read_pass(root, name):
+    """-> {kernel: {counter: [value per dispatch, in dispatch order]}}"""
+    per = defaultdict(lambda: defaultdict(dict))
+    for f in glob.glob(os.path.join(root, name, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            d = int(r["Dispatch_Id"])
+            per[k][r["Counter_Name"]][d] = per[k][r["Counter_Name"]].get(d, 0.0) + float(r["Counter_Value"])
+    return {k: {c: [v for _, v in sorted(dd.items())] for c, dd in cs.items()} for k, cs in per.items()}
+
+
+def read_trace(root, name):
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(root, name, "**", "*kernel_trace.csv"), recursive=True):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: float(r["Start_Timestamp"]))
+        for r in rows:
+            dur[short(r["Kernel_Name"])].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+    return dur
+
+
 def main(root):
-    per = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))  # kernel -> counter -> [sum, dispatches]
-    dur = defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
-        seen = defaultdict(set)
-        for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            c = r["Counter_Name"]
-            per[k][c][0] += float(r["Counter_Value"])
-            seen[(k, c)].add(r["Dispatch_Id"])
-        for (k, c), ids in seen.items():
-            per[k][c][1] += len(ids)
-    for f in glob.glob(os.path.join(root, "grbm", "**", "*kernel_trace.csv"), recursive=True) or glob.glob(os.path.join(root, "*", "**", "*kernel_trace.csv"), recursive=True)[:1]:
-        for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            dur[k][0] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-            dur[k][1] += 1
-    out = {}
-    for k in sorted(per, key=lambda k: -dur[k][0]):
+    counters = defaultdict(dict)  # kernel -> counter -> list
+    for p in ("fetch", "write", "l2", "sq1", "sq2", "grbm"):
+        for k, cs in read_pass(root, p).items():
+            counters[k].update(cs)
+    dur = read_trace(root, "trace") or read_trace(root, "grbm")
+    out = {"kernels": {}, "source": os.path.basename(root)}
+    for k in sorted(counters, key=lambda k: -sum(dur.get(k, [0.0]))):
         if not k.startswith("k_"):
             continue
-        c = per[k]
-        n = max(1, dur[k][1])
-        line = {"launches": dur[k][1], "avg_us": dur[k][0] / n / 1e3}
-        for name, (s, d) in c.items():
-            line[name] = s / max(1, d)
-        out[k] = line
-        print("== %s: %d launches, avg %.1f us (profiled)" % (k, dur[k][1], line["avg_us"]))
+        c = counters[k]
+        n = len(dur.get(k, [])) or 1
+        avg = {name: sum(v) / max(1, len(v)) for name, v in c.items()}
+        avg_us = sum(dur.get(k, [0.0])) / n
+        print("== %s: %d launches, avg %.1f us (kernel trace without counters)" % (k, len(dur.get(k, [])), avg_us))
         for name in sorted(c):
-            print("   %-28s %14.1f per launch" % (name, line[name]))
-        if "FETCH_SIZE" in line:
-            fb = line["FETCH_SIZE"] * 1024.0
-            wb = line.get("WRITE_SIZE", 0.0) * 1024.0
-            print("   HBM read  %.1f MB/launch raw (x2 = %.1f MB if all wide-coalesced), write %.1f MB" % (fb / 1e6, 2 * fb / 1e6, wb / 1e6))
-            line["hbm_read_bytes_raw"] = fb
-            line["hbm_write_bytes"] = wb
-        if "TCC_HIT_sum" in line:
-            h, m = line["TCC_HIT_sum"], line["TCC_MISS_sum"]
-            print("   L2 hit rate %.1f %%" % (100 * h / max(1.0, h + m)))
-        if "SQ_WAVE_CYCLES" in line:
-            wc = line["SQ_WAVE_CYCLES"]
+            print("   %-28s %16.1f per launch (%d dispatches)" % (name, avg[name], len(c[name])))
+        if "FETCH_SIZE" in avg:
+            print("   memory side: FETCH_SIZE %.1f MB raw per launch, WRITE_SIZE %.1f MB" % (avg["FETCH_SIZE"] * 1024 / 1e6, avg.get("WRITE_SIZE", 0.0) * 1024 / 1e6))
+        if "TCC_HIT_sum" in avg:
+            print("   L2 hit rate %.1f %%" % (100 * avg["TCC_HIT_sum"] / max(1.0, avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])))
+        if "SQ_WAVE_CYCLES" in avg:
+            wc = avg["SQ_WAVE_CYCLES"]
             print("   wave cycles: wait_any %.1f %%  wait_inst %.1f %%  active_inst %.1f %%  (valu %.1f %%)" % (
-                100 * line.get("SQ_WAIT_ANY", 0) / wc, 100 * line.get("SQ_WAIT_INST_ANY", 0) / wc,
-                100 * line.get("SQ_ACTIVE_INST_ANY", 0) / wc, 100 * line.get("SQ_ACTIVE_INST_VALU", 0) / wc))
-        if "SQ_THREAD_CYCLES_VALU" in line and "SQ_ACTIVE_INST_VALU" in per[k]:
-            pass
-    json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
-    ext = out.get("k_trace_fused") or out.get("k_trace_extend")
-    ext_name = "k_trace<2, FusedIO>" if out.get("k_trace_fused") else "k_trace<ExtendIO>"
-    if ext and "hbm_read_bytes_raw" in ext:
-        # gfx950: FETCH_SIZE tallies 64 B per 128-B request for 16-B-per-lane loads (MI355X_MICROARCH.md,
-        # HBM section) -> reads doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
-        json.dump({"kernel": ext_name, "launches": ext["launches"], "avg_us_profiled": ext["avg_us"],
-                   "fetch_size_kib_per_launch": ext["FETCH_SIZE"], "write_size_kib_per_launch": ext.get("WRITE_SIZE", 0.0),
-                   "hbm_bytes_per_launch": 2.0 * ext["hbm_read_bytes_raw"] + ext.get("hbm_write_bytes", 0.0),
-                   "note": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction for 16-B-per-lane loads); memory-side L2 requests, Infinity-Cache hits included"},
-                  open(os.path.join(root, "pmc_extend.json"), "w"), indent=1)
+                100 * avg.get("SQ_WAIT_ANY", 0) / wc, 100 * avg.get("SQ_WAIT_INST_ANY", 0) / wc,
+                100 * avg.get("SQ_ACTIVE_INST_ANY", 0) / wc, 100 * avg.get("SQ_ACTIVE_INST_VALU", 0) / wc))
+        if "SQ_THREAD_CYCLES_VALU" in avg and "SQ_INSTS_VALU" in avg:
+            print("   lanes enabled per VALU instruction: %.3f of 64" % (avg["SQ_THREAD_CYCLES_VALU"] / max(1.0, avg["SQ_INSTS_VALU"]) / 64.0))
+        if "SQ_LDS_BANK_CONFLICT" in avg and "SQ_ACTIVE_INST_LDS" in avg:
+            print("   LDS: bank-conflict cycles %.1f M vs LDS-instruction cycles %.1f M" % (avg["SQ_LDS_BANK_CONFLICT"] / 1e6, avg["SQ_ACTIVE_INST_LDS"] / 1e6))
+        if k in KEEP:
+            out["kernels"][k] = {"trace_us": dur.get(k, []), "counters": c}
+    # ---- FETCH_SIZE calibration
+    cal = read_pass(root, "calib")
+    txt = os.path.join(root, "fetch_calib.txt")
+    if cal and os.path.exists(txt):
+        t = open(txt).read()
+        print("== FETCH_SIZE calibration (scripts/microbench/fetch_calib.hip)")
+        print(t.strip())
+        calib = {}
+        m = re.search(r"k_gather64: (\d+) lanes x (\d+) records x 64 B", t)
+        for k, cs in cal.items():
+            if "FETCH_SIZE" not in cs:
+                continue
+            counter_bytes = sum(cs["FETCH_SIZE"]) * 1024.0
+            if "k_gather64" in k and m:
+                known = float(m.group(1)) * float(m.group(2)) * 64.0
+            elif "k_stream" in k:
+                known = float(1 << 26) * 64.0
+            else:
+                continue
+            calib[k] = {"known_bytes": known, "fetch_size_bytes": counter_bytes, "known_over_counter": known / max(1.0, counter_bytes)}
+            print("   %-12s known %.1f MB, FETCH_SIZE %.1f MB -> known / counter = %.3f" % (k, known / 1e6, counter_bytes / 1e6, known / max(1.0, counter_bytes)))
+        out["fetch_calibration"] = calib
+    json.dump(out, open(os.path.join(root, "pmc_bench.json"), "w"))
 
 
 if __name__ == "__main__":
