@@ -18,11 +18,15 @@ scene at 1920x1080, on 1/2/4/8 MI355X.
 * Timed region: barrier + device sync on both sides, max over ranks.
 * Scene upload and BVH build are outside the timed region (reported separately).
 
-Rank 0 prints ONE JSON line.  `roofline` is the extend (BVH traversal) kernel:
-algorithmic bytes moved per second (formula in DESIGN.md) against the 8 TB/s
-HBM3E peak, with the kernel's time measured by HIP events on the tracer's own
-stream.  `cpu_baseline` times the scalar CPU oracle on this box's host cores on
-a bounded sample of the same workload (N = 1 only).
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, k_trace<ExtendIO> (closest-hit BVH traversal),
+against the resource that binds it -- VALU instruction issue: wave64 VALU instructions per second
+(rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from the committed PMC passes over this same command,
+profiles/pmc_bench_latest.json) over this run's HIP-event kernel time, against 1024 SIMDs x 2.4 GHz / 2 cycles.  The
+memory side is reported next to it: counter HBM bytes per launch (`traffic`, FETCH_SIZE / WRITE_SIZE with the
+calibration of scripts/microbench/fetch_calib.hip) as a fraction of the 8 TB/s peak (`hbm_frac`), and the SURVEY 8(d)
+algorithmic bytes (every node / triangle record the traversal reads, mostly served by L2 / Infinity Cache) as
+`algorithmic_gbs` -- informational, not a fraction of anything.  `cpu_baseline` times the scalar CPU oracle on this
+box's host cores on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import json
@@ -37,6 +41,33 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz max clock (same guide)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")
+
+
+def pmc_for_run(config, timed_launches):
+    """Counters of the timed k_trace<ExtendIO> launches from the committed rocprofv3 --pmc passes (scripts/pmc_bench.sh)
+    over THIS command: the passes ran the same workload, so their last `timed_launches` dispatches of the kernel are the
+    launches of the timed region (it is the tail of the run).  None when the file is absent or was taken on another
+    workload / launch sequence."""
+    try:
+        pm = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None
+    want = {k: config[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
+    have = pm.get("bench_config", {})
+    if any(have.get(k) != v for k, v in want.items()) or pm.get("steps") is None:
+        return None
+    k = pm["kernels"].get("k_trace_extend")
+    if not k or pm.get("timed_launches") != timed_launches:
+        return None
+    out = {"source": "profiles/pmc_bench_latest.json (%s)" % pm.get("source", "?"), "calibration": pm.get("fetch_calibration", {})}
+    for name, vals in k["counters"].items():
+        if len(vals) < timed_launches:
+            return None
+        out[name] = float(sum(vals[-timed_launches:]))
+    return out
 
 
 def parse():
@@ -238,23 +269,43 @@ def main():
     if rank == 0:
         ext_rays, sh_rays, samples = tot[1], tot[2], tot[3]
         rays = ext_rays + sh_rays
-        # extend-kernel roofline (rank 0's launches): algorithmic bytes / HIP-event time
-        b_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray  # 64-B compressed 4-wide node
+        # ---- roofline of the dominant kernel (rank 0's launches): this run's HIP-event time, the committed counters
+        b_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray  # ray + hit + node / triangle records
         ext_ms = st["extend_kernel_ms"]
         launches = max(1, st["extend_launches"])
         alg_bytes = st["extension_rays"] * b_ray
-        achieved = alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        traffic = None
-        pm = os.path.join(ROOT, "profiles", "pmc_extend_latest.json")
-        if os.path.exists(pm):
-            try:
-                # the PMC passes (scripts/profile_pmc.sh, separate rocprofv3 --pmc runs of this bench) give bytes
-                # per profiled launch; this run's launches differ in size, so carry the measured memory-side rate
-                # (bytes per microsecond of kernel time) over to this run's average launch
-                pj = json.load(open(pm))
-                traffic = pj["hbm_bytes_per_launch"] / pj["avg_us_profiled"] * (ext_ms / launches * 1e3)
-            except Exception:
-                traffic = None
+        cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S}
+        pmc = pmc_for_run(cfg_key, int(st["extend_launches"])) if world == 1 else None
+        roof = {
+            "kernel": "k_trace<ExtendIO> (closest-hit traversal of the 4-wide BVH)",
+            "bound": "valu_issue",
+            "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instr/s", "frac": None,
+            "lanes_per_instr": None, "traffic": None, "hbm_gbs": None, "hbm_frac": None, "l2_hit_rate": None,
+            "algorithmic_bytes_per_launch": alg_bytes / launches,
+            "algorithmic_gbs": alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else None,
+            "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+            "launches": int(launches), "avg_launch_ms": ext_ms / launches,
+            "extend_ms": ext_ms, "shade_ms": st["shade_kernel_ms"], "connect_ms": st["connect_kernel_ms"],
+            "pmc": None,
+        }
+        if pmc and ext_ms > 0:
+            insts = pmc.get("SQ_INSTS_VALU", 0.0)
+            roof["achieved"] = insts / (ext_ms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
+            if insts > 0 and "SQ_THREAD_CYCLES_VALU" in pmc:
+                roof["lanes_per_instr"] = pmc["SQ_THREAD_CYCLES_VALU"] / insts / 64.0
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # FETCH_SIZE (KiB) reads 1.000 x the bytes of the traversal's divergent 16-B gathers and 0.5 x those of
+                # coalesced 16-B-per-lane reads (fetch_calib.hip, in the PMC file); the only coalesced reads of this
+                # kernel are the 32-B ray records, so the missing half of those is added back.  WRITE_SIZE is exact.
+                rd = pmc["FETCH_SIZE"] * 1024.0 + 0.5 * 32.0 * st["extension_rays"]
+                wr = pmc["WRITE_SIZE"] * 1024.0
+                roof["traffic"] = (rd + wr) / launches
+                roof["hbm_gbs"] = (rd + wr) / (ext_ms * 1e-3) / 1e9
+                roof["hbm_frac"] = roof["hbm_gbs"] / HBM_PEAK_GBS
+            if pmc.get("TCC_HIT_sum", 0) + pmc.get("TCC_MISS_sum", 0) > 0:
+                roof["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+            roof["pmc"] = pmc["source"]
         out = {
             "metric": "Mrays/s (extension + shadow rays), ~1M-tri Mitsuba-style scene at 1080p",
             "value": rays / elapsed / 1e6,
@@ -283,24 +334,7 @@ def main():
                 "bvh_build_ms": st["bvh_build_ms"],
                 "scene_upload_ms": upload_s * 1e3,
             },
-            "roofline": {
-                "kernel": "k_trace<ExtendIO> (closest-hit traversal of the 4-wide BVH)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "bytes_per_ray": b_ray,
-                "nodes_per_ray": nodes_per_ray,
-                "tris_per_ray": tris_per_ray,
-                "launches": int(launches),
-                "avg_launch_ms": ext_ms / launches,
-                "algorithmic_bytes_per_launch": alg_bytes / launches,
-                "extend_ms": ext_ms,
-                "shade_ms": st["shade_kernel_ms"],
-                "connect_ms": st["connect_kernel_ms"],
-            },
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args, scene_name)

@@ -106,6 +106,25 @@ def main(root):
             calib[k] = {"known_bytes": known, "fetch_size_bytes": counter_bytes, "known_over_counter": known / max(1.0, counter_bytes)}
             print("   %-12s known %.1f MB, FETCH_SIZE %.1f MB -> known / counter = %.3f" % (k, known / 1e6, counter_bytes / 1e6, known / max(1.0, counter_bytes)))
         out["fetch_calibration"] = calib
+    # ---- which bench run this was: the JSON line bench.py printed under the kernel-trace pass
+    for log in ("trace.log", "grbm.log", "sq1.log"):
+        try:
+            lines = [l for l in open(os.path.join(root, log)) if l.startswith('{"metric"')]
+        except OSError:
+            continue
+        if lines:
+            b = json.loads(lines[-1])
+            out["bench_config"] = {k: b["config"][k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
+            out["steps"], out["warmup"] = b["steps"], b["warmup"]
+            out["timed_launches"] = b["roofline"]["launches"]
+            out["bench_value_under_profiler"] = b["value"]
+            print("== bench under the kernel-trace pass: %.1f %s, %d timed k_trace<ExtendIO> launches of %.3f ms (HIP events)" % (
+                b["value"], b["unit"], b["roofline"]["launches"], b["roofline"]["avg_launch_ms"]))
+            k = out["kernels"].get("k_trace_extend")
+            if k and len(k["trace_us"]) >= out["timed_launches"]:
+                t = k["trace_us"][-out["timed_launches"]:]
+                print("   rocprofv3 kernel trace, the same %d launches: avg %.3f ms" % (len(t), sum(t) / len(t) / 1e3))
+            break
     json.dump(out, open(os.path.join(root, "pmc_bench.json"), "w"))
 
 
