@@ -948,7 +948,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   }
   if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[1], st));
   const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
-      1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (1024 / kShadeBlock)));
+      1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (GSP_SHADE_MINWAVES * 256 / kShadeBlock)));  // the resident blocks
   hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], L.hits.p,
                      Q[cur ^ 1], SQ, L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
   CTX_TRY(ctx, hipGetLastError());
