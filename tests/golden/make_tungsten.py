@@ -14,7 +14,7 @@ gamma 2.2 the Mitsuba XML's <film> block names.  Evidence, from the Cornell box 
 integrator, this repository's renders and an unbiased path tracer must agree to within the reference's small MIS
 bias): under gamma-2.2 linearisation the blue channel of every lit wall is 3x off and unlit regions 6-60x, with no
 single exposure that fits; under the inverse filmic curve all three channels of all lit walls agree with the HIP
-render to 1-5 % (profiles/r02_tungsten_cornell.txt).  The curve is inverted in closed form below.
+render to 1-5 % (profiles/r02_tungsten_compare.txt).  The curve is inverted in closed form below.
 
 Per scene the file holds: `lin` [h/8, w/8, 3] linear radiance, `sat` [h/8, w/8, 3] = some pixel of the 8x8 block is
 clipped (>= 254) or in the toe (<= 2) in that channel of the PNG, i.e. the block's radiance is not recoverable.

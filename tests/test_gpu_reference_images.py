@@ -4,7 +4,7 @@ renders shipped beside its scenes (tests/golden/ref_scenes/tungsten_*.npz, linea
 This is independent of the CPU oracle: nothing under oracle/ is used here.  It cannot be a bit-parity test -- Tungsten
 is an unbiased path tracer with a tent pixel filter, the reference integrator has its documented MIS quirks and a
 firefly clamp, and the PNGs are 8-bit tone-mapped -- so every check states the band it allows and where
-the numbers it was chosen from are (profiles/r02_tungsten_*.txt, measured at 1024 spp).
+the numbers it was chosen from are (profiles/r02_tungsten_compare.txt, measured at 1024 spp).
 
 Frames are rendered at the scene's own film size, then box-filtered 8x8 like the fixtures and compared on cells of
 16x16 such blocks (128x128 pixels); a cell takes part per channel when at least a quarter of its blocks are
