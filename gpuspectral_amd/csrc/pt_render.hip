@@ -55,18 +55,22 @@ struct ShadowQueue {
   q4* S3;
 };
 
-// device counter words: [0] next-queue size, [1] shadow-queue size, k_finish's ray totals, [C_LIVE, C_LIVE + kMaxSlots)
-// live paths per sample slot, then the ray hand-out counters of the extend and connect launches (kWorkShards words
-// each, on separate 128-B lines).  Words [0, C_READBACK) travel to the host once per iteration.
+// Device counter words of a pipeline lane.  Two TAIL SETS of 32 words (one 128-B line each), used alternately by
+// successive iterations: iteration i appends to the queues whose tails live in set i & 1 and reads its own input size from
+// set (i - 1) & 1, so the host can queue iteration i + 1 before it has seen iteration i's counters.  Then the live-path
+// counters of the sample slots, then the ray hand-out counters of the extend and connect launches (kWorkShards words each,
+// on separate 128-B lines; one set: launches of one stream run in order).  Words [0, C_READBACK) travel to the host once
+// per iteration.
 // kMaxSlots: a slot of the sample-result ring is held from the injection of its batch until the batch's LAST path has
 // ended (up to 52 bounces later) although ~95 % of its paths end within a few bounces, so the number of slots -- not
 // the path pool -- bounds the paths in flight on scenes with short paths: with 64 slots the reference's coffee scene
 // (4.2 rays per sample) ran 3 M-path launches in a 32 M-path pool (profiles/r02_scene_probe.txt).
 constexpr int kMaxSlots = 1024;
-enum { C_NEXT = 0, C_SHADOW = 1, C_TAIL_EXT = 2, C_TAIL_SH = 4, C_LIVE = 8, C_READBACK = C_LIVE + kMaxSlots,
+constexpr int kTailSet = 32;  // words per tail set
+enum { T_NEXT = 0, T_SHADOW = 1, T_FIN_EXT = 2, T_FIN_SH = 4 };  // within a tail set (the two 64-bit k_finish totals are 8-byte aligned)
+enum { C_LIVE = 2 * kTailSet, C_READBACK = C_LIVE + kMaxSlots,
        C_WORK_EXT = ((C_READBACK + 31) / 32) * 32, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
        C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
-static_assert((C_TAIL_EXT % 2) == 0 && (C_TAIL_SH % 2) == 0 && C_TAIL_SH + 2 <= C_LIVE, "counter layout");
 struct DevStats {
   unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays;
 };
@@ -197,10 +201,12 @@ constexpr int kShadeWaves = kShadeBlock / 64;
 #ifndef GSP_SHADE_MINWAVES
 #define GSP_SHADE_MINWAVES 4  // 128 VGPRs: 4 blocks of 256 threads per CU
 #endif
-__global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(SceneView S, RenderConsts rc, uint32_t n, PathQueue cur,
+__global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(SceneView S, RenderConsts rc, const uint32_t* __restrict__ n_ptr, PathQueue cur,
                                                         const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
-                                                        q4* __restrict__ result, uint32_t* __restrict__ counters,
+                                                        q4* __restrict__ result, uint32_t* __restrict__ tails,
+                                                        uint32_t* __restrict__ live,
                                                         uint32_t slot_paths, DevStats* __restrict__ stats) {
+  const uint32_t n = *n_ptr;  // written by the previous iteration's k_shade / the host's memset (stream order)
   __shared__ uint32_t s_dead[kMaxSlots];
   __shared__ uint32_t s_bin[12];               // counting sort of the tile by BSDF type: counts, then starts
   __shared__ uint16_t s_order[kShadeBlock];    // sorted position -> thread offset inside the tile
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       const int q = threadIdx.x;
       uint32_t tot = 0;
       for (int w = 0; w < kShadeWaves; ++w) tot += s_cnt[q][w];
-      uint32_t base = tot ? atomicAdd(&counters[q == 0 ? C_NEXT : C_SHADOW], tot) : 0u;
+      uint32_t base = tot ? atomicAdd(&tails[q == 0 ? T_NEXT : T_SHADOW], tot) : 0u;
       for (int w = 0; w < kShadeWaves; ++w) {
         s_base[q][w] = base;
         base += s_cnt[q][w];
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxSlots; k += kShadeBlock)
-    if (s_dead[k]) atomicSub(&counters[C_LIVE + k], s_dead[k]);
+    if (s_dead[k]) atomicSub(&live[k], s_dead[k]);
   shaded = wave_sum(shaded);
   if (lane == 0 && shaded) atomicAdd(&stats->shaded, shaded);
 }
@@ -357,7 +363,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
 constexpr uint32_t kFinishPaths = 262144;  // scan 0 / 64 k / 256 k / 1 M: 8-spp call 62 / 56 / 54 / 56 ms, 500x500 1-spp frames 88 / 138 / 182 / 184 per s
 
 __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc, uint32_t n, PathQueue q,
-                                                    q4* __restrict__ result, uint32_t* __restrict__ counters,
+                                                    q4* __restrict__ result, uint32_t* __restrict__ tails,
+                                                    uint32_t* __restrict__ live,
                                                     uint32_t slot_paths, DevStats* __restrict__ stats) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   unsigned long long ext = 0, sh = 0, shaded = 0;
@@ -396,14 +403,14 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
       in = out.next;
     }
     result[sid] = res;
-    atomicSub(&counters[C_LIVE + sid / slot_paths], 1u);
+    atomicSub(&live[sid / slot_paths], 1u);
   }
   ext = wave_sum(ext);
   sh = wave_sum(sh);
   shaded = wave_sum(shaded);
   if ((threadIdx.x & 63) == 0) {
-    if (ext) atomicAdd((unsigned long long*)(counters + C_TAIL_EXT), ext);
-    if (sh) atomicAdd((unsigned long long*)(counters + C_TAIL_SH), sh);
+    if (ext) atomicAdd((unsigned long long*)(tails + T_FIN_EXT), ext);
+    if (sh) atomicAdd((unsigned long long*)(tails + T_FIN_SH), sh);
     if (shaded) atomicAdd(&stats->shaded, shaded);
   }
 }
@@ -504,8 +511,10 @@ struct gsp_context {
     uint32_t num_slots = 0;
     std::deque<Batch> inflight;
     std::vector<char> slot_used;
-    uint64_t n = 0;
-    int cur = 0;
+    uint64_t n = 0;   // paths the next iteration to be queued will trace: exact when no iteration is in flight, else an upper bound
+    double n_est = 0.0;    // ... and the expected number (survival ratio of the last iterations seen)
+    double survive = 0.9;  // share of an iteration's paths that continue (running estimate)
+    int cur = 0;      // queue buffer that holds them
     uint32_t iteration = 0;
     uint32_t next_ts = 0, remaining = 0;
     uint32_t folded_end = 0;  // one past the last timestamp folded into the accumulate buffer
@@ -525,13 +534,21 @@ struct gsp_context {
     DevBuf<uint32_t> FL[2];
     DevBuf<uint32_t> counters;
     DevBuf<int32_t> spill;
-    uint32_t* h_counters = nullptr;  // pinned
-    std::vector<hipEvent_t> ev;
+    uint32_t* h_counters = nullptr;  // pinned: one read-back buffer of C_READBACK words per iteration parity
+    hipEvent_t done[2] = {nullptr, nullptr};  // that read-back has landed
+    std::vector<hipEvent_t> ev;      // 2 x 4 kernel-timing events (collect_kernel_times)
     Pipeline pipe;
-    bool in_flight = false;   // an iteration is queued on `stream` and its counters have not been read back
-    uint64_t it_n = 0;        // paths of that iteration
-    bool it_timing = false;
-    bool it_finish = false;   // that iteration was k_finish: every remaining path ran to its end
+    // Iterations in flight: queued on `stream`, counters not yet read by the host.  Up to kPipeDepth of them, so the GPU
+    // starts iteration i + 1 the moment iteration i ends instead of waiting for the host to wake up, read 4 KB and launch.
+    struct Iter {
+      bool traced = false, timing = false, finish = false;
+      uint64_t injected = 0;  // paths generated into the queue that the following iteration traces
+    } it[2];
+    uint32_t queued = 0;       // iterations in flight (0 .. kPipeDepth)
+    uint32_t enq = 0, col = 0; // running index of the next iteration to queue / to collect (parity picks the tail set)
+    uint64_t n_in = 0;         // EXACT input size of iteration `col`
+    std::vector<uint32_t> h_live;      // host mirror of the slots' live counters
+    std::vector<uint32_t> live_since;  // per slot: iteration whose read-back is the first to show the slot's current batch
   };
   static constexpr int kMaxLanes = 2;
   Lane lanes[kMaxLanes];
@@ -661,8 +678,11 @@ int gsp_ctx_create(int device, gsp_context** out) {
     gsp_context::Lane& L = c->lanes[l];
     L.index = l;
     e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&L.h_counters, C_READBACK * sizeof(uint32_t), hipHostMallocDefault);
-    if (e == hipSuccess) std::memset(L.h_counters, 0, C_READBACK * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&L.h_counters, 2 * C_READBACK * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) std::memset(L.h_counters, 0, 2 * C_READBACK * sizeof(uint32_t));
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&L.done[k], hipEventDisableTiming);
+    L.h_live.assign(kMaxSlots, 0);
+    L.live_since.assign(kMaxSlots, 0);
   }
   if (e != hipSuccess) {
     set_create_error(std::string("context setup: ") + hipGetErrorString(e));
@@ -681,6 +701,8 @@ void gsp_ctx_destroy(gsp_context* ctx) {
   for (gsp_context::Lane& L : ctx->lanes) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
     for (hipEvent_t e : L.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : L.done)
+      if (e) (void)hipEventDestroy(e);
     if (L.h_counters) (void)hipHostFree(L.h_counters);
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
@@ -865,8 +887,19 @@ static RenderConsts render_consts(const gsp_context* ctx) {
   return rcst;
 }
 
-// Queues one iteration of a lane on its stream without waiting: new batches while there is room, then
-// extend / shade / connect over the lane's dense queues and the copy of its counters to the host.
+#ifndef GSP_PIPE_DEPTH
+#define GSP_PIPE_DEPTH 2  // iterations queued ahead of the host's view of the counters (1 = wait for every read-back)
+#endif
+constexpr uint32_t kPipeDepth = GSP_PIPE_DEPTH;
+static_assert(kPipeDepth >= 1 && kPipeDepth <= 2, "two tail sets / read-back buffers");
+
+// Queues one iteration of a lane on its stream without waiting.  Iteration i:
+//   tails[i & 1] := {next-queue size = paths injected now, shadow-queue size = 0}
+//   k_generate   new batches (while the pool has room and ring slots are free) at the FRONT of the next queue
+//   k_trace<Extend> / k_shade / k_trace<Connect> over the current queue, whose size they read from tails[(i - 1) & 1]
+//                   on the device; survivors are appended behind the injected paths
+//   copy of the counter words to the host buffer of this parity + an event
+// `exact` = no iteration is in flight, so P.n is the true queue size (and 0 means there is nothing to trace).
 static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderConsts& rcst, const SceneView& view, bool drain) {
   gsp_context::Pipeline& P = L.pipe;
   hipStream_t st = L.stream;
@@ -875,139 +908,172 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   const uint64_t batch_paths = P.batch_paths;
   const bool stats_mode = rp->collect_traversal_stats != 0;
   const bool timing = rp->collect_kernel_times != 0;  // per-kernel HIP event timing (bench)
-  while (timing && L.ev.size() < 4) {
+  while (timing && L.ev.size() < 8) {
     hipEvent_t e;
     CTX_TRY(ctx, hipEventCreate(&e));
     L.ev.push_back(e);
   }
+  const uint32_t t = L.enq & 1u;
+  const bool exact = L.queued == 0;
+  uint32_t* tails_in = L.counters.p + kTailSet * (t ^ 1u);
+  uint32_t* tails_out = L.counters.p + kTailSet * t;
+  uint32_t* live = L.counters.p + C_LIVE;
+  hipEvent_t* ev = timing ? &L.ev[4 * t] : nullptr;
   PathQueue Q[2];
   for (int k = 0; k < 2; ++k) Q[k] = PathQueue{L.P0[k].p, L.P1[k].p, L.P2[k].p, L.FL[k].p};
   ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p};
   const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
-
-  // ---- inject new batches while there is room ----
-  while (P.remaining > 0 && P.n < P.pool_target) {
-    const uint32_t kb = (uint32_t)std::min<uint64_t>(P.Kb, P.remaining);
-    uint32_t slot = P.num_slots;
-    for (uint32_t s2 = 0; s2 < P.num_slots; ++s2)
-      if (!P.slot_used[s2]) {
-        slot = s2;
-        break;
-      }
-    if (slot == P.num_slots || P.n + (uint64_t)kb * npix > P.cap) break;
-    const uint64_t paths = (uint64_t)kb * npix;
-    hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
-                       ctx->subset ? ctx->pixel_ids.p : nullptr, Q[P.cur], (uint32_t)P.n, (uint32_t)(slot * batch_paths),
-                       L.result.p, L.index, ctx->num_lanes);
-    CTX_TRY(ctx, hipGetLastError());
-    CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(L.counters.p + C_LIVE + slot), (int)paths, 1, st));
-    L.h_counters[C_LIVE + slot] = (uint32_t)paths;  // not resolvable before the next read-back
-    P.slot_used[slot] = 1;
-    P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot});
-    P.n += paths;
-    P.next_ts += kb;
-    P.remaining -= kb;
-  }
-  if (P.n == 0) return GSP_OK;
-  const uint64_t n = P.n;
+  const uint64_t n = P.n;  // exact, or an upper bound of what this iteration traces
   const int cur = P.cur;
-  L.it_finish = false;
-  if (drain && P.remaining == 0 && n <= ctx->finish_paths && !stats_mode && 3 * ctx->bvh.depth + 4 <= (uint32_t)kLaneStackDepth) {
+  gsp_context::Lane::Iter& I = L.it[t];
+  I = gsp_context::Lane::Iter{};
+
+  CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
+  if (drain && exact && P.remaining == 0 && n > 0 && n <= ctx->finish_paths && !stats_mode &&
+      3 * ctx->bvh.depth + 4 <= (uint32_t)kLaneStackDepth) {
     // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
     // on its own lane (not when gsp_render merely queues work: those paths ride along with the next call's)
-    CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, 2 * sizeof(uint32_t), st));
-    CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_TAIL_EXT, 0, (C_LIVE - C_TAIL_EXT) * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_finish, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
-                       L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
+                       L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
     CTX_TRY(ctx, hipGetLastError());
-    CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, C_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    L.in_flight = true;
-    L.it_n = n;
-    L.it_timing = false;
-    L.it_finish = true;
-    return GSP_OK;
+    I.finish = true;
+  } else {
+    // ---- inject new batches while there is room: into the next queue, in front of this iteration's survivors ----
+    // (the next iteration traces this one's survivors + what is injected now: aim that sum at the pool target with the
+    // expected survivors, check the buffers against the upper bound)
+    const double expect = (exact ? (double)n : std::min((double)n, P.n_est)) * P.survive;
+    uint64_t inj = 0;
+    while (P.remaining > 0 && expect + (double)inj < (double)P.pool_target) {
+      const uint32_t kb = (uint32_t)std::min<uint64_t>(P.Kb, P.remaining);
+      uint32_t slot = P.num_slots;
+      for (uint32_t s2 = 0; s2 < P.num_slots; ++s2)
+        if (!P.slot_used[s2]) {
+          slot = s2;
+          break;
+        }
+      const uint64_t paths = (uint64_t)kb * npix;
+      if (slot == P.num_slots || n + inj + paths > P.cap) break;
+      hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
+                         ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur ^ 1], (uint32_t)inj, (uint32_t)(slot * batch_paths),
+                         L.result.p, L.index, ctx->num_lanes);
+      CTX_TRY(ctx, hipGetLastError());
+      CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(live + slot), (int)paths, 1, st));
+      L.h_live[slot] = (uint32_t)paths;
+      L.live_since[slot] = L.enq;  // read-backs of earlier iterations still show the slot's previous state
+      P.slot_used[slot] = 1;
+      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot});
+      inj += paths;
+      P.next_ts += kb;
+      P.remaining -= kb;
+    }
+    if (inj) CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(tails_out + T_NEXT), (int)inj, 1, st));
+    I.injected = inj;
+    if (!(exact && n == 0)) {
+      const uint32_t chunk = n >= (1u << 20) ? kChunkLarge : kChunkSmall;
+      const uint32_t grid = ctx->trace_grid(std::max<uint64_t>(n, 1), chunk);
+      CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_WORK_EXT, 0, (C_COUNT - C_WORK_EXT) * sizeof(uint32_t), st));
+      if (timing) CTX_TRY(ctx, hipEventRecord(ev[0], st));
+      {
+        const ExtendIO io{Q[cur], L.hits.p};
+        uint32_t* work = L.counters.p + C_WORK_EXT;
+        if (stats_mode)
+          hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                             view.root, (const uint32_t*)(tails_in + T_NEXT), 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
+                             so_ext);
+        else
+          hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                             view.root, (const uint32_t*)(tails_in + T_NEXT), 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
+                             so_ext);
+        CTX_TRY(ctx, hipGetLastError());
+      }
+      if (timing) CTX_TRY(ctx, hipEventRecord(ev[1], st));
+      const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
+          1, std::min<uint64_t>((std::max<uint64_t>(n, 1) + kShadeBlock - 1) / kShadeBlock,
+                                (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (GSP_SHADE_MINWAVES * 256 / kShadeBlock)));  // the resident blocks
+      hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
+                         L.hits.p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+      CTX_TRY(ctx, hipGetLastError());
+      if (timing) CTX_TRY(ctx, hipEventRecord(ev[2], st));
+      {
+        const ConnectIO io{SQ, Q[cur ^ 1].P2, L.result.p, rcst.clamp};
+        uint32_t* work = L.counters.p + C_WORK_SH;
+        if (stats_mode)
+          hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                             view.root, (const uint32_t*)(tails_out + T_SHADOW), 0u, chunk, io, work, L.spill.p,
+                             ctx->spill_stride, so_sh);
+        else
+          hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+                             view.root, (const uint32_t*)(tails_out + T_SHADOW), 0u, chunk, io, work, L.spill.p,
+                             ctx->spill_stride, so_sh);
+        CTX_TRY(ctx, hipGetLastError());
+      }
+      if (timing) CTX_TRY(ctx, hipEventRecord(ev[3], st));
+      I.traced = true;
+      I.timing = timing;
+    }
   }
-  const uint32_t chunk = n >= (1u << 20) ? kChunkLarge : kChunkSmall;
-  const uint32_t grid = ctx->trace_grid(n, chunk);
-  CTX_TRY(ctx, hipMemsetAsync(L.counters.p, 0, 2 * sizeof(uint32_t), st));
-  CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_WORK_EXT, 0, (C_COUNT - C_WORK_EXT) * sizeof(uint32_t), st));
-  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[0], st));
-  {
-    const ExtendIO io{Q[cur], L.hits.p};
-    uint32_t* work = L.counters.p + C_WORK_EXT;
-    if (stats_mode)
-      hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                         view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, L.spill.p, ctx->spill_stride,
-                         so_ext);
-    else
-      hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                         view.root, (const uint32_t*)nullptr, (uint32_t)n, chunk, io, work, L.spill.p, ctx->spill_stride,
-                         so_ext);
-    CTX_TRY(ctx, hipGetLastError());
-  }
-  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[1], st));
-  const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
-      1, std::min<uint64_t>((n + kShadeBlock - 1) / kShadeBlock, (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (GSP_SHADE_MINWAVES * 256 / kShadeBlock)));  // the resident blocks
-  hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], L.hits.p,
-                     Q[cur ^ 1], SQ, L.result.p, L.counters.p, (uint32_t)batch_paths, ctx->dstats.p);
-  CTX_TRY(ctx, hipGetLastError());
-  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[2], st));
-  {
-    const ConnectIO io{SQ, Q[cur ^ 1].P2, L.result.p, rcst.clamp};
-    uint32_t* work = L.counters.p + C_WORK_SH;
-    if (stats_mode)
-      hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                         view.root, (const uint32_t*)(L.counters.p + C_SHADOW), 0u, chunk, io, work, L.spill.p,
-                         ctx->spill_stride, so_sh);
-    else
-      hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                         view.root, (const uint32_t*)(L.counters.p + C_SHADOW), 0u, chunk, io, work, L.spill.p,
-                         ctx->spill_stride, so_sh);
-    CTX_TRY(ctx, hipGetLastError());
-  }
-  if (timing) CTX_TRY(ctx, hipEventRecord(L.ev[3], st));
-  CTX_TRY(ctx, hipMemcpyAsync(L.h_counters, L.counters.p, C_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  L.in_flight = true;
-  L.it_n = n;
-  L.it_timing = timing;
+  CTX_TRY(ctx, hipMemcpyAsync(L.h_counters + (size_t)t * C_READBACK, L.counters.p, C_READBACK * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, st));
+  CTX_TRY(ctx, hipEventRecord(L.done[t], st));
+  ++L.queued;
+  ++L.enq;
+  P.cur ^= 1;
+  P.n = (I.finish ? 0 : n) + I.injected;  // survivors <= n: an upper bound of the next iteration's input until the read-back says more
+  P.n_est = (I.finish ? 0.0 : (exact ? (double)n : std::min((double)n, P.n_est)) * P.survive) + (double)I.injected;
   return GSP_OK;
 }
 
-// Waits for the lane's queued iteration, reads its counters and folds finished batches into the
+// Waits for the lane's oldest queued iteration, reads its counters and folds finished batches into the
 // accumulate buffer, strictly in timestamp order.
 static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
   gsp_context::Pipeline& P = L.pipe;
   hipStream_t st = L.stream;
-  if (L.in_flight) {
-    CTX_TRY(ctx, hipStreamSynchronize(st));
+  if (L.queued) {
+    const uint32_t t = L.col & 1u;
+    CTX_TRY(ctx, hipEventSynchronize(L.done[t]));
     CTX_TRY(ctx, hipGetLastError());
-    L.in_flight = false;
-    if (L.it_finish) {
-      ctx->stats.extension_rays += (uint64_t)L.h_counters[C_TAIL_EXT] | ((uint64_t)L.h_counters[C_TAIL_EXT + 1] << 32);
-      ctx->stats.shadow_rays += (uint64_t)L.h_counters[C_TAIL_SH] | ((uint64_t)L.h_counters[C_TAIL_SH + 1] << 32);
-    } else {
-      ctx->stats.extension_rays += L.it_n;
-      ctx->stats.shadow_rays += L.h_counters[C_SHADOW];
+    const uint32_t* rb = L.h_counters + (size_t)t * C_READBACK;
+    const uint32_t* tails = rb + kTailSet * t;
+    const gsp_context::Lane::Iter I = L.it[t];
+    const uint64_t n_traced = L.n_in;
+    if (I.finish) {
+      ctx->stats.extension_rays += (uint64_t)tails[T_FIN_EXT] | ((uint64_t)tails[T_FIN_EXT + 1] << 32);
+      ctx->stats.shadow_rays += (uint64_t)tails[T_FIN_SH] | ((uint64_t)tails[T_FIN_SH + 1] << 32);
+    } else if (I.traced) {
+      ctx->stats.extension_rays += n_traced;
+      ctx->stats.shadow_rays += tails[T_SHADOW];
     }
     const uint32_t bounce = P.iteration++;
-    if (L.it_timing) {
+    if (I.timing) {
       float ms = 0.0f, e_ms = 0.0f, s_ms = 0.0f;
-      CTX_TRY(ctx, hipEventElapsedTime(&e_ms, L.ev[0], L.ev[1]));
+      hipEvent_t* ev = &L.ev[4 * t];
+      CTX_TRY(ctx, hipEventElapsedTime(&e_ms, ev[0], ev[1]));
       ctx->stats.extend_kernel_ms += e_ms;
       ctx->stats.extend_launches += 1;
-      CTX_TRY(ctx, hipEventElapsedTime(&s_ms, L.ev[1], L.ev[2]));
+      CTX_TRY(ctx, hipEventElapsedTime(&s_ms, ev[1], ev[2]));
       ctx->stats.shade_kernel_ms += s_ms;
-      CTX_TRY(ctx, hipEventElapsedTime(&ms, L.ev[2], L.ev[3]));
+      CTX_TRY(ctx, hipEventElapsedTime(&ms, ev[2], ev[3]));
       ctx->stats.connect_kernel_ms += ms;
       if (getenv("GSP_TRACE_BOUNCES"))
-        fprintf(stderr, "lane %u iter %3u: n %9llu shadow %9u inflight %2zu | extend %8.3f ms shade %8.3f ms connect %8.3f ms\n",
-                L.index, bounce, (unsigned long long)L.it_n, L.h_counters[C_SHADOW], P.inflight.size(), e_ms, s_ms, ms);
+        fprintf(stderr, "lane %u iter %3u: n %9llu shadow %9u injected %9llu inflight %2zu | extend %8.3f ms shade %8.3f ms connect %8.3f ms\n",
+                L.index, bounce, (unsigned long long)n_traced, tails[T_SHADOW], (unsigned long long)I.injected, P.inflight.size(), e_ms, s_ms, ms);
     }
-    P.n = L.h_counters[C_NEXT];
-    P.cur ^= 1;
+    // the input size of the next iteration, exactly: injected paths + survivors
+    if (I.traced && n_traced > 0) {
+      const double r = ((double)tails[T_NEXT] - (double)I.injected) / (double)n_traced;
+      P.survive = 0.5 * P.survive + 0.5 * std::min(1.0, std::max(0.0, r));
+    }
+    L.n_in = tails[T_NEXT];
+    for (const gsp_context::Batch& b : P.inflight)
+      if (L.live_since[b.slot] <= L.col) L.h_live[b.slot] = rb[C_LIVE + b.slot];
+    ++L.col;
+    --L.queued;
+    // what the next iteration to be QUEUED will trace: exact if nothing is in flight, else bounded through the one that is
+    P.n = L.queued ? L.n_in + L.it[L.col & 1u].injected : L.n_in;
+    P.n_est = L.queued ? (double)L.n_in * P.survive + (double)L.it[L.col & 1u].injected : (double)L.n_in;
   }
-  while (!P.inflight.empty() && L.h_counters[C_LIVE + P.inflight.front().slot] == 0) {
+  while (!P.inflight.empty() && L.h_live[P.inflight.front().slot] == 0) {
     const gsp_context::Batch b = P.inflight.front();
     P.inflight.pop_front();
     hipLaunchKernelGGL(k_resolve, dim3(ctx->grid_for(L.num_pixels)), dim3(kBlock), 0, st, (uint32_t)L.num_pixels, b.kb, b.t0,
@@ -1017,7 +1083,7 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
     P.folded_end = b.t0 + b.kb;
     ctx->stats.samples += (uint64_t)b.kb * L.num_pixels;
   }
-  if (P.n == 0 && P.remaining == 0 && !P.inflight.empty()) {
+  if (L.queued == 0 && P.n == 0 && P.remaining == 0 && !P.inflight.empty()) {
     ctx->err = "internal error: paths exhausted with unresolved sample batches";
     return GSP_ERR_DEVICE;
   }
@@ -1027,8 +1093,8 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
 // Runs the streaming pipelines.  drain == false: returns as soon as every queued sample has been
 // injected (stragglers of the last batches stay in flight and ride along with the next call's
 // launches); drain == true: runs until nothing is in flight and every batch has been folded into the
-// accumulate buffer.  The lanes alternate: while the host waits for one lane's counters the other
-// lane's iteration is already queued.
+// accumulate buffer.  While samples remain to be injected each lane keeps kPipeDepth iterations queued, so the GPU
+// never waits for the host; the tail of a drain (exact path counts decide k_finish and the end) runs one at a time.
 static int pipeline_run(gsp_context* ctx, bool drain) {
   if (!ctx->pipe_active) return GSP_OK;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -1038,36 +1104,43 @@ static int pipeline_run(gsp_context* ctx, bool drain) {
     const gsp_context::Pipeline& P = L.pipe;
     return P.active && (P.remaining > 0 || (drain && (P.n > 0 || !P.inflight.empty())));
   };
-  uint32_t turn = 0;
+  auto depth_for = [&](const gsp_context::Lane& L) { return L.pipe.remaining > 0 && !ctx->pipe_params.collect_traversal_stats ? kPipeDepth : 1u; };
   for (;;) {
+    bool any = false;
     for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
       gsp_context::Lane& L = ctx->lanes[l];
-      if (!L.in_flight && has_work(L)) {
+      if (!L.pipe.active) continue;
+      while (has_work(L) && L.queued < depth_for(L)) {
+        if (L.queued == 0 && L.pipe.n == 0 && L.pipe.remaining == 0) break;  // nothing to trace: only batches to fold
         int rc = lane_enqueue(ctx, L, rcst, view, drain);
         if (rc != GSP_OK) return rc;
-        if (!L.in_flight) {  // nothing left to trace: only batches to fold
-          rc = lane_collect(ctx, L);
-          if (rc != GSP_OK) return rc;
-        }
       }
     }
-    int pick = -1;
-    for (uint32_t k = 0; k < ctx->num_lanes; ++k) {
-      const uint32_t l = (turn + k) % ctx->num_lanes;
-      if (ctx->lanes[l].in_flight) {
-        pick = (int)l;
-        break;
+    for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
+      gsp_context::Lane& L = ctx->lanes[l];
+      if (!L.pipe.active) continue;
+      if (L.queued) {
+        int rc = lane_collect(ctx, L);
+        if (rc != GSP_OK) return rc;
+        any = true;
+      } else if (has_work(L)) {  // only batches to fold
+        int rc = lane_collect(ctx, L);
+        if (rc != GSP_OK) return rc;
+        any = any || has_work(L);
       }
     }
-    if (pick < 0) {
-      bool more = false;
-      for (uint32_t l = 0; l < ctx->num_lanes; ++l) more = more || has_work(ctx->lanes[l]);
-      if (!more) break;
-      continue;
+    bool more = false;
+    for (uint32_t l = 0; l < ctx->num_lanes; ++l) more = more || has_work(ctx->lanes[l]) || (drain && ctx->lanes[l].queued);
+    if (!more) break;
+    if (!any) break;
+  }
+  // leave with nothing in flight: the host's view of every lane is exact again
+  for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
+    gsp_context::Lane& L = ctx->lanes[l];
+    while (L.pipe.active && L.queued) {
+      int rc = lane_collect(ctx, L);
+      if (rc != GSP_OK) return rc;
     }
-    int rc = lane_collect(ctx, ctx->lanes[pick]);
-    if (rc != GSP_OK) return rc;
-    turn = ((uint32_t)pick + 1) % ctx->num_lanes;
   }
   for (uint32_t l = 0; l < ctx->num_lanes; ++l) CTX_TRY(ctx, hipStreamSynchronize(ctx->lanes[l].stream));
   if (drain) {
@@ -1129,7 +1202,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       // (at most 128 samples per pixel in flight: tiny frames do not allocate gigabytes; a 1/8 tile share of a
       // 1080p frame, 259 k pixels, still fills the whole pool)
       P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 128 * npix), 2 * P.batch_paths);
-      P.cap = P.pool_target + P.batch_paths;
+      P.cap = 2 * P.pool_target + P.batch_paths;  // survivors (<= the previous queue) + a pool target's worth of new paths
       // Slots of the sample-result ring: a batch holds its slot until its last path has ended, so with paths of
       // ~3 bounces on average and a tail of 52 the alive share of the batches in flight is only a few percent and
       // the ring must hold ~24 x the pool for the pool to fill (coffee: 4.2 rays per sample).  16 B per entry, most
