@@ -17,7 +17,9 @@
 // one GPU): that is how the single-GPU test box exercises partition + gather + scatter.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -56,7 +58,12 @@ struct gsp_multi {
 
 namespace {
 
+std::mutex g_multi_err_mutex;
 std::string g_multi_create_error;
+void set_multi_create_error(const std::string& e) {
+  std::lock_guard<std::mutex> lk(g_multi_err_mutex);
+  g_multi_create_error = e;
+}
 
 // Runs fn(share) on one host thread per share and returns the first failing status (GSP_OK if none).
 template <class F>
@@ -68,7 +75,13 @@ int for_each_share(gsp_multi* m, F fn) {
   } else {
     std::vector<std::thread> th;
     th.reserve(n);
-    for (size_t r = 0; r < n; ++r) th.emplace_back([&, r] { rc[r] = fn(r); });
+    try {
+      for (size_t r = 0; r < n; ++r) th.emplace_back([&, r] { rc[r] = fn(r); });
+    } catch (const std::system_error& e) {  // could not start a host thread: the shares that did start still finish
+      for (auto& t : th) t.join();
+      m->err = std::string("cannot start a host thread per share: ") + e.what();
+      return GSP_ERR_NOMEM;
+    }
     for (auto& t : th) t.join();
   }
   for (size_t r = 0; r < n; ++r)
@@ -122,7 +135,13 @@ uint64_t gsp_tile_partition(uint32_t width, uint32_t height, uint32_t rank, uint
   return n;
 }
 
-const char* gsp_multi_last_error(const gsp_multi* m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+const char* gsp_multi_last_error(const gsp_multi* m) {
+  if (m) return m->err.c_str();
+  std::lock_guard<std::mutex> lk(g_multi_err_mutex);
+  static thread_local std::string copy;
+  copy = g_multi_create_error;
+  return copy.c_str();
+}
 
 void gsp_multi_destroy(gsp_multi* m) {
   if (!m) return;
@@ -139,7 +158,7 @@ int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
   if (!out) return GSP_ERR_INVALID;
   *out = nullptr;
   if (!devices || n <= 0 || n > 64) {
-    g_multi_create_error = "gsp_multi_create: need 1..64 devices";
+    set_multi_create_error("gsp_multi_create: need 1..64 devices");
     return GSP_ERR_INVALID;
   }
   gsp_multi* m = new gsp_multi();
@@ -148,7 +167,7 @@ int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
     gsp_context* c = nullptr;
     int rc = gsp_ctx_create(devices[r], &c);
     if (rc != GSP_OK) {
-      g_multi_create_error = std::string("share ") + std::to_string(r) + ": " + gsp_last_error(nullptr);
+      set_multi_create_error(std::string("share ") + std::to_string(r) + ": " + gsp_last_error(nullptr));
       gsp_multi_destroy(m);
       return rc;
     }
@@ -160,15 +179,14 @@ int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
     int can = 0;
     if (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) == hipSuccess && can) {
       (void)hipSetDevice(devices[r]);
-      hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // copies fall back to staging through the host
-      else (void)hipGetLastError();
+      (void)hipDeviceEnablePeerAccess(devices[0], 0);  // "already enabled" is fine; without peer access the runtime
+      (void)hipGetLastError();                         // stages the device-to-device copy through the host
     }
   }
   hipError_t e = hipSetDevice(devices[0]);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
-    g_multi_create_error = std::string("gsp_multi_create: ") + hipGetErrorString(e);
+    set_multi_create_error(std::string("gsp_multi_create: ") + hipGetErrorString(e));
     gsp_multi_destroy(m);
     return GSP_ERR_DEVICE;
   }
