@@ -1202,13 +1202,29 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       // (at most 128 samples per pixel in flight: tiny frames do not allocate gigabytes; a 1/8 tile share of a
       // 1080p frame, 259 k pixels, still fills the whole pool)
       P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 128 * npix), 2 * P.batch_paths);
+      uint64_t ring_bytes = 16ull << 30;
+      if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
+      {
+        // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline
+        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  184 B of queues per
+        // path of capacity (2 x 52-B path records, 16-B hit, 64-B shadow record), capacity = 2 x the pool target.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+          const uint64_t have = L.pool_cap * 184ull + L.result_cap * sizeof(q4);
+          const uint64_t budget = (uint64_t)((double)free_b * 0.4) + have;
+          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 184ull;
+          if (queues > budget / 2) {
+            const uint64_t fit = budget / 2 / 184ull;  // paths of capacity that fit
+            P.pool_target = std::max<uint64_t>(2 * P.batch_paths, fit > P.batch_paths ? (fit - P.batch_paths) / 2 : 0);
+          }
+          ring_bytes = std::min<uint64_t>(ring_bytes, std::max<uint64_t>(budget / 2, 4 * P.batch_paths * sizeof(q4)));
+        }
+      }
       P.cap = 2 * P.pool_target + P.batch_paths;  // survivors (<= the previous queue) + a pool target's worth of new paths
       // Slots of the sample-result ring: a batch holds its slot until its last path has ended, so with paths of
       // ~3 bounces on average and a tail of 52 the alive share of the batches in flight is only a few percent and
       // the ring must hold ~24 x the pool for the pool to fill (coffee: 4.2 rays per sample).  16 B per entry, most
       // of it never touched on scenes with long paths; bounded by GSP_RING_BYTES (default 16 GiB of the 288).
-      uint64_t ring_bytes = 16ull << 30;
-      if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
       const uint64_t want_slots = 24 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths);
       const uint64_t fit_slots = ring_bytes / ctx->num_lanes / (P.batch_paths * sizeof(q4));
       P.num_slots = (uint32_t)std::min<uint64_t>(kMaxSlots, std::max<uint64_t>(4, std::min(want_slots, fit_slots)));
