@@ -194,6 +194,7 @@ struct TestIO {  // gsp_trace
 #define GSP_SHADE_BLOCK 256
 #endif
 constexpr int kShadeBlock = GSP_SHADE_BLOCK;
+constexpr int kShadeTableBytes = 8192;  // BSDF + light tables up to this size are staged into LDS by k_shade
 constexpr int kShadeWaves = kShadeBlock / 64;
 #ifndef GSP_SHADE_GRID_MULT
 #define GSP_SHADE_GRID_MULT 1  // grid = exactly the resident blocks, each loops over tiles
@@ -207,6 +208,29 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
                                                         uint32_t* __restrict__ live,
                                                         uint32_t slot_paths, DevStats* __restrict__ stats) {
   const uint32_t n = *n_ptr;  // written by the previous iteration's k_shade / the host's memset (stream order)
+#ifndef GSP_NO_LDS_TABLES
+  // The BSDF and light tables of a scene are a few hundred bytes to a few KB, and every vertex makes two DEPENDENT
+  // fetches into them (material record after the shading packet, light record after the RNG draw): staged into LDS
+  // once per block those become ~64-cycle reads instead of L2 round trips in a kernel whose 4 waves per SIMD cannot
+  // hide them.
+  __shared__ uint4 s_tables[kShadeTableBytes / 16];
+  if (S.tables_bytes <= (uint32_t)kShadeTableBytes) {
+    const uint4* src = (const uint4*)S.tables;
+    for (uint32_t k = threadIdx.x; k < S.tables_bytes / 16; k += kShadeBlock) s_tables[k] = src[k];
+    const uint8_t* lb = (const uint8_t*)s_tables;
+    const uint8_t* gb = S.tables;
+    S.bsdf.diffuse = (const gsp_diffuse_bsdf*)(lb + ((const uint8_t*)S.bsdf.diffuse - gb));
+    S.bsdf.smooth_dielectric = (const gsp_smooth_dielectric_bsdf*)(lb + ((const uint8_t*)S.bsdf.smooth_dielectric - gb));
+    S.bsdf.smooth_conductor = (const gsp_smooth_conductor_bsdf*)(lb + ((const uint8_t*)S.bsdf.smooth_conductor - gb));
+    S.bsdf.smooth_plastic = (const gsp_smooth_plastic_bsdf*)(lb + ((const uint8_t*)S.bsdf.smooth_plastic - gb));
+    S.bsdf.rough_conductor = (const gsp_rough_conductor_bsdf*)(lb + ((const uint8_t*)S.bsdf.rough_conductor - gb));
+    S.bsdf.smooth_floor = (const gsp_smooth_floor_bsdf*)(lb + ((const uint8_t*)S.bsdf.smooth_floor - gb));
+    S.bsdf.rough_floor = (const gsp_rough_floor_bsdf*)(lb + ((const uint8_t*)S.bsdf.rough_floor - gb));
+    S.bsdf.rough_plastic = (const gsp_rough_plastic_bsdf*)(lb + ((const uint8_t*)S.bsdf.rough_plastic - gb));
+    S.lights = (const gsp_triangle_light*)(lb + ((const uint8_t*)S.lights - gb));
+  }
+  // (the barrier behind the s_dead initialisation below also publishes the staged tables)
+#endif
   __shared__ uint32_t s_dead[kMaxSlots];
   __shared__ uint32_t s_bin[12];               // counting sort of the tile by BSDF type: counts, then starts
   __shared__ uint16_t s_order[kShadeBlock];    // sorted position -> thread offset inside the tile
@@ -475,15 +499,11 @@ struct gsp_context {
   // scene
   bool have_scene = false;
   DeviceBvh bvh;
-  DevBuf<gsp_diffuse_bsdf> b0;
-  DevBuf<gsp_smooth_dielectric_bsdf> b1;
-  DevBuf<gsp_smooth_conductor_bsdf> b2;
-  DevBuf<gsp_smooth_plastic_bsdf> b3;
-  DevBuf<gsp_rough_conductor_bsdf> b4;
-  DevBuf<gsp_smooth_floor_bsdf> b5;
-  DevBuf<gsp_rough_floor_bsdf> b6;
-  DevBuf<gsp_rough_plastic_bsdf> b7;
-  DevBuf<gsp_triangle_light> lights;
+  // the eight BSDF tables and the light table live back to back in ONE allocation (16-B aligned each), so that a kernel
+  // can stage all of them into LDS with one cooperative copy when they are small (k_shade)
+  DevBuf<uint8_t> tables;
+  size_t table_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets: BSDF types 0..7, then the lights
+  size_t tables_bytes = 0;
   uint32_t num_lights = 0;
   gsp_camera camera{};
   double bvh_build_ms = 0.0;
@@ -563,15 +583,18 @@ struct gsp_context {
     v.nodes = bvh.nodes;
     v.tri_isect = bvh.tri_isect;
     v.tri_shade = bvh.tri_shade;
-    v.bsdf.diffuse = b0.p;
-    v.bsdf.smooth_dielectric = b1.p;
-    v.bsdf.smooth_conductor = b2.p;
-    v.bsdf.smooth_plastic = b3.p;
-    v.bsdf.rough_conductor = b4.p;
-    v.bsdf.smooth_floor = b5.p;
-    v.bsdf.rough_floor = b6.p;
-    v.bsdf.rough_plastic = b7.p;
-    v.lights = lights.p;
+    const uint8_t* tb = tables.p;
+    v.bsdf.diffuse = (const gsp_diffuse_bsdf*)(tb + table_off[0]);
+    v.bsdf.smooth_dielectric = (const gsp_smooth_dielectric_bsdf*)(tb + table_off[1]);
+    v.bsdf.smooth_conductor = (const gsp_smooth_conductor_bsdf*)(tb + table_off[2]);
+    v.bsdf.smooth_plastic = (const gsp_smooth_plastic_bsdf*)(tb + table_off[3]);
+    v.bsdf.rough_conductor = (const gsp_rough_conductor_bsdf*)(tb + table_off[4]);
+    v.bsdf.smooth_floor = (const gsp_smooth_floor_bsdf*)(tb + table_off[5]);
+    v.bsdf.rough_floor = (const gsp_rough_floor_bsdf*)(tb + table_off[6]);
+    v.bsdf.rough_plastic = (const gsp_rough_plastic_bsdf*)(tb + table_off[7]);
+    v.lights = (const gsp_triangle_light*)(tb + table_off[8]);
+    v.tables = tb;
+    v.tables_bytes = (uint32_t)tables_bytes;
     v.num_lights = num_lights;
     v.root = bvh.root;
     return v;
@@ -758,15 +781,27 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     acc += in.vertex_count / 3;
   }
   tri_first[sc->num_instances] = acc;
-  CTX_TRY(ctx, ctx->b0.upload(sc->diffuse_bsdfs, sc->num_bsdfs[0], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->b1.upload(sc->smooth_dielectric_bsdfs, sc->num_bsdfs[1], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->b2.upload(sc->smooth_conductor_bsdfs, sc->num_bsdfs[2], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->b3.upload(sc->smooth_plastic_bsdfs, sc->num_bsdfs[3], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->b4.upload(sc->rough_conductor_bsdfs, sc->num_bsdfs[4], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->b5.upload(sc->smooth_floor_bsdfs, sc->num_bsdfs[5], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->b6.upload(sc->rough_floor_bsdfs, sc->num_bsdfs[6], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->b7.upload(sc->rough_plastic_bsdfs, sc->num_bsdfs[7], st, &ctx->bytes));
-  CTX_TRY(ctx, ctx->lights.upload(sc->lights, sc->num_lights, st, &ctx->bytes));
+  {
+    const void* src[9] = {sc->diffuse_bsdfs, sc->smooth_dielectric_bsdfs, sc->smooth_conductor_bsdfs, sc->smooth_plastic_bsdfs,
+                          sc->rough_conductor_bsdfs, sc->smooth_floor_bsdfs, sc->rough_floor_bsdfs, sc->rough_plastic_bsdfs, sc->lights};
+    const size_t rec[9] = {sizeof(gsp_diffuse_bsdf), sizeof(gsp_smooth_dielectric_bsdf), sizeof(gsp_smooth_conductor_bsdf),
+                           sizeof(gsp_smooth_plastic_bsdf), sizeof(gsp_rough_conductor_bsdf), sizeof(gsp_smooth_floor_bsdf),
+                           sizeof(gsp_rough_floor_bsdf), sizeof(gsp_rough_plastic_bsdf), sizeof(gsp_triangle_light)};
+    size_t bytes[9], total = 0;
+    for (int k = 0; k < 9; ++k) {
+      bytes[k] = rec[k] * (k < 8 ? sc->num_bsdfs[k] : sc->num_lights);
+      if (bytes[k] && !src[k]) {
+        ctx->err = "null array with non-zero count";
+        return GSP_ERR_SCENE;
+      }
+      ctx->table_off[k] = total;
+      total += (bytes[k] + 15) & ~(size_t)15;
+    }
+    ctx->tables_bytes = total;
+    CTX_TRY(ctx, ctx->tables.ensure(std::max<size_t>(total, 16), &ctx->bytes));
+    for (int k = 0; k < 9; ++k)
+      if (bytes[k]) CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p + ctx->table_off[k], src[k], bytes[k], hipMemcpyHostToDevice, st));
+  }
   ctx->num_lights = sc->num_lights;
   ctx->camera = sc->camera;
 

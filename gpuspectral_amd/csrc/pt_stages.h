@@ -43,6 +43,8 @@ struct SceneView {
   const gsp_triangle_light* lights;
   uint32_t num_lights;
   int32_t root;
+  const uint8_t* tables = nullptr;  // the BSDF tables + lights back to back (device: one allocation), for LDS staging
+  uint32_t tables_bytes = 0;
 };
 
 // path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9
