@@ -541,3 +541,30 @@ def test_tiny_frames_with_many_samples(ctx, oracle_mod):
         ctx.render(spp=spp)
         ref, _ = o.render(W, H, spp=spp)
         assert np.array_equal(ctx.download().reshape(-1, 4), ref), (W, H, spp)
+
+
+def test_many_lights_tables_beyond_the_lds_budget(ctx, oracle_mod):
+    """k_shade stages the BSDF + light tables into LDS when they fit 8 KB; an emissive tessellated sphere makes 720
+    triangle lights (46 KB), so this scene runs the global-memory path of the same code."""
+    from gpuspectral_amd import scenes
+
+    b = scenes.SceneBuilder()
+    room = b.add_mesh(*scenes.box_mesh())
+    ball = b.add_mesh(*scenes.sphere_mesh(24, 16))
+    b.add_object(room, scenes.trs((0, 1, 0), (2.0, 1.2, 2.0)), b.diffuse((0.7, 0.6, 0.5)), twofaced=True)
+    b.add_object(ball, scenes.trs((0.3, 1.4, -0.2), (0.3, 0.3, 0.3)), b.diffuse((0, 0, 0)), emission=(60.0, 50.0, 30.0))
+    b.add_object(ball, scenes.trs((-0.6, 0.4, 0.5), (0.4, 0.4, 0.4)), b.rough_conductor((0.2, 0.9, 1.1), (3.9, 2.4, 2.2), 0.2, (1, 1, 1)))
+    b.camera_lookat((1.6, 1.1, 1.7), (0, 0.9, 0), fov_deg=60)
+    sc = b.build()
+    assert len(sc.lights) * 64 > 8192
+    W, H, spp = 64, 48, 4
+    ctx.upload_scene(sc)
+    ctx.frame_begin(W, H)
+    ctx.reset_stats()
+    ctx.render(spp=spp)
+    img = ctx.download().reshape(-1, 4)
+    st = ctx.stats()
+    ref, so = oracle_mod.Oracle(sc).render(W, H, spp=spp)
+    assert rmse(img, ref) < TOL_RMSE
+    assert np.array_equal(img, ref)
+    assert st["shadow_rays"] == so["shadow_rays"] and st["extension_rays"] == so["extension_rays"] and st["shadow_rays"] > 0
