@@ -201,13 +201,13 @@ def main():
     tdev = "cuda" if on_gpu else "cpu"
 
     def barrier():
+        ctx.sync()  # this rank's tracer has nothing queued or in flight (its own stream + the path pool)
         if dist is not None:
             if on_gpu:
                 torch.cuda.synchronize()
             dist.barrier()
             if on_gpu:
                 torch.cuda.synchronize()
-        ctx.sync()
 
     ts = 0
     for _ in range(args.warmup):
