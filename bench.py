@@ -20,8 +20,8 @@ scene at 1920x1080, on 1/2/4/8 MI355X.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, k_trace<ExtendIO> (closest-hit BVH traversal),
 against the resource that binds it -- VALU instruction issue: wave64 VALU instructions per second
-(rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from the committed PMC passes over this same command,
-profiles/pmc_bench_latest.json) over this run's HIP-event kernel time, against 1024 SIMDs x 2.4 GHz / 2 cycles.  The
+(rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from the committed PMC passes over this same command line,
+profiles/pmc_bench_*.json) over this run's HIP-event kernel time, against 1024 SIMDs x 2.4 GHz / 2 cycles.  The
 memory side is reported next to it: counter HBM bytes per launch (`traffic`, FETCH_SIZE / WRITE_SIZE with the
 calibration of scripts/microbench/fetch_calib.hip) as a fraction of the 8 TB/s peak (`hbm_frac`), and the SURVEY 8(d)
 algorithmic bytes (every node / triangle record the traversal reads, mostly served by L2 / Infinity Cache) as
@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz max clock (same guide)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_bench_latest.json")
+PMC_GLOB = os.path.join(ROOT, "profiles", "pmc_bench_*.json")  # one file per profiled command line (steps / warmup)
 
 
 def pmc_for_run(config, timed_launches):
@@ -51,18 +51,26 @@ def pmc_for_run(config, timed_launches):
     over THIS command: the passes ran the same workload, so their last `timed_launches` dispatches of the kernel are the
     launches of the timed region (it is the tail of the run).  None when the file is absent or was taken on another
     workload / launch sequence."""
-    try:
-        pm = json.load(open(PMC_FILE))
-    except (OSError, ValueError):
-        return None
+    import glob
+
     want = {k: config[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
-    have = pm.get("bench_config", {})
-    if any(have.get(k) != v for k, v in want.items()) or pm.get("steps") is None:
+    pm = None
+    for path in sorted(glob.glob(PMC_GLOB)):
+        try:
+            cand = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        have = cand.get("bench_config", {})
+        if all(have.get(k) == v for k, v in want.items()) and cand.get("timed_launches") == timed_launches and \
+                cand.get("steps") == config.get("steps") and cand.get("warmup") == config.get("warmup"):
+            pm, pm_path = cand, path
+            break
+    if pm is None:
         return None
     k = pm["kernels"].get("k_trace_extend")
-    if not k or pm.get("timed_launches") != timed_launches:
+    if not k:
         return None
-    out = {"source": "profiles/pmc_bench_latest.json (%s)" % pm.get("source", "?"), "calibration": pm.get("fetch_calibration", {})}
+    out = {"source": "profiles/%s (%s)" % (os.path.basename(pm_path), pm.get("source", "?")), "calibration": pm.get("fetch_calibration", {})}
     for name, vals in k["counters"].items():
         if len(vals) < timed_launches:
             return None
@@ -274,7 +282,8 @@ def main():
         ext_ms = st["extend_kernel_ms"]
         launches = max(1, st["extend_launches"])
         alg_bytes = st["extension_rays"] * b_ray
-        cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S}
+        cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S,
+                   "steps": args.steps, "warmup": args.warmup}
         pmc = pmc_for_run(cfg_key, int(st["extend_launches"])) if world == 1 else None
         roof = {
             "kernel": "k_trace<ExtendIO> (closest-hit traversal of the 4-wide BVH)",
