@@ -25,4 +25,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_calib $ROOT/scripts/microbench/fetch_calib.hip > $OUT/fetch_calib_build.log 2>&1
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib -- /tmp/fetch_calib > $OUT/fetch_calib.txt 2>&1 || echo "calib failed"
 python3 $ROOT/scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+# the raw per-dispatch CSVs are tens of MB (gpurun brings back at most 64 MiB): keep the summary, the JSON and the
+# kernel-stats table
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*kernel_trace.csv" -delete
 tail -n 60 $OUT/summary.txt
