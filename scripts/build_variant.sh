@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../gpuspectral_amd/csrc"
 mkdir -p build/var_$1 ../lib/variants
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $2"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize $2"
 hipcc $F -c pt_render.hip -o build/var_$1/pt_render.o &
 hipcc $F -c pt_bvh.hip -o build/var_$1/pt_bvh.o &
 hipcc $F -c pt_multi.hip -o build/var_$1/pt_multi.o &
