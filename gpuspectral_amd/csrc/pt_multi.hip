@@ -234,8 +234,9 @@ int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height) {
   }
   int rc = for_each_share(m, [&](size_t r) {
     // a single share owns the whole frame: no subset, no gather
+    static const uint32_t none = 0;  // a share without a tile (more shares than tiles) owns NO pixel: non-null list, length 0
     return world == 1 ? gsp_frame_begin(m->ctx[r], width, height, nullptr, 0)
-                      : gsp_frame_begin(m->ctx[r], width, height, m->ids[r].data(), m->ids[r].size());
+                      : gsp_frame_begin(m->ctx[r], width, height, m->ids[r].empty() ? &none : m->ids[r].data(), m->ids[r].size());
   });
   m->have_frame = rc == GSP_OK;
   return rc;
@@ -263,6 +264,7 @@ int gsp_multi_gather(gsp_multi* m, void** device_frame) {
   }
   // the one exchange of the job: every share copies its compact buffer into the staging buffer on devices[0]
   int rc = for_each_share(m, [&](size_t r) {
+    if (m->ids[r].empty()) return gsp_sync(m->ctx[r]);
     return gsp_copy_accum_to_device(m->ctx[r], m->staging + m->offset[r], m->ids[r].size() * sizeof(q4));
   });
   if (rc != GSP_OK) return rc;

@@ -48,6 +48,27 @@ def test_shares_on_one_gpu_reproduce_the_single_gpu_frame(materials_scene, world
         assert np.array_equal(m.download(), ref)
 
 
+def test_more_shares_than_tiles(materials_scene):
+    """A 40 x 40 frame has four 32 x 32 tiles: with eight shares, four of them own no pixel at all."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import pt
+
+    W, H, spp = 40, 40, 5
+    with g.Context(0) as ctx:
+        ctx.upload_scene(materials_scene)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        ref = ctx.download()
+    assert sum(len(pt.tile_partition(W, H, r, 8)) == 0 for r in range(8)) == 4
+    with pt.MultiContext([0] * 8) as m:
+        m.upload_scene(materials_scene)
+        m.frame_begin(W, H)
+        m.render(spp=spp)
+        assert np.array_equal(m.download(), ref)
+        tot, each = m.stats(per_share=True)
+        assert tot["samples"] == W * H * spp and sum(e["samples"] == 0 for e in each) == 4
+
+
 def test_config4_partition_at_full_resolution():
     """BASELINE config 4 (bathroom2 stand-in, 1920x1080, tiled over 8 GPUs) with the eight shares on one GPU: the
     gathered frame equals the single-context frame.  8 spp here; the full 4096 spp of the same frame are checked

@@ -5,6 +5,8 @@ the same deterministic transcendentals, so images are expected to agree bit for
 bit.  The contract (BASELINE.json north_star) is per-pixel RMSE < 1e-3 at equal
 spp; the tests assert that bound and report exactness separately.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -568,3 +570,57 @@ def test_many_lights_tables_beyond_the_lds_budget(ctx, oracle_mod):
     assert rmse(img, ref) < TOL_RMSE
     assert np.array_equal(img, ref)
     assert st["shadow_rays"] == so["shadow_rays"] and st["extension_rays"] == so["extension_rays"] and st["shadow_rays"] > 0
+
+
+def test_random_call_sequences_equal_one_shot_renders(oracle_mod):
+    """The streaming pool and the host-one-iteration-behind loop under arbitrary call patterns: random frame sizes, random
+    splits of the samples over gsp_render calls with random batch sizes, peeks / syncs / stats reads / downloads in between,
+    two contexts interleaved -- the final frame and the ray counts must equal ONE gsp_render call of all samples on a fresh
+    context (which the other tests tie to the oracle; the first sequence is also checked against the oracle here)."""
+    import sys
+
+    import gpuspectral_amd as g
+    from conftest import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import fuzz_parity
+
+    rng = np.random.RandomState(77)
+    a, b = g.Context(0), g.Context(0)
+    try:
+        for seq in range(16):
+            sc = fuzz_parity.random_scene(9000 + seq)
+            W, H = int(rng.randint(1, 180)), int(rng.randint(1, 120))
+            total = int(rng.randint(1, 60))
+            tif = int(rng.choice([0, 0, 1, 2, 7]))
+            for c in (a, b):
+                c.upload_scene(sc)
+                c.frame_begin(W, H)
+                c.reset_stats()
+            b.render(spp=total, timestamps_in_flight=tif)  # one shot
+            done = 0
+            while done < total:
+                k = int(min(total - done, rng.randint(1, 12)))
+                a.render(spp=k, first_timestamp=done, timestamps_in_flight=tif)
+                done += k
+                op = rng.randint(6)
+                if op == 0:
+                    img, folded = a.peek()
+                    assert 0 <= folded <= done
+                elif op == 1:
+                    a.sync()
+                elif op == 2:
+                    assert a.stats()["samples"] == W * H * done
+                elif op == 3:
+                    a.download_compact()
+            ia, ib = a.download(), b.download()
+            sa, sb = a.stats(), b.stats()
+            assert np.array_equal(ia, ib, equal_nan=True), (seq, W, H, total, tif)
+            for key in ("extension_rays", "shadow_rays", "shaded_vertices", "samples"):
+                assert sa[key] == sb[key], (seq, key)
+            if seq == 0:
+                ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=total)
+                assert np.array_equal(ib.reshape(-1, 4), ref, equal_nan=True)
+    finally:
+        a.close()
+        b.close()
