@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-GSP_ABI_VERSION = 1
+GSP_ABI_VERSION = 2
 
 BSDF_DIFFUSE = 0
 BSDF_SMOOTH_DIELECTRIC = 1
@@ -151,6 +151,7 @@ class Stats(C.Structure):
         ("num_triangles", C.c_uint64),
         ("num_bvh_nodes", C.c_uint64),
         ("device_bytes", C.c_uint64),
+        ("algorithmic_bytes", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -315,6 +315,7 @@ int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
       t.shadow_nodes_visited += s.shadow_nodes_visited;
       t.shadow_tris_tested += s.shadow_tris_tested;
       t.shadow_stat_rays += s.shadow_stat_rays;
+      t.algorithmic_bytes += s.algorithmic_bytes;
       t.extend_launches += s.extend_launches;
       t.device_bytes += s.device_bytes;
       t.render_seconds = std::max(t.render_seconds, s.render_seconds);

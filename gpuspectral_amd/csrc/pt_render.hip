@@ -1393,6 +1393,9 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
   ctx->stats.num_triangles = ctx->bvh.num_tris;
   ctx->stats.num_bvh_nodes = ctx->bvh.num_nodes;
   ctx->stats.device_bytes = ctx->bytes;
+  ctx->stats.algorithmic_bytes = 48ull * ctx->stats.stat_rays + 64ull * ctx->stats.nodes_visited + 48ull * ctx->stats.tris_tested +
+                                 96ull * ctx->stats.shadow_stat_rays + 64ull * ctx->stats.shadow_nodes_visited +
+                                 48ull * ctx->stats.shadow_tris_tested;
   *out = ctx->stats;
   return GSP_OK;
 }

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 1
+#define GSP_ABI_VERSION 2 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -210,6 +210,10 @@ typedef struct gsp_stats {
   uint64_t num_triangles;
   uint64_t num_bvh_nodes;
   uint64_t device_bytes;     /* device memory currently held by the context      */
+  uint64_t algorithmic_bytes; /* SURVEY 8(d) bytes of the rays the stats mode covered: per extension ray 32 (ray)
+                                 + 16 (hit) + 64 per node + 48 per triangle record read, per shadow ray 64 + 32 + the
+                                 same node / triangle terms.  What the traversal ASKS of the memory hierarchy; the
+                                 bytes that reach HBM are a quarter of it (rocprofv3 FETCH_SIZE) */
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;
