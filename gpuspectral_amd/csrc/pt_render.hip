@@ -83,6 +83,26 @@ __device__ __forceinline__ q4 mkq(float x, float y, float z, float w) {
   r.w = w;
   return r;
 }
+// Queue records are written once and read once per iteration, ~7 GB per iteration through a 256-MiB Infinity Cache that
+// would otherwise hold the BVH, the triangle packets and the shading packets (140 MB for a million triangles): the
+// streaming accesses of k_generate and k_shade carry the non-temporal hint (A/B: k_shade -3.7 %, bench +1.1 %; on the
+// ray loads / hit stores of k_trace the hint costs 1 %, so those stay plain; profiles/r02_ab_nt_queues.txt).
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ q4 qld(const q4* p) {
+  const v4f v = __builtin_nontemporal_load((const v4f*)p);
+  q4 r;
+  r.x = v.x;
+  r.y = v.y;
+  r.z = v.z;
+  r.w = v.w;
+  return r;
+}
+__device__ __forceinline__ void qst(q4* p, q4 a) {
+  const v4f v = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(v, (v4f*)p);
+}
+__device__ __forceinline__ uint32_t qld(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void qst(uint32_t* p, uint32_t a) { __builtin_nontemporal_store(a, p); }
 __device__ __forceinline__ float ub(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t fb(float f) { return __float_as_uint(f); }
 
@@ -109,10 +129,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
     PathState p;
     generate_path(rc, gid, first_timestamp + k, sid, p);
     const uint64_t j = offset + i;
-    q.P0[j] = mkq(p.o.x, p.o.y, p.o.z, p.d.x);
-    q.P1[j] = mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid));
-    q.P2[j] = mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight);
-    q.FL[j] = p.flags;
+    qst(&q.P0[j], mkq(p.o.x, p.o.y, p.o.z, p.d.x));
+    qst(&q.P1[j], mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid)));
+    qst(&q.P2[j], mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight));
+    qst(&q.FL[j], p.flags);
     result[sid] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
   }
 }
@@ -259,12 +279,12 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       uint32_t key = 9;
       // the tile is read in queue order (fully coalesced) and handed to its sorted position through LDS
       if (i0 < n) {
-        const q4 hq0 = hits[i0];
+        const q4 hq0 = qld(&hits[i0]);
         s_hq[threadIdx.x] = hq0;
-        s_p0[threadIdx.x] = cur.P0[i0];
-        s_p1[threadIdx.x] = cur.P1[i0];
-        s_p2[threadIdx.x] = cur.P2[i0];
-        s_fl[threadIdx.x] = cur.FL[i0];
+        s_p0[threadIdx.x] = qld(&cur.P0[i0]);
+        s_p1[threadIdx.x] = qld(&cur.P1[i0]);
+        s_p2[threadIdx.x] = qld(&cur.P2[i0]);
+        s_fl[threadIdx.x] = qld(&cur.FL[i0]);
         const uint32_t w = fb(hq0.w);
         key = (w == 0xffffffffu) ? 8u : ((w >> 28) & 7u);
       }
@@ -357,18 +377,18 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     const uint32_t j = s_base[0][wave] + (uint32_t)__popcll(am & lt_mask);
     if (alive) {
       const PathState& p = out.next;
-      nxt.P0[j] = mkq(p.o.x, p.o.y, p.o.z, p.d.x);
-      nxt.P1[j] = mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid));
-      nxt.P2[j] = mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight);
-      nxt.FL[j] = p.flags;
+      qst(&nxt.P0[j], mkq(p.o.x, p.o.y, p.o.z, p.d.x));
+      qst(&nxt.P1[j], mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid)));
+      qst(&nxt.P2[j], mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight));
+      qst(&nxt.FL[j], p.flags);
     }
     if (has_shadow) {
       const uint32_t s = s_base[1][wave] + (uint32_t)__popcll(sm & lt_mask);
       const ShadowRay& r = out.shadow;
-      sq.S0[s] = mkq(r.o.x, r.o.y, r.o.z, r.tmax);
-      sq.S1[s] = mkq(r.d.x, r.d.y, r.d.z, ub(r.sid));
-      sq.S2[s] = mkq(r.nee.x, r.nee.y, r.nee.z, r.dw_nee);
-      sq.S3[s] = mkq(r.emis.x, r.emis.y, r.emis.z, ub(alive ? j : 0xffffffffu));
+      qst(&sq.S0[s], mkq(r.o.x, r.o.y, r.o.z, r.tmax));
+      qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(r.sid)));
+      qst(&sq.S2[s], mkq(r.nee.x, r.nee.y, r.nee.z, r.dw_nee));
+      qst(&sq.S3[s], mkq(r.emis.x, r.emis.y, r.emis.z, ub(alive ? j : 0xffffffffu)));
     }
   }
   __syncthreads();
