@@ -1237,10 +1237,10 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     // of a batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
     // owns a slot of the sample-result ring and is folded into the accumulate buffer, in timestamp
     // order, once its live count has dropped to zero.
-    // paths in flight over all lanes: per-launch fixed costs (drained wave tails, launch gaps, the host's
-    // counter read-back) amortise over the pool size -- bench: 8 M 5.35, 12 M 5.76, 24 M 6.11, 48 M 6.16, 96 M 6.25
-    // Grays/s; 32 M paths = 5.9 GB of queues
-    uint64_t total_target = 32ull << 20;
+    // paths in flight over all lanes: per-launch fixed costs (drained wave tails, launch gaps) amortise over the pool
+    // size -- r01 bench scan: 8 M 5.35, 12 M 5.76, 24 M 6.11, 48 M 6.16, 96 M 6.25 Grays/s; r02 (final kernels): 32 M 7.48,
+    // 48 M 7.63, 64 M 7.64 (profiles/r02_ab_pool_size.txt).  48 M paths: 18 GB of queues (capacity 2 x the target)
+    uint64_t total_target = 48ull << 20;
     if (const char* e = getenv("GSP_POOL_PATHS")) total_target = std::max<uint64_t>(1ull << 16, strtoull(e, nullptr, 10));
     for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
       gsp_context::Lane& L = ctx->lanes[l];
@@ -1254,9 +1254,9 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
       P.Kb = Kb;
       P.batch_paths = Kb * npix;
-      // (at most 128 samples per pixel in flight: tiny frames do not allocate gigabytes; a 1/8 tile share of a
+      // (at most 192 samples per pixel in flight: tiny frames do not allocate gigabytes; a 1/8 tile share of a
       // 1080p frame, 259 k pixels, still fills the whole pool)
-      P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 128 * npix), 2 * P.batch_paths);
+      P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 192 * npix), 2 * P.batch_paths);
       uint64_t ring_bytes = 16ull << 30;
       if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
       {
