@@ -342,6 +342,7 @@ def main():
                 "shadow_rays": int(sh_rays),
                 "bvh_build_ms": st["bvh_build_ms"],
                 "scene_upload_ms": upload_s * 1e3,
+                "library_digest": g.pt.build_info()["digest"],
             },
             "roofline": roof,
         }

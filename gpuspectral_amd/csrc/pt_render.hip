@@ -538,6 +538,9 @@ struct gsp_context {
   DevBuf<q4> accum;
 
   DevBuf<DevStats> dstats;
+  DevBuf<float> trace_rays;  // gsp_trace: grow-only staging, kept across calls
+  DevBuf<q4> trace_hits;
+  DevBuf<uint32_t> trace_work;
   uint32_t spill_stride = 0;
   gsp_stats stats{};
 
@@ -657,6 +660,8 @@ struct gsp_context {
 
 extern "C" {
 
+extern const char gsp_build_info_string[];  // build/pt_buildinfo.cpp, written by the Makefile
+
 void gsp_default_render_params(gsp_render_params* p) {
   if (!p) return;
   std::memset(p, 0, sizeof(*p));
@@ -668,6 +673,8 @@ void gsp_default_render_params(gsp_render_params* p) {
 }
 
 int gsp_abi_version(void) { return GSP_ABI_VERSION; }
+
+const char* gsp_build_info(void) { return gsp_build_info_string; }
 
 int gsp_device_count(void) {
   int n = 0;
@@ -1444,11 +1451,11 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   if (n == 0) return GSP_OK;
   if (n >= (1ull << 31)) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
-  DevBuf<float> d_rays;
-  DevBuf<q4> d_hits;
+  DevBuf<float>& d_rays = ctx->trace_rays;
+  DevBuf<q4>& d_hits = ctx->trace_hits;
+  DevBuf<uint32_t>& d_work = ctx->trace_work;
   CTX_TRY(ctx, d_rays.upload(rays, 8 * n, ctx->stream, nullptr));
   CTX_TRY(ctx, d_hits.ensure(n, nullptr));
-  DevBuf<uint32_t> d_work;
   CTX_TRY(ctx, d_work.ensure(kWorkShards * kWorkStride, nullptr));
   CTX_TRY(ctx, hipMemsetAsync(d_work.p, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
   const SceneView view = ctx->view();
@@ -1465,6 +1472,10 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   CTX_TRY(ctx, hipGetLastError());
   CTX_TRY(ctx, hipMemcpyAsync(hits, d_hits.p, n * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n > (8u << 20)) {  // a one-off large query does not pin half a gigabyte for the life of the context
+    d_rays.release();
+    d_hits.release();
+  }
   return GSP_OK;
 }
 

@@ -17,6 +17,7 @@ _LIB = None
 EXPORTS = (
     "gsp_default_render_params",
     "gsp_abi_version",
+    "gsp_build_info",
     "gsp_device_count",
     "gsp_ctx_create",
     "gsp_ctx_destroy",
@@ -74,6 +75,7 @@ def load():
     L.gsp_default_render_params.argtypes = [C.POINTER(abi.RenderParams)]
     L.gsp_default_render_params.restype = None
     L.gsp_abi_version.restype = C.c_int
+    L.gsp_build_info.restype = C.c_char_p
     L.gsp_device_count.restype = C.c_int
     L.gsp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.gsp_ctx_destroy.argtypes = [vp]
@@ -116,6 +118,31 @@ def load():
 
 def device_count():
     return load().gsp_device_count()
+
+
+def build_info():
+    """What the loaded library was built from (gsp_build_info): {'arch', 'digest', 'flags'}."""
+    text = load().gsp_build_info().decode()
+    head, _, flags = text.partition(" flags=")
+    info = dict(kv.split("=", 1) for kv in head.split())
+    info["flags"] = flags
+    return info
+
+
+# the files csrc/Makefile hashes into the digest, in its order
+DIGEST_SOURCES = ("pt_render.hip", "pt_bvh.hip", "pt_multi.hip", "pt_wavetrace.h", "pt_hostmath.h", "pt_math.h", "pt_shading.h",
+                  "pt_trace.h", "pt_stages.h", "pt_internal.h", "../../include/gpuspectral_pt.h")
+
+
+def source_digest():
+    """The digest csrc/Makefile would stamp into a library built from the tree as it is now."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in DIGEST_SOURCES:
+        with open(os.path.join(_HERE, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 HIT_DT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<i4")])

@@ -224,6 +224,11 @@ void gsp_default_render_params(gsp_render_params* p);
 /* ABI version of the loaded library (== GSP_ABI_VERSION of this header). */
 int gsp_abi_version(void);
 
+/* What the loaded library was built from: "arch=gfx950 digest=<sha256[:16] of csrc/{pt_render,pt_bvh,pt_multi}.hip + the
+ * headers, in the Makefile's order> flags=<compiler flags>".  A deployment (and tests/test_abi_and_host.py) compares the
+ * digest with the tree to tell a stale prebuilt .so from a fresh build.  Static storage, never NULL. */
+const char* gsp_build_info(void);
+
 /* Number of HIP devices visible (0 if none / runtime unavailable). */
 int gsp_device_count(void);
 

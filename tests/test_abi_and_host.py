@@ -33,6 +33,19 @@ def test_library_exports_every_declared_symbol():
     assert L.gsp_abi_version() == g.abi.GSP_ABI_VERSION
 
 
+def test_loaded_library_was_built_from_this_tree():
+    """gsp_build_info(): the digest stamped into the .so by csrc/Makefile == the digest of the sources in the tree, so a
+    stale prebuilt library cannot stand in for the code under review; the flags that pin the float arithmetic are on."""
+    from gpuspectral_amd import pt
+
+    if os.environ.get("GSP_LIB_PATH"):
+        pytest.skip("GSP_LIB_PATH points at a build variant")
+    info = pt.build_info()
+    assert info["arch"] == "gfx950"
+    assert info["digest"] == pt.source_digest(), "libgpuspectral_pt.so is stale: run make -C gpuspectral_amd/csrc"
+    assert "-ffp-contract=off" in info["flags"].split()
+
+
 def test_struct_layouts_match_header(tmp_path):
     """sizeof/offsetof from the C header (gcc) == the ctypes/numpy mirrors."""
     from gpuspectral_amd import abi
