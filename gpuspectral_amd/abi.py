@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-GSP_ABI_VERSION = 2
+GSP_ABI_VERSION = 3
 
 BSDF_DIFFUSE = 0
 BSDF_SMOOTH_DIELECTRIC = 1
@@ -90,6 +90,13 @@ class Camera(C.Structure):
     _fields_ = [("to_world", C.c_float * 16), ("fov", C.c_float)]
 
 
+TEXTURE_DT = np.dtype([("width", "<u4"), ("height", "<u4"), ("first_texel", "<u8")])  # gsp_texture, 16 B
+
+
+class Envmap(C.Structure):  # gsp_envmap
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("to_local", C.c_float * 16)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("instances", C.c_void_p),
@@ -109,6 +116,14 @@ class SceneDesc(C.Structure):
         ("lights", C.c_void_p),
         ("num_lights", C.c_uint32),
         ("camera", Camera),
+        # dormant-feature extension (textures / environment map); all zero = the reference's behaviour
+        ("uvs", C.c_void_p),
+        ("textures", C.c_void_p),
+        ("num_textures", C.c_uint32),
+        ("texels", C.c_void_p),
+        ("num_texels", C.c_uint64),
+        ("texel_decode", C.c_void_p),
+        ("envmap", Envmap),
     ]
 
 
@@ -173,6 +188,23 @@ class SceneArrays:
         self.lights = np.zeros(0, LIGHT_DT)
         self.to_world = np.eye(4, dtype=np.float32).T.reshape(16).copy()  # glm memory order
         self.fov = np.float32(0.5)
+        # dormant-feature extension (include/gpuspectral_pt.h): absent by default
+        self.uvs = None            # (num_vertices, 2) float32
+        self.textures = np.zeros(0, TEXTURE_DT)
+        self.texels = np.zeros(0, np.uint32)     # RGBA8, all textures back to back
+        self.texel_decode = None   # 256 float32, None = byte / 255
+        self.env_texels = None     # (height, width, 4) float32, rows bottom-up
+        self.env_to_local = np.eye(4, dtype=np.float32).reshape(16).copy()
+
+    def add_texture(self, rgba8):
+        """Append an (H, W, 4) uint8 image whose row 0 is the BOTTOM row; returns the has_texture value (index + 1)."""
+        img = np.ascontiguousarray(rgba8, np.uint8)
+        h, w = img.shape[:2]
+        t = np.zeros(1, TEXTURE_DT)
+        t["width"], t["height"], t["first_texel"] = w, h, len(self.texels)
+        self.textures = np.concatenate([self.textures, t])
+        self.texels = np.concatenate([self.texels, img.reshape(-1, 4).view("<u4").reshape(-1)])
+        return len(self.textures)
 
     @property
     def num_triangles(self):
@@ -200,6 +232,29 @@ class SceneArrays:
         for i in range(16):
             d.camera.to_world[i] = float(self.to_world[i])
         d.camera.fov = float(self.fov)
+        if len(self.textures):
+            if self.uvs is None:
+                self.uvs = np.zeros((len(self.positions), 2), np.float32)
+            self.uvs = np.ascontiguousarray(self.uvs, np.float32).reshape(-1, 2)
+            assert len(self.uvs) == len(self.positions)
+            self.textures = np.ascontiguousarray(self.textures, TEXTURE_DT)
+            self.texels = np.ascontiguousarray(self.texels, np.uint32)
+            d.uvs = self.uvs.ctypes.data
+            d.textures = self.textures.ctypes.data
+            d.num_textures = len(self.textures)
+            d.texels = self.texels.ctypes.data
+            d.num_texels = len(self.texels)
+            if self.texel_decode is not None:
+                self.texel_decode = np.ascontiguousarray(self.texel_decode, np.float32)
+                assert self.texel_decode.shape == (256,)
+                d.texel_decode = self.texel_decode.ctypes.data
+        if self.env_texels is not None:
+            self.env_texels = np.ascontiguousarray(self.env_texels, np.float32)
+            h, w = self.env_texels.shape[:2]
+            d.envmap.texels = self.env_texels.ctypes.data
+            d.envmap.width, d.envmap.height = w, h
+            for i in range(16):
+                d.envmap.to_local[i] = float(self.env_to_local[i])
         return d
 
     def save(self, path):
@@ -207,7 +262,17 @@ class SceneArrays:
         np.savez_compressed(
             path, instances=self.instances, positions=self.positions, normals=self.normals, lights=self.lights,
             to_world=np.asarray(self.to_world, np.float32), fov=np.float32(self.fov),
-            **{"bsdf_" + n: b for n, b in zip(BSDF_NAMES, self.bsdfs)})
+            **{"bsdf_" + n: b for n, b in zip(BSDF_NAMES, self.bsdfs)}, **self._extension_arrays())
+
+    def _extension_arrays(self):
+        ext = {}
+        if len(self.textures):
+            ext.update(uvs=self.uvs, textures=self.textures, texels=self.texels)
+            if self.texel_decode is not None:
+                ext["texel_decode"] = self.texel_decode
+        if self.env_texels is not None:
+            ext.update(env_texels=self.env_texels, env_to_local=self.env_to_local)
+        return ext
 
     @classmethod
     def load(cls, path):
@@ -217,4 +282,9 @@ class SceneArrays:
         s.positions, s.normals, s.lights = z["positions"], z["normals"], z["lights"].astype(LIGHT_DT)
         s.bsdfs = [z["bsdf_" + n].astype(dt) for n, dt in zip(BSDF_NAMES, BSDF_DTYPES)]
         s.to_world, s.fov = z["to_world"].copy(), np.float32(z["fov"])
+        if "textures" in z:
+            s.uvs, s.textures, s.texels = z["uvs"], z["textures"].astype(TEXTURE_DT), z["texels"]
+            s.texel_decode = z["texel_decode"] if "texel_decode" in z else None
+        if "env_texels" in z:
+            s.env_texels, s.env_to_local = z["env_texels"], z["env_to_local"]
         return s

@@ -178,4 +178,32 @@ GSP_HD float det_expf(float x) {
   return (y * s1) * s2;
 }
 
+// atan2 for the environment-map lookup (dormant-feature extension, include/gpuspectral_pt.h): Cephes atanf kernel
+// (reduction at tan(pi/8) and tan(3pi/8), degree-4 polynomial in z = x^2) with explicit fmaf, quadrant by sign bits;
+// atan2(0, 0) = 0.  ~2 ulp; what matters here is that it is the same function everywhere.
+GSP_HD float det_atanf_pos(float x) {  // x >= 0
+  float y0 = 0.0f;
+  if (x > 2.414213562373095f) {
+    y0 = 1.5707963267948966f;
+    x = -1.0f / x;
+  } else if (x > 0.4142135623730950f) {
+    y0 = 0.7853981633974483f;
+    x = (x - 1.0f) / (x + 1.0f);
+  }
+  const float z = x * x;
+  float p = gfma(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = gfma(p, z, 1.99777106478e-1f);
+  p = gfma(p, z, -3.33329491539e-1f);
+  return y0 + gfma(p * z, x, x);
+}
+GSP_HD float det_atan2f(float y, float x) {
+  const float ax = gabs(x), ay = gabs(y);
+  if (!(ax > 0.0f) && !(ay > 0.0f)) return 0.0f;  // (0, 0) and NaN
+  float r;
+  if (ax == 0.0f) r = 1.5707963267948966f;
+  else r = det_atanf_pos(ay / ax);  // [0, pi/2]
+  if (x < 0.0f) r = 3.14159265358979323846f - r;
+  return y < 0.0f ? -r : r;
+}
+
 }  // namespace gsp

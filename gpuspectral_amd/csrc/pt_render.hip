@@ -222,6 +222,9 @@ constexpr int kShadeWaves = kShadeBlock / 64;
 #ifndef GSP_SHADE_MINWAVES
 #define GSP_SHADE_MINWAVES 4  // 128 VGPRs: 4 blocks of 256 threads per CU
 #endif
+// TEX: scene with textures / an environment map (dormant-feature extension): a second instantiation, so that the code
+// of the reference's path (TEX = false) is what it was
+template <bool TEX>
 __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(SceneView S, RenderConsts rc, const uint32_t* __restrict__ n_ptr, PathQueue cur,
                                                         const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
                                                         q4* __restrict__ result, uint32_t* __restrict__ tails,
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
         in.weight = mk3(p2.x, p2.y, p2.z);
         in.directWeight = p2.w;
         in.flags = fl;
-        shade_vertex(S, rc, in, h, out);
+        shade_vertex<TEX>(S, rc, in, h, out);
         alive = out.alive;
         has_shadow = out.has_shadow;
         ++shaded;
@@ -338,6 +341,13 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
           add_emitted(rc.clamp, out.emitted, r);
           result[in.sid] = r;
         }
+      } else if (TEX && S.tex.env_texels != nullptr) {  // escaped: environment radiance, then the path ends
+        PathState in;
+        in.d = mk3(p0.w, p1.x, p1.y);
+        in.weight = mk3(p2.x, p2.y, p2.z);
+        q4 r = result[my_sid];
+        add_emitted(rc.clamp, miss_emitted(S, in), r);
+        result[my_sid] = r;
       }
     }
     // paths that ended here leave their sample slot's live count (a slot is resolved when it
@@ -406,6 +416,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
 // same per-sample order of additions as k_shade / ConnectIO, so the arithmetic per path is unchanged.
 constexpr uint32_t kFinishPaths = 262144;  // scan 0 / 64 k / 256 k / 1 M: 8-spp call 62 / 56 / 54 / 56 ms, 500x500 1-spp frames 88 / 138 / 182 / 184 per s
 
+template <bool TEX>
 __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc, uint32_t n, PathQueue q,
                                                     q4* __restrict__ result, uint32_t* __restrict__ tails,
                                                     uint32_t* __restrict__ live,
@@ -428,9 +439,12 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
       HitRec h;
       uint32_t aux;
       ++ext;
-      if (!trace_ray4<false>(S.nodes, S.tri_isect, S.root, in.o, in.d, 0.0f, 1e10f, h, aux)) break;  // miss.rmiss:15-18
+      if (!trace_ray4<false>(S.nodes, S.tri_isect, S.root, in.o, in.d, 0.0f, 1e10f, h, aux)) {  // miss.rmiss:15-18
+        if (TEX && S.tex.env_texels != nullptr) add_emitted(rc.clamp, miss_emitted(S, in), res);
+        break;
+      }
       ShadeOut out;
-      shade_vertex(S, rc, in, h, out);
+      shade_vertex<TEX>(S, rc, in, h, out);
       ++shaded;
       if (!out.has_shadow) {
         add_emitted(rc.clamp, out.emitted, res);
@@ -469,6 +483,27 @@ __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_
     for (uint32_t k = 0; k < K; ++k) resolve_sample(first_timestamp + k, result[(uint64_t)k * num_pixels + l], a);
     accum[lp] = a;
   }
+}
+
+// ---- per-slot texture coordinates (dormant-feature extension) -----------------------------------------------------
+// slot -> global triangle (BVH order) -> instance (tri_first is ascending) -> the instance's vertices in the uv array
+__global__ __launch_bounds__(kBlock) void k_gather_uv(uint32_t num_tris, const uint32_t* __restrict__ slot_to_global,
+                                                      const uint32_t* __restrict__ tri_first, uint32_t num_instances,
+                                                      const gsp_instance* __restrict__ instances, const float* __restrict__ uvs,
+                                                      float* __restrict__ tri_uv) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= num_tris) return;
+  const uint32_t g = slot_to_global[s];
+  uint32_t lo = 0, hi = num_instances;  // last instance with tri_first <= g
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) / 2;
+    if (tri_first[mid] <= g) lo = mid;
+    else hi = mid;
+  }
+  const float* src = uvs + 2ull * (instances[lo].first_vertex + 3ull * (g - tri_first[lo]));
+  float* dst = tri_uv + 8ull * s;
+  for (int k = 0; k < 6; ++k) dst[k] = src[k];
+  dst[6] = dst[7] = 0.0f;
 }
 
 template <class T>
@@ -538,6 +573,13 @@ struct gsp_context {
   DevBuf<q4> accum;
 
   DevBuf<DevStats> dstats;
+  // dormant-feature extension (textures / environment map, include/gpuspectral_pt.h); `textured` selects the <TEX> kernels
+  DevBuf<float> tri_uv, texel_decode, env_texels;
+  DevBuf<gsp_texture> textures;
+  DevBuf<uint32_t> texels;
+  uint32_t num_textures = 0, env_width = 0, env_height = 0;
+  float env_to_local[16] = {};
+  bool textured = false;
   DevBuf<float> trace_rays;  // gsp_trace: grow-only staging, kept across calls
   DevBuf<q4> trace_hits;
   DevBuf<uint32_t> trace_work;
@@ -620,6 +662,17 @@ struct gsp_context {
     v.tables_bytes = (uint32_t)tables_bytes;
     v.num_lights = num_lights;
     v.root = bvh.root;
+    if (textured) {
+      v.tex.tri_uv = num_textures ? tri_uv.p : nullptr;
+      v.tex.textures = textures.p;
+      v.tex.texels = texels.p;
+      v.tex.decode = texel_decode.p;
+      v.tex.num_textures = num_textures;
+      v.tex.env_texels = env_width ? env_texels.p : nullptr;
+      v.tex.env_width = env_width;
+      v.tex.env_height = env_height;
+      for (int k = 0; k < 16; ++k) v.tex.env_to_local[k] = env_to_local[k];
+    }
     return v;
   }
 #ifndef GSP_BLOCKS_PER_CU
@@ -793,6 +846,40 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     ctx->err = "too many triangles (limit 2^28)";
     return GSP_ERR_SCENE;
   }
+  // dormant-feature extension: textures / environment map
+  const bool want_tex = sc->num_textures != 0;
+  const bool want_env = sc->envmap.texels != nullptr;
+  if (want_tex) {
+    if (!sc->textures || !sc->texels || (sc->num_vertices && !sc->uvs)) {
+      ctx->err = "textures need the textures, texels and uvs arrays";
+      return GSP_ERR_SCENE;
+    }
+    for (uint32_t k = 0; k < sc->num_textures; ++k) {
+      const gsp_texture& t = sc->textures[k];
+      if (t.width == 0 || t.height == 0 || t.width > (1u << 15) || t.height > (1u << 15) ||
+          t.first_texel + (uint64_t)t.width * t.height > sc->num_texels) {
+        ctx->err = "texture " + std::to_string(k) + ": size 0, above 32768 or outside the texel array";
+        return GSP_ERR_SCENE;
+      }
+    }
+  }
+  {
+    auto bad = [&](int32_t h) { return h < 0 || (uint32_t)h > sc->num_textures; };
+    bool oob = false;
+    for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_DIFFUSE] && sc->diffuse_bsdfs; ++k) oob |= bad(sc->diffuse_bsdfs[k].has_texture);
+    for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_ROUGH_CONDUCTOR] && sc->rough_conductor_bsdfs; ++k)
+      oob |= bad(sc->rough_conductor_bsdfs[k].has_texture);
+    for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_ROUGH_PLASTIC] && sc->rough_plastic_bsdfs; ++k)
+      oob |= bad(sc->rough_plastic_bsdfs[k].has_texture);
+    if (oob) {
+      ctx->err = "has_texture must be 0 or 1 + the index of an entry of `textures`";
+      return GSP_ERR_SCENE;
+    }
+  }
+  if (want_env && (sc->envmap.width == 0 || sc->envmap.height == 0 || sc->envmap.width > (1u << 15) || sc->envmap.height > (1u << 15))) {
+    ctx->err = "environment map: size 0 or above 32768";
+    return GSP_ERR_SCENE;
+  }
   auto t0 = std::chrono::steady_clock::now();
   hipStream_t st = ctx->stream;
   // ---- PathTracer::prepareScene (PathTracer.cpp:58-93): per-instance table ----
@@ -853,6 +940,31 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   int rc = build_bvh(st, bi, ctx->bvh, ctx->err);
   if (rc != GSP_OK) return rc;
   ctx->bytes += ctx->bvh.bytes;
+  // ---- dormant-feature extension: per-slot uv, texel arrays, environment map ----
+  ctx->textured = want_tex || want_env;
+  ctx->num_textures = want_tex ? sc->num_textures : 0;
+  ctx->env_width = want_env ? sc->envmap.width : 0;
+  ctx->env_height = want_env ? sc->envmap.height : 0;
+  DevBuf<float> d_uv;
+  if (want_tex) {
+    float decode[256];
+    for (int b = 0; b < 256; ++b) decode[b] = sc->texel_decode ? sc->texel_decode[b] : (float)b / 255.0f;
+    CTX_TRY(ctx, ctx->texel_decode.upload(decode, 256, st, &ctx->bytes));
+    CTX_TRY(ctx, ctx->textures.upload(sc->textures, sc->num_textures, st, &ctx->bytes));
+    CTX_TRY(ctx, ctx->texels.upload(sc->texels, sc->num_texels, st, &ctx->bytes));
+    CTX_TRY(ctx, ctx->tri_uv.ensure(8ull * std::max<uint64_t>(total_tris, 1), &ctx->bytes));
+    if (total_tris) {
+      CTX_TRY(ctx, d_uv.upload(sc->uvs, 2ull * sc->num_vertices, st, nullptr));
+      hipLaunchKernelGGL(k_gather_uv, dim3((uint32_t)((total_tris + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (uint32_t)total_tris,
+                         ctx->bvh.slot_to_global, d_first.p, sc->num_instances, d_inst.p, d_uv.p, ctx->tri_uv.p);
+      CTX_TRY(ctx, hipGetLastError());
+    }
+    CTX_TRY(ctx, hipStreamSynchronize(st));  // `decode` is a stack array
+  }
+  if (want_env) {
+    CTX_TRY(ctx, ctx->env_texels.upload(sc->envmap.texels, 4ull * sc->envmap.width * sc->envmap.height, st, &ctx->bytes));
+    for (int k = 0; k < 16; ++k) ctx->env_to_local[k] = sc->envmap.to_local[k];
+  }
   CTX_TRY(ctx, hipStreamSynchronize(st));
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   rc = ctx->ensure_spill();
@@ -996,7 +1108,11 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       3 * ctx->bvh.depth + 4 <= (uint32_t)kLaneStackDepth) {
     // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
     // on its own lane (not when gsp_render merely queues work: those paths ride along with the next call's)
-    hipLaunchKernelGGL(k_finish, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
+    if (ctx->textured)
+      hipLaunchKernelGGL(k_finish<true>, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
+                       L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+    else
+      hipLaunchKernelGGL(k_finish<false>, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
                        L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
     CTX_TRY(ctx, hipGetLastError());
     I.finish = true;
@@ -1053,8 +1169,12 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
           1, std::min<uint64_t>((std::max<uint64_t>(n, 1) + kShadeBlock - 1) / kShadeBlock,
                                 (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (GSP_SHADE_MINWAVES * 256 / kShadeBlock)));  // the resident blocks
-      hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
-                         L.hits.p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+      if (ctx->textured)
+        hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
+                           L.hits.p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+      else
+        hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
+                           L.hits.p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
       CTX_TRY(ctx, hipGetLastError());
       if (timing) CTX_TRY(ctx, hipEventRecord(ev[2], st));
       {

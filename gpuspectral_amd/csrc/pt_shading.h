@@ -217,6 +217,68 @@ struct BsdfResult {
 };
 
 GSP_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// ---- dormant-feature extension: textures and the environment map (include/gpuspectral_pt.h) ----------------------------
+struct TextureView {
+  const float* tri_uv = nullptr;           // 8 floats per triangle slot: u0 v0 u1 v1 | u2 v2 0 0
+  const gsp_texture* textures = nullptr;
+  const uint32_t* texels = nullptr;        // RGBA8
+  const float* decode = nullptr;           // 256 floats
+  uint32_t num_textures = 0;
+  const float* env_texels = nullptr;       // RGBA32F
+  uint32_t env_width = 0, env_height = 0;
+  float env_to_local[16] = {};
+};
+
+GSP_HD int32_t wrap_index(int32_t i, int32_t n) {
+  i = i % n;
+  return i < 0 ? i + n : i;
+}
+GSP_HD float texel_coord(float t, uint32_t n) {  // continuous texel coordinate, texel centres at integers
+  float x = t * (float)n - 0.5f;
+  if (!(gabs(x) < 1.0e9f)) x = 0.0f;  // huge or NaN uv: texel 0
+  return x;
+}
+GSP_HD f3 lerp4(f3 c00, f3 c10, f3 c01, f3 c11, float tx, float ty) {
+  const f3 a = c00 * (1.0f - tx) + c10 * tx;
+  const f3 b = c01 * (1.0f - tx) + c11 * tx;
+  return a * (1.0f - ty) + b * ty;
+}
+GSP_HD f3 decode_texel(const float* decode, uint32_t t) {
+  return mk3(decode[t & 0xffu], decode[(t >> 8) & 0xffu], decode[(t >> 16) & 0xffu]);
+}
+// bilinear, repeat in both directions
+GSP_HD f3 sample_texture(const TextureView& T, uint32_t id, float u, float v) {
+  const gsp_texture tx = T.textures[id];
+  const int32_t w = (int32_t)tx.width, h = (int32_t)tx.height;
+  const float x = texel_coord(u, tx.width), y = texel_coord(v, tx.height);
+  const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+  const int32_t x0 = wrap_index((int32_t)fx, w), y0 = wrap_index((int32_t)fy, h);
+  const int32_t x1 = x0 + 1 == w ? 0 : x0 + 1, y1 = y0 + 1 == h ? 0 : y0 + 1;
+  const uint32_t* base = T.texels + tx.first_texel;
+  const f3 c00 = decode_texel(T.decode, base[(int64_t)y0 * w + x0]), c10 = decode_texel(T.decode, base[(int64_t)y0 * w + x1]);
+  const f3 c01 = decode_texel(T.decode, base[(int64_t)y1 * w + x0]), c11 = decode_texel(T.decode, base[(int64_t)y1 * w + x1]);
+  return lerp4(c00, c10, c01, c11, x - fx, y - fy);
+}
+// lat-long environment radiance for world direction d: repeat in u, clamp in v
+GSP_HD f3 sample_envmap(const TextureView& T, f3 d) {
+  const f3 e = xform_dir(T.env_to_local, d);
+  const float kInv2Pi = 0.15915494309189533577f, kInvPi = 0.31830988618379067154f;
+  const float u = det_atan2f(e.x, -e.z) * kInv2Pi + 0.5f;
+  const float v = 1.0f - det_atan2f(gsqrt(e.x * e.x + e.z * e.z), e.y) * kInvPi;
+  const int32_t w = (int32_t)T.env_width, h = (int32_t)T.env_height;
+  const float x = texel_coord(u, T.env_width), y = texel_coord(v, T.env_height);
+  const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+  const int32_t x0 = wrap_index((int32_t)fx, w);
+  const int32_t x1 = x0 + 1 == w ? 0 : x0 + 1;
+  int32_t y0 = (int32_t)fy, y1 = y0 + 1;
+  y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0);
+  y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+  const float* p = T.env_texels;
+  const f3 c00 = ld3(p + 4 * ((int64_t)y0 * w + x0)), c10 = ld3(p + 4 * ((int64_t)y0 * w + x1));
+  const f3 c01 = ld3(p + 4 * ((int64_t)y1 * w + x0)), c11 = ld3(p + 4 * ((int64_t)y1 * w + x1));
+  return lerp4(c00, c10, c01, c11, x - fx, y - fy);
+}
 GSP_HD f3 mirror(f3 wo) { return mk3(-wo.x, -wo.y, wo.z); }
 GSP_HD f3 reflect_about(f3 wo, f3 wh) { return normalize(-wo + (2.0f * dot(wh, wo)) * wh); }
 GSP_HD float microfacet_pdf_half(f3 wo, f3 wh, float alpha) {  // 0.5 * D_beckmann * |wh.z| / (4 |wo.wh|)
@@ -229,7 +291,7 @@ GSP_HD f3 plastic_diffuse(f3 kD, float Fri, float Fro, float eta, float Ri) {
   return ((((kD * (1.0f - Fri)) * (1.0f - Fro)) * eta) * eta) / (kPi * (1.0f - kD * Ri));
 }
 
-GSP_HD void rough_plastic_value(const gsp_rough_plastic_bsdf& b, f3 wo, f3 wi, f3& wh, f3& f) {
+GSP_HD void rough_plastic_value(const gsp_rough_plastic_bsdf& b, f3 wo, f3 wi, f3& wh, f3& f, bool kd_on = false, f3 kd = f3{}) {
   float no = b.ior_out, nt = b.ior_in;
   float eta = no / nt;
   wh = normalize(wi + wo);
@@ -237,7 +299,7 @@ GSP_HD void rough_plastic_value(const gsp_rough_plastic_bsdf& b, f3 wo, f3 wi, f
   float Fro = fresnel_cos(gabs(dot(wh, wi)), no, nt);
   float Ri = escape_fraction(b.r0, no, nt);
   f3 spec = ((splat(Fri) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) / ((4.0f * gabs(wo.z)) * gabs(wi.z));
-  f = plastic_diffuse(ld3(b.diffuse), Fri, Fro, eta, Ri) + spec;
+  f = plastic_diffuse(kd_on ? kd : ld3(b.diffuse), Fri, Fro, eta, Ri) + spec;
 }
 GSP_HD void rough_floor_value(const gsp_rough_floor_bsdf& b, f3 wo, f3 wi, BsdfResult& r) {  // :595-601,:607-614
   f3 wh = normalize(wi + wo);
@@ -256,7 +318,22 @@ GSP_HD f3 sample_half_or_cosine(uint32_t& rng, f3 wo, float alpha) {
 }
 
 // sampleBSDF, rayhit.rchit:630-641.  wo, wi in the shading frame.
-GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 wo, f3& wi, BsdfResult& r) {
+// index + 1 of the texture that replaces the record's kD, 0 = none (dormant-feature extension, gpuspectral_pt.h)
+GSP_HD uint32_t bsdf_texture(const BsdfTables& T, uint32_t handle) {
+  const uint32_t i = handle & 0xffffu;
+  int32_t k = 0;
+  switch (handle >> 16) {
+    case GSP_BSDF_DIFFUSE: k = T.diffuse[i].has_texture; break;
+    case GSP_BSDF_ROUGH_CONDUCTOR: k = T.rough_conductor[i].has_texture; break;
+    case GSP_BSDF_ROUGH_PLASTIC: k = T.rough_plastic[i].has_texture; break;
+    default: break;
+  }
+  return k > 0 ? (uint32_t)k : 0u;
+}
+
+// kd_on: `kd` (the texel at the hit) stands in for the record's kD
+GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 wo, f3& wi, BsdfResult& r, bool kd_on = false,
+                        f3 kd = f3{}) {
   const uint32_t i = handle & 0xffffu;
   r.f = splat(0.0f);
   r.pdf = 0.0f;
@@ -265,7 +342,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
   switch (handle >> 16) {
     case GSP_BSDF_DIFFUSE: {  // :341-349
       wi = sample_cosine_hemisphere(rng);
-      r.f = ld3(T.diffuse[i].reflectance) / kPi;
+      r.f = (kd_on ? kd : ld3(T.diffuse[i].reflectance)) / kPi;
       r.pdf = cosine_pdf(wi);
     } break;
     case GSP_BSDF_SMOOTH_DIELECTRIC: {  // :362-398
@@ -336,7 +413,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       f3 Fr = fresnel_conductor(ld3(b.eta), ld3(b.k), gabs(wo.z));
       f3 wh = sample_half_beckmann(rng, b.alpha);
       wi = reflect_about(wo, wh);
-      r.f = (((ld3(b.reflectance) * Fr) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
+      r.f = ((((kd_on ? kd : ld3(b.reflectance)) * Fr) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
             ((4.0f * gabs(wi.z)) * gabs(wo.z));
       r.pdf = (beckmann_d(wh, b.alpha) * gabs(wh.z)) / (4.0f * gabs(dot(wo, wh)));
     } break;
@@ -364,7 +441,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       const gsp_rough_plastic_bsdf b = T.rough_plastic[i];
       wi = sample_half_or_cosine(rng, wo, b.alpha);
       f3 wh;
-      rough_plastic_value(b, wo, wi, wh, r.f);
+      rough_plastic_value(b, wo, wi, wh, r.f, kd_on, kd);
       r.pdf = microfacet_pdf_half(wo, wh, b.alpha) + 0.5f * cosine_pdf(wi);
     } break;
     default: break;
@@ -372,14 +449,14 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
 }
 
 // evalBSDF, rayhit.rchit:643-654
-GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfResult& r) {
+GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfResult& r, bool kd_on = false, f3 kd = f3{}) {
   const uint32_t i = handle & 0xffffu;
   r.f = splat(0.0f);
   r.pdf = 0.0f;
   r.delta = false;
   switch (handle >> 16) {
     case GSP_BSDF_DIFFUSE:  // :351-358
-      r.f = ld3(T.diffuse[i].reflectance) / kPi;
+      r.f = (kd_on ? kd : ld3(T.diffuse[i].reflectance)) / kPi;
       r.pdf = cosine_pdf(wi);
       break;
     case GSP_BSDF_SMOOTH_DIELECTRIC:  // :400-404
@@ -400,7 +477,7 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
       const gsp_rough_conductor_bsdf b = T.rough_conductor[i];
       f3 Fr = fresnel_conductor(ld3(b.eta), ld3(b.k), gabs(wo.z));
       f3 wh = normalize(wo + wi);
-      r.f = (((Fr * ld3(b.reflectance)) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
+      r.f = (((Fr * (kd_on ? kd : ld3(b.reflectance))) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
             ((4.0f * gabs(wi.z)) * gabs(wo.z));
       r.pdf = (beckmann_d(wh, b.alpha) * gabs(wh.z)) / (4.0f * gabs(dot(wo, wh)));
     } break;
@@ -416,7 +493,7 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
     case GSP_BSDF_ROUGH_PLASTIC: {  // :565-582
       const gsp_rough_plastic_bsdf b = T.rough_plastic[i];
       f3 wh;
-      rough_plastic_value(b, wo, wi, wh, r.f);
+      rough_plastic_value(b, wo, wi, wh, r.f, kd_on, kd);
       r.pdf = (0.5f * gmax(beckmann_d(wh, b.alpha) * gabs(wh.z), 0.01f)) / (4.0f * gabs(dot(wo, wh))) +
               0.5f * cosine_pdf(wi);
     } break;

@@ -45,6 +45,7 @@ struct SceneView {
   int32_t root;
   const uint8_t* tables = nullptr;  // the BSDF tables + lights back to back (device: one allocation), for LDS staging
   uint32_t tables_bytes = 0;
+  TextureView tex;                  // dormant-feature extension; read only by the <TEX = true> instantiations
 };
 
 // path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9
@@ -105,6 +106,10 @@ struct ShadeOut {
   f3 emitted;        // when !has_shadow: prd.emitted of this bounce (emission term only)
 };
 
+// TEX: the scene carries textures (include/gpuspectral_pt.h, dormant-feature extension).  The reference's shader
+// passes uv = vec2(0) and never reads a texture (rayhit.rchit:716,729): TEX = false is that code, instruction for
+// instruction; TEX = true interpolates the hit's uv and, for a record with has_texture, takes kD from the texture.
+template <bool TEX = false>
 GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathState& in, const HitRec& hit,
                          ShadeOut& out) {
   uint32_t rng = in.seed;                                                 // rchit:668
@@ -127,9 +132,21 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   }
   const Frame onb = make_frame(SN);                                       // :712
   const f3 wo = normalize(to_local(onb, -rayDir));                        // :713
+  bool kd_on = false;
+  f3 kd = splat(0.0f);
+  if (TEX) {
+    const uint32_t tid = bsdf_texture(S.bsdf, bsdf);
+    if (tid != 0u && tid <= S.tex.num_textures && S.tex.tri_uv != nullptr) {
+      const float* uv = S.tex.tri_uv + 8ll * hit.slot;
+      const float tu = (b0 * uv[0] + hit.u * uv[2]) + hit.v * uv[4];
+      const float tv = (b0 * uv[1] + hit.u * uv[3]) + hit.v * uv[5];
+      kd = sample_texture(S.tex, tid - 1u, tu, tv);
+      kd_on = true;
+    }
+  }
   BsdfResult bs;
   f3 wi_l;
-  bsdf_sample(S.bsdf, bsdf, rng, wo, wi_l, bs);                      // :716
+  bsdf_sample(S.bsdf, bsdf, rng, wo, wi_l, bs, kd_on, kd);           // :716
   const float NoW = gabs(wi_l.z);                                         // :717
   const f3 wi = to_world(onb, wi_l);                                      // :718
 
@@ -141,7 +158,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   const float NoL = gabs(dot(SN, L));                                     // :725
   const float lightPdf = ls.pdf;
   BsdfResult lb;
-  bsdf_eval(S.bsdf, bsdf, wo, wL, lb);                               // :729
+  bsdf_eval(S.bsdf, bsdf, wo, wL, lb, kd_on, kd);                    // :729
 
   const bool transmits = bsdf_transmits(bsdf);
   const float NdotV = dot(N, -rayDir);
@@ -201,6 +218,11 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
     out.shadow.next = -1;
   }
 }
+
+// dormant-feature extension: a path that leaves the scene (miss.rmiss:15-18 ends it) first picks up the environment
+// map along its direction.  MIS: sampleLight never draws the environment, so the weight is the one an emitter met after a
+// delta bounce gets (rayhit.rchit:766-768): the full path weight.
+GSP_HD f3 miss_emitted(const SceneView& S, const PathState& in) { return sample_envmap(S.tex, in.d) * in.weight; }
 
 // rayhit.rchit:750-754 + raygen.rgen:60-63 for a vertex that traced a shadow ray
 GSP_HD void connect_vertex(float clampv, const ShadowRay& s, bool occluded, q4& result, bool& nee_done) {

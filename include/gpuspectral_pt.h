@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 2 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes */
+#define GSP_ABI_VERSION 3 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -74,7 +74,8 @@ extern "C" {
 /* ---- BSDF parameter records, scalar layout = S/renderer/Scene.h:29-81 ---- */
 typedef struct gsp_diffuse_bsdf {
   float reflectance[3];
-  int32_t has_texture; /* never set by the reference loader; ignored */
+  int32_t has_texture; /* never set by the reference loader.  0 = none; k > 0 = gsp_scene_desc.textures[k - 1] replaces
+                          `reflectance` (dormant-feature extension below); the same in the two other records with this field */
 } gsp_diffuse_bsdf; /* 16 B */
 
 typedef struct gsp_smooth_dielectric_bsdf {
@@ -151,6 +152,40 @@ typedef struct gsp_camera {
   float fov;
 } gsp_camera;
 
+/*
+ * ---- Dormant features of the reference, SURVEY 8(f).3: bitmap / checkerboard textures and an environment map ----
+ * The reference declares them -- `hasTexture` in DiffuseBSDF / RoughConductorBSDF / RoughPlasticBSDF
+ * (S/renderer/Scene.h:31,66,75; rayhit.rchit:24,54,63), `Scene::envMap` + `Envmap` (Scene.h:116-119,182), the loaders
+ * loadTexture / loadHdrTexture (S/engine/Loader.cpp:66-116), the texture and emitter branches (:122-143,338-346) --
+ * but the branches are commented out, no shader samples a texture and the closest-hit shader passes uv = vec2(0)
+ * (rayhit.rchit:716,729).  A scene loaded the reference's way therefore never sets any field below, and all-zero
+ * (absent) reproduces the reference exactly.  When a caller does set them, the semantics are the ones the declarations
+ * imply, fixed here because no running reference code defines them:
+ *   texture    RGBA8 texels, rows bottom-up as loadTexture writes them (Loader.cpp:74-81: image row height-1 first), so
+ *              v = 0 is the bottom of the image; channel value = texel_decode[byte] (NULL: byte / 255); repeat wrap,
+ *              bilinear filter, texel centres at (i + 0.5) / width; A ignored
+ *   uv         per-vertex (Mesh Vertex::uv, Loader.cpp:50-52), interpolated with the hit's barycentrics like the normal
+ *   where      a record with has_texture = k > 0 takes its kD (Diffuse::reflectance, RoughConductor::reflectance,
+ *              RoughPlastic::diffuse: the `vec3 kD = bsdf.reflectance` lines, rayhit.rchit:342,352,512,526,552,574) from
+ *              textures[k - 1] at the hit's uv
+ *   envmap     RGBA32F lat-long image, rows bottom-up as loadHdrTexture writes them (Loader.cpp:103-110); a path that
+ *              escapes the scene (miss.rmiss) adds weight * texel(direction) behind the firefly test like any emitted term;
+ *              light sampling does not see it (sampleLight draws triangle lights only, rayhit.rchit:123-153).  Direction d
+ *              (world) -> e = to_local * d; u = atan2(e.x, -e.z) / 2pi + 0.5, v = 1 - atan2(|e.xz|, e.y) / pi; wrap in u,
+ *              clamp in v, bilinear.
+ */
+typedef struct gsp_texture {
+  uint32_t width, height;
+  uint64_t first_texel; /* index of texel (0, 0) in gsp_scene_desc.texels */
+} gsp_texture;          /* 16 B */
+
+typedef struct gsp_envmap {
+  const float* texels; /* width * height RGBA32F, NULL = no environment map */
+  uint32_t width, height;
+  float to_local[16];  /* world -> envmap frame, glm memory order (the inverse of Envmap::transform, Scene.h:118; the
+                          host inverts it so that no matrix inversion sits on the parity path) */
+} gsp_envmap;
+
 typedef struct gsp_scene_desc {
   const gsp_instance* instances;
   uint32_t num_instances;
@@ -172,6 +207,15 @@ typedef struct gsp_scene_desc {
   uint32_t num_lights;
 
   gsp_camera camera;
+
+  /* dormant-feature extension (see above); all zero = the reference's behaviour */
+  const float* uvs;             /* tight float2 per vertex (same indexing as positions), or NULL */
+  const gsp_texture* textures;
+  uint32_t num_textures;
+  const uint32_t* texels;       /* RGBA8, R in bits 0-7 */
+  uint64_t num_texels;
+  const float* texel_decode;    /* 256 floats (e.g. an sRGB -> linear table), or NULL = byte / 255 */
+  gsp_envmap envmap;
 } gsp_scene_desc;
 
 /*

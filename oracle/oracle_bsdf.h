@@ -466,38 +466,65 @@ static inline bool isTransimissionBSDF(uint32_t type) { return type == GSP_BSDF_
 
 // rayhit.rchit:630-654.  An out-of-range type/index is a scene error that the
 // reference leaves undefined; the oracle returns a zero, non-delta response.
-static inline void sampleBSDF(const gsp_scene_desc& sc, uint32_t handle, Rng& g, vec3 wo, vec3& wi, BSDFOutput& res) {
+// `tex`: non-null when the record's hasTexture selects a texture -- the texel at the hit's uv, which stands in for kD
+// (the GLSL signature passes `vec2 uv`; the lookup itself is oracle_texture.h, the dormant-feature extension)
+static inline void sampleBSDF(const gsp_scene_desc& sc, uint32_t handle, Rng& g, vec3 wo, vec3& wi, BSDFOutput& res,
+                              const vec3* tex = nullptr) {
   uint32_t i = handle & 0xffffu;
   res.bsdf = V(0.0f);
   res.pdf = 0.0f;
   res.isDelta = false;
   wi = V(0.0f, 0.0f, 1.0f);
   switch (handle >> 16) {
-    case GSP_BSDF_DIFFUSE: diffuseBSDFSample(sc.diffuse_bsdfs[i], g, wo, wi, res); break;
+    case GSP_BSDF_DIFFUSE: {
+      auto rec = sc.diffuse_bsdfs[i];
+      if (tex) rec.reflectance[0] = tex->x, rec.reflectance[1] = tex->y, rec.reflectance[2] = tex->z;
+      diffuseBSDFSample(rec, g, wo, wi, res);
+    } break;
     case GSP_BSDF_SMOOTH_DIELECTRIC: smoothDielectricBSDFSample(sc.smooth_dielectric_bsdfs[i], g, wo, wi, res); break;
     case GSP_BSDF_SMOOTH_CONDUCTOR: smoothConductorBSDFSample(sc.smooth_conductor_bsdfs[i], g, wo, wi, res); break;
     case GSP_BSDF_SMOOTH_PLASTIC: smoothPlasticBSDFSample(sc.smooth_plastic_bsdfs[i], g, wo, wi, res); break;
-    case GSP_BSDF_ROUGH_CONDUCTOR: roughConductorBSDFSample(sc.rough_conductor_bsdfs[i], g, wo, wi, res); break;
+    case GSP_BSDF_ROUGH_CONDUCTOR: {
+      auto rec = sc.rough_conductor_bsdfs[i];
+      if (tex) rec.reflectance[0] = tex->x, rec.reflectance[1] = tex->y, rec.reflectance[2] = tex->z;
+      roughConductorBSDFSample(rec, g, wo, wi, res);
+    } break;
     case GSP_BSDF_SMOOTH_FLOOR: smoothFloorBSDFSample(sc.smooth_floor_bsdfs[i], g, wo, wi, res); break;
     case GSP_BSDF_ROUGH_FLOOR: roughFloorBSDFSample(sc.rough_floor_bsdfs[i], g, wo, wi, res); break;
-    case GSP_BSDF_ROUGH_PLASTIC: roughPlasticBSDFSample(sc.rough_plastic_bsdfs[i], g, wo, wi, res); break;
+    case GSP_BSDF_ROUGH_PLASTIC: {
+      auto rec = sc.rough_plastic_bsdfs[i];
+      if (tex) rec.diffuse[0] = tex->x, rec.diffuse[1] = tex->y, rec.diffuse[2] = tex->z;
+      roughPlasticBSDFSample(rec, g, wo, wi, res);
+    } break;
     default: break;
   }
 }
-static inline void evalBSDF(const gsp_scene_desc& sc, uint32_t handle, vec3 wo, vec3 wi, BSDFOutput& res) {
+static inline void evalBSDF(const gsp_scene_desc& sc, uint32_t handle, vec3 wo, vec3 wi, BSDFOutput& res, const vec3* tex = nullptr) {
   uint32_t i = handle & 0xffffu;
   res.bsdf = V(0.0f);
   res.pdf = 0.0f;
   res.isDelta = false;
   switch (handle >> 16) {
-    case GSP_BSDF_DIFFUSE: diffuseBSDFEval(sc.diffuse_bsdfs[i], wo, wi, res); break;
+    case GSP_BSDF_DIFFUSE: {
+      auto rec = sc.diffuse_bsdfs[i];
+      if (tex) rec.reflectance[0] = tex->x, rec.reflectance[1] = tex->y, rec.reflectance[2] = tex->z;
+      diffuseBSDFEval(rec, wo, wi, res);
+    } break;
     case GSP_BSDF_SMOOTH_DIELECTRIC: smoothDielectricBSDFEval(sc.smooth_dielectric_bsdfs[i], wo, wi, res); break;
     case GSP_BSDF_SMOOTH_CONDUCTOR: smoothConductorBSDFEval(sc.smooth_conductor_bsdfs[i], wo, wi, res); break;
     case GSP_BSDF_SMOOTH_PLASTIC: smoothPlasticBSDFEval(sc.smooth_plastic_bsdfs[i], wo, wi, res); break;
-    case GSP_BSDF_ROUGH_CONDUCTOR: roughConductorBSDFEval(sc.rough_conductor_bsdfs[i], wo, wi, res); break;
+    case GSP_BSDF_ROUGH_CONDUCTOR: {
+      auto rec = sc.rough_conductor_bsdfs[i];
+      if (tex) rec.reflectance[0] = tex->x, rec.reflectance[1] = tex->y, rec.reflectance[2] = tex->z;
+      roughConductorBSDFEval(rec, wo, wi, res);
+    } break;
     case GSP_BSDF_SMOOTH_FLOOR: smoothFloorBSDFEval(sc.smooth_floor_bsdfs[i], wo, wi, res); break;
     case GSP_BSDF_ROUGH_FLOOR: roughFloorBSDFEval(sc.rough_floor_bsdfs[i], wo, wi, res); break;
-    case GSP_BSDF_ROUGH_PLASTIC: roughPlasticBSDFEval(sc.rough_plastic_bsdfs[i], wo, wi, res); break;
+    case GSP_BSDF_ROUGH_PLASTIC: {
+      auto rec = sc.rough_plastic_bsdfs[i];
+      if (tex) rec.diffuse[0] = tex->x, rec.diffuse[1] = tex->y, rec.diffuse[2] = tex->z;
+      roughPlasticBSDFEval(rec, wo, wi, res);
+    } break;
     default: break;
   }
 }

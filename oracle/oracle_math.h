@@ -251,4 +251,30 @@ static inline float det_expf(float x) {
   return (y * s1) * s2;
 }
 
+// atan2 for the environment-map lookup of the dormant-feature extension (include/gpuspectral_pt.h).  No reference code
+// runs it; the oracle fixes one implementation: Cephes atanf (reduction at tan(pi/8), tan(3pi/8); degree-4 minimax in
+// x^2), the first-quadrant angle of (|y|, |x|) reflected by the signs.  atan2(0, 0) = 0.
+static inline float det_atanf_q1(float t) {  // t >= 0
+  float base = 0.0f;
+  if (t > 2.414213562373095f) {
+    base = 1.5707963267948966f;
+    t = -1.0f / t;
+  } else if (t > 0.4142135623730950f) {
+    base = 0.7853981633974483f;
+    t = (t - 1.0f) / (t + 1.0f);
+  }
+  float z = t * t;
+  float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = fmaf(p, z, 1.99777106478e-1f);
+  p = fmaf(p, z, -3.33329491539e-1f);
+  return base + fmaf(p * z, t, t);
+}
+static inline float det_atan2f(float y, float x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  if (!(ax > 0.0f) && !(ay > 0.0f)) return 0.0f;
+  float a = ax == 0.0f ? 1.5707963267948966f : det_atanf_q1(ay / ax);
+  if (x < 0.0f) a = 3.14159265358979323846f - a;
+  return y < 0.0f ? -a : a;
+}
+
 }  // namespace orc

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "oracle_bsdf.h"
+#include "oracle_texture.h"
 
 namespace orc {
 
@@ -394,6 +395,7 @@ struct SceneCtx {
   std::vector<uint32_t> triFirst;    // first global triangle id of each instance
   float fov;
   float toWorld[16];
+  TexelDecode decode{nullptr};  // dormant-feature extension (oracle_texture.h)
 };
 
 static inline bool isvalid(float x) { return !gisnan(x) && !gisinf(x); }
@@ -435,9 +437,19 @@ static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit,
   }
   Onb onb = onbCreate(SN);                                                 // :712
   vec3 wo = normalize(onbTransform(onb, -rayDir));                         // :713
+  // the reference passes uv = vec2(0) here and never samples (:716,729); with the dormant-feature extension the hit's
+  // interpolated uv selects the texel that stands in for kD
+  vec3 texel = V(0.0f);
+  const vec3* tex = nullptr;
+  if (int k = textureOf(S.sc, instance.bsdf)) {
+    const float* T = S.sc.uvs + 2ull * ix;
+    vec2 uv = {(bary.x * T[0] + bary.y * T[2]) + bary.z * T[4], (bary.x * T[1] + bary.y * T[3]) + bary.z * T[5]};
+    texel = textureLookup(S.sc, S.decode, (uint32_t)k - 1u, uv);
+    tex = &texel;
+  }
   BSDFOutput bsdfRes;
   vec3 wi;
-  sampleBSDF(S.sc, instance.bsdf, rng, wo, wi, bsdfRes);                   // :716
+  sampleBSDF(S.sc, instance.bsdf, rng, wo, wi, bsdfRes, tex);              // :716
   float NoW = gabs(wi.z);                                                  // :717
   wi = onbUntransform(onb, wi);                                            // :718
 
@@ -449,7 +461,7 @@ static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit,
   float lightPdf = lightRes.pdf;                                           // :726
 
   BSDFOutput lightBsdfRes;
-  evalBSDF(S.sc, instance.bsdf, wo, wL, lightBsdfRes);                     // :729
+  evalBSDF(S.sc, instance.bsdf, wo, wL, lightBsdfRes, tex);                // :729
 
   bool neeDone = false;
   const uint32_t btype = instance.bsdf >> 16;
@@ -538,6 +550,8 @@ static vec3 samplePixel(const SceneCtx& S, const RenderCfg& cfg, uint32_t px, ui
       closestHitShader(S, prd, h, prd.origin, C, collect);
     } else {
       prd.done = 1;                                                        // miss.rmiss:15-18
+      // dormant-feature extension: the escaping path sees the environment map
+      if (S.sc.envmap.texels) prd.emitted = envmapLookup(S.sc, prd.direction) * prd.weight;
     }
     rng.state = prd.seed;                                                  // :59
     if (prd.emitted.x < cfg.clamp && prd.emitted.y < cfg.clamp && prd.emitted.z < cfg.clamp) {  // :60-63
@@ -568,6 +582,9 @@ struct Oracle {
   std::vector<gsp_rough_floor_bsdf> b6;
   std::vector<gsp_rough_plastic_bsdf> b7;
   std::vector<gsp_triangle_light> lights;
+  std::vector<float> uvs, envTexels;  // dormant-feature extension
+  std::vector<gsp_texture> textures;
+  std::vector<uint32_t> texels;
   double build_seconds = 0.0;
 };
 
@@ -619,6 +636,25 @@ void* oracle_create(const gsp_scene_desc* sc) {
   d.rough_floor_bsdfs = o->b6.data();
   d.rough_plastic_bsdfs = o->b7.data();
   d.lights = o->lights.data();
+  // dormant-feature extension
+  const bool textured = sc->num_textures && sc->textures && sc->texels && sc->uvs;
+  if (textured) {
+    copyv(o->uvs, sc->uvs, 2 * (size_t)sc->num_vertices);
+    copyv(o->textures, sc->textures, sc->num_textures);
+    copyv(o->texels, sc->texels, (size_t)sc->num_texels);
+  }
+  d.uvs = textured ? o->uvs.data() : nullptr;
+  d.textures = textured ? o->textures.data() : nullptr;
+  d.texels = textured ? o->texels.data() : nullptr;
+  d.num_textures = textured ? sc->num_textures : 0;
+  o->S.decode = TexelDecode(sc->texel_decode);
+  d.texel_decode = nullptr;  // (copied into S.decode)
+  if (sc->envmap.texels && sc->envmap.width && sc->envmap.height) {
+    copyv(o->envTexels, sc->envmap.texels, 4 * (size_t)sc->envmap.width * sc->envmap.height);
+    d.envmap.texels = o->envTexels.data();
+  } else {
+    d.envmap.texels = nullptr;
+  }
   // PathTracer.cpp:62  transformInvT = inverse(transpose(M))
   o->S.transformInvT.resize(16ull * sc->num_instances);
   uint32_t first = 0;

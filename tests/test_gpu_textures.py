@@ -1,0 +1,91 @@
+"""SURVEY 8(f).3 -- the reference's dormant features (textures, environment map) as an opt-in extension of the C ABI.
+
+No reference code runs these (Loader.cpp:122-143,338-346 are commented out; rayhit.rchit:716,729 pass uv = vec2(0)), so
+the oracle's oracle_texture.h is the definition and the HIP path must match it bit for bit like everything else.  The
+second half checks that scenes which do not set the fields are untouched by the extension's existence.
+"""
+import numpy as np
+import pytest
+
+import textured
+from conftest import rmse
+
+pytestmark = pytest.mark.gpu
+
+
+def render_both(g, oracle_mod, sc, W, H, spp, env=None):
+    import os
+
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        with g.Context(0) as ctx:
+            ctx.upload_scene(sc)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=spp)
+            img = ctx.download().reshape(-1, 4)
+            st = ctx.stats()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    ref, ost = oracle_mod.Oracle(sc).render(W, H, spp=spp)
+    return img, ref, st, ost
+
+
+@pytest.mark.parametrize("mode", ["default", "wavefront-only"])
+@pytest.mark.parametrize("what", ["textures", "envmap", "both", "both-srgb"])
+def test_open_scene_matches_oracle(oracle_mod, what, mode):
+    import gpuspectral_amd as g
+
+    sc = textured.decorate(textured.open_scene(16), seed=3, textures=what != "envmap", envmap=what != "textures",
+                           decode=textured.srgb_table() if what == "both-srgb" else None)
+    img, ref, st, ost = render_both(g, oracle_mod, sc, 96, 64, 4, {"GSP_FINISH_PATHS": "0"} if mode == "wavefront-only" else None)
+    assert np.array_equal(img, ref), "RMSE %.3e, %d pixels differ" % (rmse(img, ref), int((img != ref).any(1).sum()))
+    assert st["extension_rays"] == ost["extension_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+
+
+def test_extension_changes_the_image_and_only_where_it_should(oracle_mod):
+    """Same scene with and without the fields: the textured spheres / the sky change, and a scene whose has_texture
+    fields are set but which passes no textures array renders exactly like the plain one (the reference's case: the
+    loader never fills them)."""
+    import gpuspectral_amd as g
+
+    plain = textured.open_scene(16)
+    img0, ref0, _, _ = render_both(g, oracle_mod, plain, 96, 64, 2)
+    assert np.array_equal(img0, ref0)
+    deco = textured.decorate(textured.open_scene(16), seed=3)
+    img1, ref1, _, _ = render_both(g, oracle_mod, deco, 96, 64, 2)
+    assert np.array_equal(img1, ref1)
+    assert not np.array_equal(img0, img1)
+    sky = img0.reshape(64, 96, 4)[:8]  # top rows look at the sky: black without an environment map
+    assert float(sky[..., :3].max()) == 0.0 and float(img1.reshape(64, 96, 4)[:8, :, :3].min()) > 0.0
+
+
+def test_cornell_materials_with_textures(oracle_mod, materials_scene):
+    """All eight BSDF types in one closed room, the three texturable ones textured."""
+    import copy
+
+    import gpuspectral_amd as g
+
+    sc = textured.decorate(copy.deepcopy(materials_scene), seed=5, envmap=False)
+    img, ref, st, ost = render_both(g, oracle_mod, sc, 80, 80, 3)
+    assert np.array_equal(img, ref), "RMSE %.3e" % rmse(img, ref)
+    assert st["shadow_rays"] == ost["shadow_rays"]
+
+
+def test_bad_extension_inputs_are_rejected(materials_scene):
+    import copy
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi
+
+    with g.Context(0) as ctx:
+        sc = textured.decorate(copy.deepcopy(materials_scene), seed=1, envmap=False)
+        sc.bsdfs[abi.BSDF_NAMES.index("diffuse")]["has_texture"][0] = 99  # beyond the textures array
+        with pytest.raises(g.GspError, match="has_texture"):
+            ctx.upload_scene(sc)
+        sc = textured.decorate(copy.deepcopy(materials_scene), seed=1, envmap=False)
+        sc.textures["first_texel"][-1] = len(sc.texels)  # runs off the texel array
+        with pytest.raises(g.GspError, match="texture 3"):
+            ctx.upload_scene(sc)
+        ctx.upload_scene(materials_scene)  # the context is still usable
