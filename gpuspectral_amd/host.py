@@ -31,6 +31,10 @@ def load():
     L.gsph_last_error.restype = C.c_char_p
     L.gsph_load_scene.restype = vp
     L.gsph_load_scene.argtypes = [C.c_char_p, C.c_char_p]
+    L.gsph_load_scene_ex.restype = vp
+    L.gsph_load_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.gsph_load_bitmap.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp]
+    L.gsph_load_hdr_bitmap.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp]
     L.gsph_scene_free.argtypes = [vp]
     L.gsph_scene_free.restype = None
     L.gsph_scene_desc.restype = C.POINTER(abi.SceneDesc)
@@ -73,9 +77,15 @@ def _view(ptr, count, dtype):
 class Scene:
     """A C++ GPUSpectral::Scene produced by loadScene (S/engine/Loader.cpp:253-349)."""
 
-    def __init__(self, path, asset_dir=None):
+    def __init__(self, path, asset_dir=None, dormant_features=False, srgb_textures=True):
+        """dormant_features: LoadOptions::dormantFeatures (textures / environment map, SURVEY 8(f).3); the default is the
+        reference's behaviour."""
         self._L = load()
-        self._h = self._L.gsph_load_scene(path.encode(), asset_dir.encode() if asset_dir else None)
+        ad = asset_dir.encode() if asset_dir else None
+        if dormant_features:
+            self._h = self._L.gsph_load_scene_ex(path.encode(), ad, 1, 1 if srgb_textures else 0)
+        else:
+            self._h = self._L.gsph_load_scene(path.encode(), ad)
         if not self._h:
             raise GspError("loadScene(%s): %s" % (path, _err(self._L)))
 
@@ -112,7 +122,40 @@ class Scene:
         sc.lights = _view(d.lights, d.num_lights, abi.LIGHT_DT)
         sc.to_world = np.array(list(d.camera.to_world), np.float32)
         sc.fov = np.float32(d.camera.fov)
+        if d.num_textures:
+            sc.uvs = _view(d.uvs, d.num_vertices * 2, np.float32).reshape(-1, 2)
+            sc.textures = _view(d.textures, d.num_textures, abi.TEXTURE_DT)
+            sc.texels = _view(d.texels, d.num_texels, np.uint32)
+            sc.texel_decode = _view(d.texel_decode, 256, np.float32) if d.texel_decode else None
+        if d.envmap.texels:
+            w, h = d.envmap.width, d.envmap.height
+            sc.env_texels = _view(d.envmap.texels, w * h * 4, np.float32).reshape(h, w, 4)
+            sc.env_to_local = np.array(list(d.envmap.to_local), np.float32)
         return sc
+
+
+def load_bitmap(path):
+    """Image.h loadBitmap: (H, W, 4) uint8, row 0 = bottom image row."""
+    L = load()
+    w, h = C.c_uint32(), C.c_uint32()
+    if L.gsph_load_bitmap(path.encode(), C.byref(w), C.byref(h), None):
+        raise GspError("loadBitmap(%s): %s" % (path, _err(L)))
+    out = np.zeros((h.value, w.value), np.uint32)
+    if L.gsph_load_bitmap(path.encode(), C.byref(w), C.byref(h), out.ctypes.data):
+        raise GspError("loadBitmap(%s): %s" % (path, _err(L)))
+    return out.view(np.uint8).reshape(h.value, w.value, 4)
+
+
+def load_hdr_bitmap(path):
+    """Image.h loadHdrBitmap: (H, W, 4) float32, row 0 = bottom image row."""
+    L = load()
+    w, h = C.c_uint32(), C.c_uint32()
+    if L.gsph_load_hdr_bitmap(path.encode(), C.byref(w), C.byref(h), None):
+        raise GspError("loadHdrBitmap(%s): %s" % (path, _err(L)))
+    out = np.zeros((h.value, w.value, 4), np.float32)
+    if L.gsph_load_hdr_bitmap(path.encode(), C.byref(w), C.byref(h), out.ctypes.data):
+        raise GspError("loadHdrBitmap(%s): %s" % (path, _err(L)))
+    return out
 
 
 class PathTracer:

@@ -12,6 +12,7 @@
 // <ref id> resolution into anonymous children, typed property getters with defaults
 // (number 0, colour 0, bool default), fan triangulation, relative OBJ indices.
 #include "Loader.h"
+#include "Image.h"
 
 #include <algorithm>
 #include <cmath>
@@ -370,15 +371,51 @@ MeshPtr builtinQuadMesh(uint32_t id, bool box) {
   return std::make_shared<Mesh>(id, std::move(v));
 }
 
+struct LoadContext {
+  std::string parentPath;
+  LoadOptions options;
+  std::map<std::string, uint32_t> textureCache;  // file / checkerboard key -> hasTexture value
+};
+
+// Loader.cpp:122-143 (dormant there): the texture child named `slot` of a BSDF -> hasTexture value, 0 = none
+int loadTexture(Scene& scene, LoadContext& lc, const Object& bsdf, const std::string& slot, const char* what) {
+  for (auto& nc : bsdf.named) {
+    if (nc.first != slot || nc.second->kind != "texture") continue;
+    if (!lc.options.dormantFeatures) {
+      scene.warnings.push_back(std::string(what) + ": textured " + slot + " unsupported (Loader.cpp:122-143), colour default used");
+      return 0;
+    }
+    const Object& tex = *nc.second;
+    if (tex.plugin == "bitmap") {
+      const std::string file = joinPath(lc.parentPath, tex.string("filename"));
+      auto it = lc.textureCache.find(file);
+      if (it != lc.textureCache.end()) return (int)it->second;
+      Image8 img = loadBitmap(file);  // throws like the reference's loadTexture (Loader.cpp:70-72)
+      const uint32_t id = scene.addTexture(Texture{img.width, img.height, std::move(img.texels)});
+      lc.textureCache.emplace(file, id);
+      return (int)id;
+    }
+    if (tex.plugin == "checkerboard") {  // Loader.cpp:127-139
+      const uint32_t uSize = (uint32_t)tex.number("uscale", 1.0f), vSize = (uint32_t)tex.number("vscale", 1.0f);
+      const vec3 on = tex.color("color0"), off = tex.color("color1");
+      const float c0[3] = {on.x, on.y, on.z}, c1[3] = {off.x, off.y, off.z};
+      Image8 img = makeCheckerboard(uSize, vSize, c0, c1);
+      return (int)scene.addTexture(Texture{img.width, img.height, std::move(img.texels)});
+    }
+    scene.warnings.push_back(std::string(what) + ": texture type '" + tex.plugin + "' unsupported, colour default used");
+    return 0;
+  }
+  return 0;
+}
+
 // Loader.cpp:145-234
-void loadMaterial(Scene& scene, Material* material, const Object& obj) {
+void loadMaterial(Scene& scene, Material* material, const Object& obj, LoadContext& lc) {
   const std::string& type = obj.plugin;
   if (type == "twosided") material->twofaced = true;
   if (type == "diffuse") {
     vec3 rgb = obj.color("reflectance");
-    for (auto& nc : obj.named)
-      if (nc.first == "reflectance") scene.warnings.push_back("diffuse: textured reflectance unsupported (Loader.cpp:122-143), colour default used");
-    material->bsdf = scene.addDiffuseBSDF(DiffuseBSDF{{rgb.x, rgb.y, rgb.z}, 0});
+    const int tex = loadTexture(scene, lc, obj, "reflectance", "diffuse");
+    material->bsdf = scene.addDiffuseBSDF(DiffuseBSDF{{rgb.x, rgb.y, rgb.z}, tex});
   } else if (type == "roughplastic") {
     vec3 rgb = obj.color("diffuse_reflectance");
     float alpha = obj.number("alpha");
@@ -394,8 +431,7 @@ void loadMaterial(Scene& scene, Material* material, const Object& obj) {
     b.ior_out = 1.0f;
     b.r0 = R0;
     b.alpha = (float)std::sqrt(2.0f) * alpha;
-    for (auto& nc : obj.named)
-      if (nc.first == "diffuse_reflectance") scene.warnings.push_back("roughplastic: textured diffuse_reflectance unsupported, colour default used");
+    b.has_texture = loadTexture(scene, lc, obj, "diffuse_reflectance", "roughplastic");
     material->bsdf = scene.addRoughPlasticBSDF(b);
   } else if (type == "dielectric") {
     float intIOR = obj.number("int_ior");
@@ -427,10 +463,11 @@ void loadMaterial(Scene& scene, Material* material, const Object& obj) {
     b.k[0] = k.x; b.k[1] = k.y; b.k[2] = k.z;
     b.reflectance[0] = refl.x; b.reflectance[1] = refl.y; b.reflectance[2] = refl.z;
     b.alpha = (float)std::sqrt(2) * alpha;
+    b.has_texture = loadTexture(scene, lc, obj, "specular_reflectance", "roughconductor");
     material->bsdf = scene.addRoughConductorBSDF(b);
   }
   for (auto& child : obj.children)
-    if (child->kind == "bsdf") loadMaterial(scene, material, *child);
+    if (child->kind == "bsdf") loadMaterial(scene, material, *child, lc);
 }
 
 }  // namespace
@@ -534,7 +571,7 @@ MeshPtr loadMesh(const std::string& path, uint32_t id) {
 }
 
 // Loader.cpp:253-349
-Scene loadScene(const std::string& path, const std::string& assetDirArg) {
+Scene loadScene(const std::string& path, const std::string& assetDirArg, const LoadOptions& options) {
   std::ifstream f(path, std::ios::binary);
   if (!f) throw std::runtime_error("cannot open scene file: " + path);
   std::stringstream ss;
@@ -550,6 +587,10 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg) {
   std::unordered_map<std::string, MeshPtr> meshCache;
   uint32_t nextMeshId = 1;
   Scene outScene;
+  outScene.srgbTextures = options.srgbTextures;
+  LoadContext lc;
+  lc.parentPath = parentPath;
+  lc.options = options;
   resolveRefs(ps, outScene.warnings);
   auto loadOrGetMesh = [&](const std::string& objPath, int builtin) -> MeshPtr {
     auto it = meshCache.find(objPath);
@@ -597,7 +638,7 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg) {
       Material material;
       for (auto& child : obj->children) {
         if (child->kind == "bsdf") {
-          loadMaterial(outScene, &material, *child);
+          loadMaterial(outScene, &material, *child, lc);
         } else if (child->kind == "emitter" && child->plugin == "area") {
           material.emission = child->color("radiance");
           emitting = true;
@@ -636,7 +677,22 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg) {
       outScene.camera.setFov((float)(fov * M_PI / 180.f));
       outScene.camera.setToWorld(transpose(make_mat4(rowMajor)));
     } else if (obj->kind == "emitter") {
-      outScene.warnings.push_back("top-level emitter (envmap) ignored, as in the reference (Loader.cpp:338-346)");
+      if (!options.dormantFeatures || obj->plugin != "envmap") {
+        outScene.warnings.push_back("top-level emitter (envmap) ignored, as in the reference (Loader.cpp:338-346)");
+      } else {  // Loader.cpp:339-345, dormant there
+        ImageF img = loadHdrBitmap(joinPath(parentPath, obj->string("filename")));
+        float rowMajor[16];
+        for (int k = 0; k < 16; ++k) rowMajor[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+        auto tw = obj->props.find("to_world");
+        if (tw != obj->props.end() && tw->second.type == PT_TRANSFORM) std::memcpy(rowMajor, tw->second.matrix, sizeof(rowMajor));
+        outScene.envMap.width = img.width;
+        outScene.envMap.height = img.height;
+        outScene.envMap.texels = std::move(img.texels);
+        // (the dormant line is make_mat4 without the transpose the shapes and the sensor get, :286,335 vs :343; a
+        // row-major file matrix read as column-major would be the inverse rotation -- the transpose is applied here)
+        outScene.envMap.transform = transpose(make_mat4(rowMajor));
+        outScene.hasEnvMap = true;
+      }
     }
   }
   return outScene;
@@ -655,6 +711,7 @@ void flattenScene(const Scene& scene, FlatScene& out) {
       for (uint32_t i = 0; i < count; ++i) {
         out.positions.insert(out.positions.end(), {vs[i].pos.x, vs[i].pos.y, vs[i].pos.z});
         out.normals.insert(out.normals.end(), {vs[i].normal.x, vs[i].normal.y, vs[i].normal.z});
+        if (!scene.textures.empty()) out.uvs.insert(out.uvs.end(), {vs[i].uv.x, vs[i].uv.y});
       }
       it = placed.emplace(m, std::make_pair(first, count)).first;
     }
@@ -696,6 +753,60 @@ void flattenScene(const Scene& scene, FlatScene& out) {
   d.num_lights = (uint32_t)scene.triangleLights.size();
   std::memcpy(d.camera.to_world, scene.camera.getToWorld().data(), sizeof(d.camera.to_world));
   d.camera.fov = scene.camera.getFov();
+  // ---- dormant features ----
+  if (!scene.textures.empty()) {
+    for (const Texture& t : scene.textures) {
+      out.textures.push_back(gsp_texture{t.width, t.height, (uint64_t)out.texels.size()});
+      out.texels.insert(out.texels.end(), t.texels.begin(), t.texels.end());
+    }
+    out.texelDecode.resize(256);
+    for (int b = 0; b < 256; ++b) {
+      const double c = b / 255.0;  // IEC 61966-2-1 sRGB -> linear; the table is DATA for the renderer and the oracle alike
+      out.texelDecode[b] = scene.srgbTextures ? (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4)) : (float)b / 255.0f;
+    }
+    d.uvs = out.uvs.data();
+    d.textures = out.textures.data();
+    d.num_textures = (uint32_t)out.textures.size();
+    d.texels = out.texels.data();
+    d.num_texels = out.texels.size();
+    d.texel_decode = out.texelDecode.data();
+  }
+  if (scene.hasEnvMap) {
+    out.envTexels = scene.envMap.texels;
+    d.envmap.texels = out.envTexels.data();
+    d.envmap.width = scene.envMap.width;
+    d.envmap.height = scene.envMap.height;
+    const mat4 inv = inverse(scene.envMap.transform);
+    std::memcpy(d.envmap.to_local, inv.data(), sizeof(d.envmap.to_local));
+  }
+}
+
+mat4 inverse(const mat4& a) {
+  // Gauss-Jordan with partial pivoting in double precision; a singular matrix yields the identity
+  double m[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      m[r][c] = a[c][r];
+      m[r][4 + c] = r == c ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r)
+      if (std::fabs(m[r][col]) > std::fabs(m[piv][col])) piv = r;
+    if (std::fabs(m[piv][col]) < 1e-30) return mat4::identity();
+    for (int c = 0; c < 8; ++c) std::swap(m[col][c], m[piv][c]);
+    const double inv = 1.0 / m[col][col];
+    for (int c = 0; c < 8; ++c) m[col][c] *= inv;
+    for (int r = 0; r < 4; ++r)
+      if (r != col) {
+        const double f = m[r][col];
+        for (int c = 0; c < 8; ++c) m[r][c] -= f * m[col][c];
+      }
+  }
+  mat4 out;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) out[c][r] = (float)m[r][4 + c];
+  return out;
 }
 
 }  // namespace GPUSpectral

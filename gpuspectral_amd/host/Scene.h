@@ -119,6 +119,19 @@ struct Material {
   BSDFHandle bsdf;
 };
 
+// ---- dormant features of the reference (include/gpuspectral_pt.h "Dormant features") ----
+// The reference keeps a Handle<HwTexture> where this keeps the decoded image (loadTexture, Loader.cpp:66-86), and its
+// Envmap is {texture, transform} (Scene.h:116-119).
+struct Texture {
+  uint32_t width = 0, height = 0;
+  std::vector<uint32_t> texels;  // RGBA8, row 0 = bottom image row
+};
+struct Envmap {
+  uint32_t width = 0, height = 0;
+  std::vector<float> texels;  // RGBA32F, row 0 = bottom image row
+  mat4 transform = mat4::identity();  // to_world of the emitter (envMapTransform, Loader.cpp:343-345)
+};
+
 class Camera {
  public:
   void setToWorld(const mat4& m) { toWorld = m; }
@@ -171,14 +184,30 @@ struct Scene {
   std::vector<RoughFloorBSDF> roughFloorBSDFs;
   std::vector<RoughPlasticBSDF> roughPlasticBSDFs;
   std::vector<std::string> warnings;  // what the loader skipped (the reference printed these to stdout)
+
+  // dormant features: filled only by loadScene(..., LoadOptions{.dormantFeatures = true}); a BSDF record's hasTexture is
+  // 1 + the index into `textures`
+  uint32_t addTexture(Texture t) {
+    textures.push_back(std::move(t));
+    return (uint32_t)textures.size();
+  }
+  std::vector<Texture> textures;
+  bool srgbTextures = true;  // 8-bit bitmaps hold sRGB-encoded values (what Mitsuba / Tungsten assume); false = value / 255
+  bool hasEnvMap = false;    // std::optional<Envmap> envMap (Scene.h:182)
+  Envmap envMap;
 };
 
 // Scene flattened to the arrays gsp_scene_desc points at (owns the storage).
 struct FlatScene {
   std::vector<gsp_instance> instances;
   std::vector<float> positions, normals;
+  std::vector<float> uvs, texelDecode, envTexels;  // dormant features
+  std::vector<gsp_texture> textures;
+  std::vector<uint32_t> texels;
   gsp_scene_desc desc{};
 };
+// 4x4 inverse (cofactors, float); used for Envmap::transform -> gsp_envmap.to_local
+mat4 inverse(const mat4& m);
 // Host half of PathTracer::prepareScene (S/renderer/PathTracer.cpp:58-93): instance table in
 // renderObjects order, shared meshes stored once.
 void flattenScene(const Scene& scene, FlatScene& out);

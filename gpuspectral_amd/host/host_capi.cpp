@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <string>
 
+#include "Image.h"
 #include "Loader.h"
 #include "PathTracer.h"
 
@@ -45,7 +46,43 @@ void* gsph_load_scene(const char* path, const char* asset_dir) {
   }
   return b;
 }
+// dormant != 0: loadScene with LoadOptions{dormantFeatures = true, srgbTextures = srgb != 0}
+void* gsph_load_scene_ex(const char* path, const char* asset_dir, int dormant, int srgb) {
+  SceneBox* b = nullptr;
+  int rc = guard([&] {
+    b = new SceneBox();
+    LoadOptions opt;
+    opt.dormantFeatures = dormant != 0;
+    opt.srgbTextures = srgb != 0;
+    b->scene = loadScene(path, asset_dir ? asset_dir : "", opt);
+    flattenScene(b->scene, b->flat);
+  });
+  if (rc) {
+    delete b;
+    return nullptr;
+  }
+  return b;
+}
 void gsph_scene_free(void* s) { delete (SceneBox*)s; }
+
+// Image.h readers.  Two calls: texels == NULL returns the size, the second call fills width * height RGBA8 words
+// (floats x 4 for the HDR reader); rows bottom-up.
+int gsph_load_bitmap(const char* path, uint32_t* width, uint32_t* height, uint32_t* texels) {
+  return guard([&] {
+    Image8 img = loadBitmap(path);
+    *width = img.width;
+    *height = img.height;
+    if (texels) std::memcpy(texels, img.texels.data(), img.texels.size() * sizeof(uint32_t));
+  });
+}
+int gsph_load_hdr_bitmap(const char* path, uint32_t* width, uint32_t* height, float* texels) {
+  return guard([&] {
+    ImageF img = loadHdrBitmap(path);
+    *width = img.width;
+    *height = img.height;
+    if (texels) std::memcpy(texels, img.texels.data(), img.texels.size() * sizeof(float));
+  });
+}
 // The flattened scene (pointers stay valid until gsph_scene_free).
 const gsp_scene_desc* gsph_scene_desc(void* s) { return &((SceneBox*)s)->flat.desc; }
 uint32_t gsph_scene_num_warnings(void* s) { return (uint32_t)((SceneBox*)s)->scene.warnings.size(); }

@@ -1,8 +1,9 @@
 // main.cpp -- headless counterpart of the reference's S/main.cpp:15-30:
 //   Engine + PathTracer + loadScene + Window::run(frame loop)
 // becomes: load the Mitsuba XML, render N samples per pixel, write the HDR framebuffer.
-//   gsp_render <scene.xml> <out.pfm> [width height spp [devices]]     devices: "0" (default) or a list "0,1,2,3":
-//   the frame is then tiled over those GPUs (MultiGpuPathTracer); an index may repeat
+//   gsp_render [--dormant-features] <scene.xml> <out.pfm> [width height spp [devices]]
+//   devices: "0" (default) or a list "0,1,2,3": the frame is then tiled over those GPUs (MultiGpuPathTracer); an index
+//   may repeat.  --dormant-features: LoadOptions::dormantFeatures (bitmap / checkerboard textures, envmap emitter)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,8 +17,14 @@
 using namespace GPUSpectral;
 
 int main(int argc, char** argv) {
+  LoadOptions options;
+  if (argc > 1 && std::string(argv[1]) == "--dormant-features") {
+    options.dormantFeatures = true;
+    --argc;
+    ++argv;
+  }
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s scene.xml out.pfm [width height spp [device | d0,d1,...]]\n", argv[0]);
+    std::fprintf(stderr, "usage: gsp_render [--dormant-features] scene.xml out.pfm [width height spp [device | d0,d1,...]]\n");
     return 2;
   }
   const uint32_t width = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 500;  // S/main.cpp:17: 500x500 window
@@ -31,7 +38,7 @@ int main(int argc, char** argv) {
     if (e == p && *p) break;
   }
   try {
-    Scene scene = loadScene(argv[1]);
+    Scene scene = loadScene(argv[1], "", options);
     for (auto& w : scene.warnings) std::fprintf(stderr, "WARN: %s\n", w.c_str());
     std::vector<float> img;
     gsp_stats st;

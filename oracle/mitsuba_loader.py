@@ -41,26 +41,33 @@ _BOX_FACES = [
 ]
 
 
+_QUAD_UV = [(0.0, 1.0), (1.0, 1.0), (0.0, 0.0), (1.0, 0.0)]  # vt of rect.obj, per corner
+
+
 def _quad(corners, normal):
     order = (0, 2, 1, 2, 3, 1)  # f 1 3 2 / f 3 4 2
     pos = np.array([corners[i] for i in order], F)
     nrm = np.tile(np.array(normal, F), (6, 1))
-    return pos, nrm
+    uv = np.array([_QUAD_UV[i] for i in order], F)
+    return pos, nrm, uv
 
 
-def rect_mesh():
-    return _quad(_RECT_V, (0.0, 0.0, 1.0))
+def rect_mesh(with_uv=False):
+    pos, nrm, uv = _quad(_RECT_V, (0.0, 0.0, 1.0))
+    return (pos, nrm, uv) if with_uv else (pos, nrm)
 
 
-def box_mesh():
-    ps, ns = zip(*[_quad(c, n) for n, c in _BOX_FACES])
+def box_mesh(with_uv=False):
+    ps, ns, us = zip(*[_quad(c, n) for n, c in _BOX_FACES])
+    if with_uv:
+        return np.concatenate(ps), np.concatenate(ns), np.concatenate(us)
     return np.concatenate(ps), np.concatenate(ns)
 
 
-def load_obj(path):
-    """Loader.cpp:19-64: de-indexed position/normal arrays, all shapes concatenated."""
-    v, vn = [], []
-    pos_idx, nrm_idx = [], []
+def load_obj(path, with_uv=False):
+    """Loader.cpp:19-64: de-indexed position/normal (and uv) arrays, all shapes concatenated."""
+    v, vn, vt = [], [], []
+    pos_idx, nrm_idx, uv_idx = [], [], []
     with open(path, "r", errors="replace") as f:
         for line in f:
             if line.startswith("v "):
@@ -69,6 +76,9 @@ def load_obj(path):
             elif line.startswith("vn "):
                 p = line.split()
                 vn.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("vt "):
+                p = line.split()
+                vt.append((float(p[1]), float(p[2])))
             elif line.startswith("f "):
                 corners = []
                 for tok in line.split()[1:]:
@@ -79,11 +89,16 @@ def load_obj(path):
                     if len(parts) >= 3 and parts[2]:
                         ni = int(parts[2])
                         ni = ni - 1 if ni > 0 else len(vn) + ni
-                    corners.append((vi, ni))
+                    ti = -1
+                    if len(parts) >= 2 and parts[1]:
+                        ti = int(parts[1])
+                        ti = ti - 1 if ti > 0 else len(vt) + ti
+                    corners.append((vi, ni, ti))
                 for k in range(2, len(corners)):
                     for c in (corners[0], corners[k - 1], corners[k]):
                         pos_idx.append(c[0])
                         nrm_idx.append(c[1])
+                        uv_idx.append(c[2])
     va = np.array(v, F).reshape(-1, 3)
     pos = va[np.array(pos_idx, np.int64)] if pos_idx else np.zeros((0, 3), F)
     ni = np.array(nrm_idx, np.int64)
@@ -97,6 +112,11 @@ def load_obj(path):
         ln = np.sqrt((fn * fn).sum(1, keepdims=True)).astype(F)
         fn = np.where(ln > 0, fn / np.where(ln > 0, ln, 1), 0).astype(F)
         nrm = np.repeat(fn, 3, axis=0)
+    if with_uv:  # a corner without vt keeps Vertex::uv's default (0, 0)
+        ti = np.array(uv_idx, np.int64)
+        vta = np.concatenate([np.array(vt, F).reshape(-1, 2), np.zeros((1, 2), F)])
+        uv = vta[np.where((ti >= 0) & (ti < len(vt)), ti, len(vt))] if len(ti) else np.zeros((0, 2), F)
+        return np.ascontiguousarray(pos, F), np.ascontiguousarray(nrm, F), np.ascontiguousarray(uv, F)
     return np.ascontiguousarray(pos, F), np.ascontiguousarray(nrm, F)
 
 
@@ -210,9 +230,55 @@ def glm_mul_point(m, p):
     return ((m[0] * x + m[1] * y) + (m[2] * z + m[3] * F(1.0))).astype(F)
 
 
+def srgb_decode_table():
+    """byte -> linear (IEC 61966-2-1), the table flattenScene hands to the renderer."""
+    c = np.arange(256, dtype=np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4).astype(F)
+
+
+def read_bitmap(path):
+    """loadTexture (Loader.cpp:66-86): RGBA8 words, last image row first, A = 0xFF.  PIL stands in for stb_image: PNG is
+    lossless, so this equals the product's own decoder exactly; JPEG decoders agree to a few levels only."""
+    from PIL import Image
+
+    rgb = np.asarray(Image.open(path).convert("RGB"))[::-1]
+    rgba = np.dstack([rgb, np.full(rgb.shape[:2], 255, np.uint8)])
+    return np.ascontiguousarray(rgba)
+
+
+def read_pfm(path):
+    """RGBA32F, rows bottom-up (PFM's own order), A = 1."""
+    with open(path, "rb") as f:
+        magic = f.readline().strip()
+        w, h = (int(t) for t in f.readline().split())
+        scale = float(f.readline())
+        ch = 3 if magic == b"PF" else 1
+        data = np.frombuffer(f.read(4 * w * h * ch), "<f4" if scale < 0 else ">f4").reshape(h, w, ch).astype(F)
+    if ch == 1:
+        data = np.repeat(data, 3, axis=2)
+    return np.ascontiguousarray(np.dstack([data, np.ones((h, w, 1), F)]))
+
+
+def checkerboard(usize, vsize, color0, color1):
+    """Loader.cpp:127-139 (dormant): 2*usize x 2*vsize cells of 100 x 100 texels."""
+    def byte(c):
+        return np.floor(np.clip(np.asarray(c, np.float64), 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+
+    y, x = np.mgrid[0 : vsize * 200, 0 : usize * 200]
+    off = ((x // 100 + y // 100) & 1).astype(bool)
+    img = np.zeros((vsize * 200, usize * 200, 4), np.uint8)
+    img[..., :3] = np.where(off[..., None], byte(color1), byte(color0))
+    img[..., 3] = 255
+    return img
+
+
 class _Builder:
-    def __init__(self, asset_dir):
+    def __init__(self, asset_dir, parent="", dormant=False):
         self.asset_dir = asset_dir
+        self.parent = parent
+        self.dormant = dormant
+        self.uv = []
+        self.texture_cache = {}
         self.sc = abi.SceneArrays()
         self.meshes = {}  # path -> (first_vertex, vertex_count)
         self.pos, self.nrm = [], []
@@ -227,14 +293,15 @@ class _Builder:
             return self.meshes[path]
         base = os.path.basename(path)
         if not os.path.exists(path) and base == "rect.obj":
-            pos, nrm = rect_mesh()
+            pos, nrm, uv = rect_mesh(True)
         elif not os.path.exists(path) and base == "box.obj":
-            pos, nrm = box_mesh()
+            pos, nrm, uv = box_mesh(True)
         else:
-            pos, nrm = load_obj(path)
+            pos, nrm, uv = load_obj(path, True)
         rec = (self.nverts, len(pos))
         self.pos.append(pos)
         self.nrm.append(nrm)
+        self.uv.append(uv)
         self.nverts += len(pos)
         self.meshes[path] = rec
         return rec
@@ -246,13 +313,34 @@ class _Builder:
         self.bsdfs[btype].append(rec)
         return abi.bsdf_handle(btype, len(self.bsdfs[btype]) - 1)
 
+    # Loader.cpp:122-143 (dormant in the reference): texture child `slot` -> has_texture value
+    def load_texture(self, obj, slot, what):
+        for name, tex in obj.named:
+            if name != slot or tex.kind != "texture":
+                continue
+            if not self.dormant:
+                self.warnings.append("%s: textured %s unsupported (Loader.cpp:122-143), colour default used" % (what, slot))
+                return 0
+            if tex.plugin == "bitmap":
+                f = os.path.join(self.parent, tex.string("filename"))
+                if f not in self.texture_cache:
+                    self.texture_cache[f] = self.sc.add_texture(read_bitmap(f))
+                return self.texture_cache[f]
+            if tex.plugin == "checkerboard":
+                return self.sc.add_texture(checkerboard(int(tex.number("uscale", 1.0)), int(tex.number("vscale", 1.0)),
+                                                        tex.color("color0"), tex.color("color1")))
+            self.warnings.append("%s: texture type '%s' unsupported, colour default used" % (what, tex.plugin))
+            return 0
+        return 0
+
     # Loader.cpp:145-234
     def load_material(self, mat, obj):
         t = obj.plugin
         if t == "twosided":
             mat["twofaced"] = 1
         if t == "diffuse":
-            mat["bsdf"] = self.add_bsdf(abi.BSDF_DIFFUSE, {"reflectance": obj.color("reflectance")})
+            mat["bsdf"] = self.add_bsdf(abi.BSDF_DIFFUSE, {"reflectance": obj.color("reflectance"),
+                                                           "has_texture": self.load_texture(obj, "reflectance", "diffuse")})
         elif t == "roughplastic":
             diffuse = obj.color("diffuse_reflectance")
             alpha = obj.number("alpha")
@@ -261,7 +349,8 @@ class _Builder:
             r0 = F(r0 * r0)
             mat["bsdf"] = self.add_bsdf(
                 abi.BSDF_ROUGH_PLASTIC,
-                {"diffuse": diffuse, "ior_in": ior, "ior_out": F(1.0), "r0": r0, "alpha": F(F(math.sqrt(2.0)) * alpha)},
+                {"diffuse": diffuse, "ior_in": ior, "ior_out": F(1.0), "r0": r0, "alpha": F(F(math.sqrt(2.0)) * alpha),
+                 "has_texture": self.load_texture(obj, "diffuse_reflectance", "roughplastic")},
             )
         elif t == "dielectric":
             mat["bsdf"] = self.add_bsdf(
@@ -286,6 +375,7 @@ class _Builder:
                     "k": obj.color("k"),
                     "reflectance": obj.color("specular_reflectance"),
                     "alpha": F(F(math.sqrt(2.0)) * obj.number("alpha")),
+                    "has_texture": self.load_texture(obj, "specular_reflectance", "roughconductor"),
                 },
             )
         for child in obj.children:
@@ -293,15 +383,16 @@ class _Builder:
                 self.load_material(mat, child)
 
 
-def load_scene(path, asset_dir=None):
-    """Loader.cpp:253-349 -> abi.SceneArrays."""
+def load_scene(path, asset_dir=None, dormant_features=False, srgb_textures=True):
+    """Loader.cpp:253-349 -> abi.SceneArrays.  dormant_features: LoadOptions::dormantFeatures of the product's loader
+    (the texture and envmap branches the reference keeps commented out, Loader.cpp:122-143,338-346)."""
     parent = os.path.dirname(os.path.abspath(path))
     asset_dir = asset_dir or parent
     root = ET.parse(path).getroot()
     ids = {}
     pending = []
     top = _parse_object(root, ids, pending)
-    b = _Builder(asset_dir)
+    b = _Builder(asset_dir, parent, dormant_features)
     _resolve_refs(ids, pending, b.warnings)
     sc = b.sc
     for obj in top.children:
@@ -359,6 +450,18 @@ def load_scene(path, asset_dir=None):
             fov = obj.number("fov")
             sc.fov = F(np.float64(fov) * math.pi / np.float64(F(180.0)))
             sc.to_world = rowmajor.reshape(4, 4).T.copy().reshape(16)
+        elif obj.kind == "emitter":
+            if not dormant_features or obj.plugin != "envmap":
+                b.warnings.append("top-level emitter (envmap) ignored, as in the reference (Loader.cpp:338-346)")
+            else:  # Loader.cpp:339-345 (dormant)
+                tr = obj.props.get("to_world")
+                rowmajor = tr[1] if tr and tr[0] == "transform" else np.eye(4, dtype=F).reshape(16)
+                sc.env_texels = read_pfm(os.path.join(parent, obj.string("filename")))
+                to_world = rowmajor.reshape(4, 4).astype(np.float64)  # row-major = the mathematical matrix
+                sc.env_to_local = np.linalg.inv(to_world).T.reshape(16).astype(F)  # glm memory order
+    if len(sc.textures):
+        sc.uvs = np.concatenate(b.uv) if b.uv else np.zeros((0, 2), F)
+        sc.texel_decode = srgb_decode_table() if srgb_textures else (np.arange(256, dtype=F) / F(255.0)).astype(F)
     sc.instances = np.concatenate(b.instances) if b.instances else np.zeros(0, abi.INSTANCE_DT)
     sc.positions = np.concatenate(b.pos) if b.pos else np.zeros((0, 3), F)
     sc.normals = np.concatenate(b.nrm) if b.nrm else np.zeros((0, 3), F)
