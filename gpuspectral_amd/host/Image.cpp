@@ -712,7 +712,7 @@ ImageF loadHdrBitmap(const std::string& path) {
 
 Image8 makeCheckerboard(uint32_t uSize, uint32_t vSize, const float color0[3], const float color1[3]) {
   if (uSize == 0 || vSize == 0 || uSize > 64 || vSize > 64) fail("checkerboard: uscale / vscale must be in [1, 64]");
-  auto byte = [](float c) { return (uint32_t)std::lround(std::min(std::max(c, 0.0f), 1.0f) * 255.0f); };
+  auto byte = [](float c) { return (uint32_t)std::floor(std::min(std::max(c, 0.0f), 1.0f) * 255.0f + 0.5f); };  // float32 throughout
   const uint32_t on = rgba(byte(color0[0]), byte(color0[1]), byte(color0[2]));
   const uint32_t off = rgba(byte(color1[0]), byte(color1[1]), byte(color1[2]));
   Image8 img;

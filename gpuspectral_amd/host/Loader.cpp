@@ -454,6 +454,8 @@ void loadMaterial(Scene& scene, Material* material, const Object& obj, LoadConte
     b.ior_in = ior;
     b.ior_out = 1.0f;
     b.r0 = R0;
+    for (auto& nc : obj.named)  // SmoothPlasticBSDF has no hasTexture field (Scene.h:48-53): never textured
+      if (nc.first == "diffuse_reflectance") scene.warnings.push_back("plastic: textured diffuse_reflectance unsupported (no hasTexture field), colour default used");
     material->bsdf = scene.addSmoothPlasticBSDF(b);
   } else if (type == "roughconductor") {
     vec3 eta = obj.color("eta"), k = obj.color("k"), refl = obj.color("specular_reflectance");

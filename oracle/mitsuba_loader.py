@@ -262,7 +262,7 @@ def read_pfm(path):
 def checkerboard(usize, vsize, color0, color1):
     """Loader.cpp:127-139 (dormant): 2*usize x 2*vsize cells of 100 x 100 texels."""
     def byte(c):
-        return np.floor(np.clip(np.asarray(c, np.float64), 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+        return np.floor(np.clip(np.asarray(c, F), F(0.0), F(1.0)) * F(255.0) + F(0.5)).astype(np.uint8)  # float32 throughout
 
     y, x = np.mgrid[0 : vsize * 200, 0 : usize * 200]
     off = ((x // 100 + y // 100) & 1).astype(bool)
@@ -364,6 +364,8 @@ class _Builder:
             ior = obj.number("int_ior") if obj.has("int_ior") else F(1.3)
             r0 = (ior - F(1.0)) / (ior + F(1.0))
             r0 = F(r0 * r0)
+            if any(n == "diffuse_reflectance" for n, _ in obj.named):
+                self.warnings.append("plastic: textured diffuse_reflectance unsupported (no hasTexture field), colour default used")
             mat["bsdf"] = self.add_bsdf(
                 abi.BSDF_SMOOTH_PLASTIC, {"diffuse": diffuse, "ior_in": ior, "ior_out": F(1.0), "r0": r0}
             )

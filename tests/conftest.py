@@ -69,6 +69,8 @@ def staircase2_xml(tmp_path_factory):
     d = tmp_path_factory.mktemp("ref_scenes")
     with tarfile.open(os.path.join(GOLDEN, "ref_scenes", "staircase2.tar.xz")) as t:
         t.extractall(str(d))
+    with tarfile.open(os.path.join(GOLDEN, "ref_scenes", "staircase2_textures.tar")) as t:  # textures/*.jpg (dormant features)
+        t.extractall(str(d))
     return os.path.join(str(d), "staircase2", "scene.xml")
 
 

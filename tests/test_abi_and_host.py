@@ -225,6 +225,50 @@ def test_cpp_loader_matches_numpy_restatement_on_material_scene(tmp_path, oracle
     assert np.array_equal(i1, i2)
 
 
+def test_cpp_loader_dormant_features_match_numpy_restatement(tmp_path, oracle_mod):
+    """SURVEY 8(f).3: LoadOptions::dormantFeatures.  Off (the default, = the reference): textured slots fall back to the
+    colour default with a warning, the envmap emitter is ignored, nothing of the extension is set.  On: the C++ loader
+    and the numpy restatement agree array by array (PNG texels exactly, JPEG texels to the decoders' few levels, the
+    world-to-envmap matrix to rounding), and the oracle renders the same image from either."""
+    pytest.importorskip("PIL.Image")
+    import textured
+    from gpuspectral_amd import host
+    from oracle import mitsuba_loader as ml
+
+    xml = textured.write_dormant_scene(str(tmp_path))
+    off = host.Scene(xml)
+    a0 = off.arrays()
+    same_scene(a0, ml.load_scene(xml))
+    assert len(a0.textures) == 0 and a0.uvs is None and a0.env_texels is None
+    assert sum("textured" in w for w in off.warnings) == 5 and any("envmap" in w for w in off.warnings)
+    assert a0.bsdfs[0]["has_texture"].tolist() == [0, 0, 0] and np.allclose(a0.bsdfs[0]["reflectance"][1], 0.5)
+
+    on = host.Scene(xml, dormant_features=True)
+    a, b = on.arrays(), ml.load_scene(xml, dormant_features=True)
+    same_scene(a, b)  # instances, geometry, BSDF tables (has_texture values included), lights, camera
+    assert a.bsdfs[0]["has_texture"].tolist() == [1, 2, 0]       # checkerboard, paint.png, the emitter's black diffuse
+    assert a.bsdfs[7]["has_texture"].tolist() == [3] and a.bsdfs[4]["has_texture"].tolist() == [2]  # wood.jpg; paint.png shared
+    assert [w for w in on.warnings if "textured" in w] == ["plastic: textured diffuse_reflectance unsupported (no hasTexture field), colour default used"]
+    assert a.textures.tobytes() == b.textures.tobytes() and a.textures["width"].tolist() == [400, 80, 80]
+    assert a.uvs.tobytes() == b.uvs.tobytes() and len(a.uvs) == len(a.positions)
+    ta, tb = a.texels.view(np.uint8).reshape(-1, 4), b.texels.view(np.uint8).reshape(-1, 4)
+    n_exact = 400 * 600 + 80 * 48  # checkerboard + PNG
+    assert np.array_equal(ta[:n_exact], tb[:n_exact])
+    assert np.abs(ta[n_exact:].astype(int) - tb[n_exact:].astype(int)).max() <= 4  # JPEG: own decoder vs libjpeg
+    assert np.array_equal(a.texel_decode, b.texel_decode) and a.texel_decode[0] == 0 and a.texel_decode[255] == 1
+    assert np.array_equal(a.env_texels, b.env_texels) and a.env_texels.shape == (16, 32, 4)
+    assert np.allclose(a.env_to_local, b.env_to_local, atol=1e-6)
+    rot = np.array(a.env_to_local).reshape(4, 4).T  # world -> envmap = inverse of the file's (row-major) toWorld
+    assert np.allclose(rot @ np.array([[0.8, 0, 0.6, 0], [0, 1, 0, 0], [-0.6, 0, 0.8, 0], [0, 0, 0, 1]]), np.eye(4), atol=1e-6)
+    # the same data through the oracle: identical images once the two loaders' arrays are identical
+    b.texels, b.env_to_local = a.texels.copy(), a.env_to_local.copy()
+    i1, _ = oracle_mod.Oracle(a).render(40, 30, spp=2)
+    i2, _ = oracle_mod.Oracle(b).render(40, 30, spp=2)
+    assert np.array_equal(i1, i2)
+    i0, _ = oracle_mod.Oracle(a0).render(40, 30, spp=2)
+    assert not np.array_equal(i0, i1)
+
+
 def test_cpp_loader_errors_are_reported(tmp_path):
     from gpuspectral_amd import host
     from gpuspectral_amd.pt import GspError

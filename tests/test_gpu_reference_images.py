@@ -102,6 +102,46 @@ def test_staircase2_against_tungsten(staircase2_xml):
     assert np.abs(ct / ct.sum() - co / co.sum()).max() < 0.03
 
 
+def test_staircase2_with_dormant_features_against_tungsten(staircase2_xml):
+    """SURVEY 8(f).3 checked against a fixture the reference holds: the same scene loaded with
+    LoadOptions::dormantFeatures (wood5.jpg / Tiles.jpg / Wallpaper.jpg on the treads, the floor and the back wall, read by
+    the product's own JPEG decoder, sRGB-decoded) must agree with Tungsten's render where the reference's way of loading
+    it cannot: the textured floor and everything lit through it.  Measured at 1024 spp (profiles/r02_texture_probe.txt),
+    ratio ours / Tungsten per cell-channel, reference behaviour -> dormant features:
+      whole frame   median 0.64 -> 1.06, mean |log2 ratio| 1.16 -> 0.46
+      lower half    median 0.37 -> 1.01, mean |log2 ratio| 1.72 -> 0.39     (rows 4-7: floor + stairs)
+      bottom rows   0.22 .. 0.60 -> 0.92 .. 1.24                            (rows 6-7 without column 1: the tiled floor itself)
+    and with the bytes taken as linear values (srgb_textures = False) the floor comes out 1.4-2.2 x too bright: the
+    sRGB table is what the files mean.  What stays outside: one column of cells (1, rows 2-6) that looks at geometry
+    the loader skips (sphere shapes, S/engine/Loader.cpp:276-283), and the integrator's own excess on directly lit
+    walls (1.1-1.4, as in the untextured test above)."""
+    from gpuspectral_amd import host
+
+    fix = np.load(os.path.join(REF, "tungsten_staircase2.npz"))
+
+    def cells(**kw):
+        scene = host.Scene(staircase2_xml, **kw)
+        r, _ = _cells(_render(scene.arrays(), 1024, 1024), fix)
+        return r, scene
+
+    plain, _ = cells()
+    tex, scene = cells(dormant_features=True)
+    assert len(scene.arrays().textures) == 3 and not [w for w in scene.warnings if "textured" in w]
+
+    def spread(r):
+        return float(np.nanmean(np.abs(np.log2(r[np.isfinite(r)]))))
+
+    assert np.isfinite(tex).sum() >= 180
+    assert 0.95 < np.nanmedian(tex) < 1.15 and np.nanmedian(plain) < 0.75, (np.nanmedian(tex), np.nanmedian(plain))
+    assert spread(tex) < 0.6 and spread(plain) > 1.0 and spread(tex[4:8]) < 0.5 and spread(plain[4:8]) > 1.4
+    floor = tex[6:8][:, [0, 2, 3, 4, 5, 6, 7]]  # (column 1: see above)
+    assert np.isfinite(floor).all() and 0.85 < floor.min() and floor.max() < 1.3, (floor.min(), floor.max())
+    assert np.nanmax(plain[6:8]) < 0.7
+    # hue of the floor tiles: the textured render's chromaticity is Tungsten's, cell by cell
+    chroma = floor / floor.mean(axis=2, keepdims=True)
+    assert np.abs(chroma - 1.0).max() < 0.12, np.abs(chroma - 1.0).max()
+
+
 def test_coffee_against_tungsten():
     """'Coffee Maker' (168 199 triangles; smooth/rough plastic, dielectric glass, rough conductor).  The camera is pitched
     and the reference flips the ray's *world-space* y (raygen.rgen:25: d = toWorld * d; d.y *= -1), which displaces

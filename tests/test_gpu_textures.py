@@ -89,3 +89,59 @@ def test_bad_extension_inputs_are_rejected(materials_scene):
         with pytest.raises(g.GspError, match="texture 3"):
             ctx.upload_scene(sc)
         ctx.upload_scene(materials_scene)  # the context is still usable
+
+
+def test_cpp_host_renders_a_scene_file_with_dormant_features(tmp_path, oracle_mod):
+    """End to end through the C++ host: scene.xml + OBJ + PNG / JPEG / PFM files -> loadScene(dormantFeatures) ->
+    flattenScene -> PathTracer -> gsp_render, bit-equal to the oracle on the arrays the loader produced; the default
+    load of the same file renders the reference's image (no textures, no sky)."""
+    pytest.importorskip("PIL.Image")
+    from gpuspectral_amd import host
+
+    xml = textured.write_dormant_scene(str(tmp_path))
+    W, H, spp = 96, 72, 3
+    for dormant in (True, False):
+        scene = host.Scene(xml, dormant_features=dormant)
+        pt = host.PathTracer(W, H)
+        pt.render(scene, spp)
+        img = pt.download().reshape(-1, 4)
+        pt.close()
+        sc = scene.arrays()
+        assert (len(sc.textures) == 3 and sc.env_texels is not None) if dormant else (len(sc.textures) == 0 and sc.env_texels is None)
+        ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=spp)
+        assert np.array_equal(img, ref), "dormant=%s: RMSE %.3e" % (dormant, rmse(img, ref))
+        black = float((img[:, :3].max(axis=1) == 0.0).mean())  # pixels whose every path escaped unlit
+        assert black < 0.05 if dormant else black > 0.1, black  # (the sky's sun texel exceeds the firefly cutoff: dropped samples)
+
+
+def test_cli_dormant_features_flag(tmp_path, oracle_mod):
+    import os
+    import subprocess
+
+    pytest.importorskip("PIL.Image")
+    from gpuspectral_amd import host
+
+    xml = textured.write_dormant_scene(str(tmp_path))
+    exe = os.path.join(os.path.dirname(host.lib_path()), "gsp_render")
+    out = str(tmp_path / "o.pfm")
+    r = subprocess.run([exe, "--dormant-features", xml, out, "64", "48", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = host.load_hdr_bitmap(out)[::-1, :, :3]  # PFM rows are bottom-up
+    ref, _ = oracle_mod.Oracle(host.Scene(xml, dormant_features=True).arrays()).render(64, 48, spp=2)
+    assert np.array_equal(got, ref.reshape(48, 64, 4)[..., :3])
+
+
+def test_multi_gpu_shares_with_textures(oracle_mod):
+    """The tiled multi-share path (gsp_multi_*) replicates the extension's arrays like the rest of the scene."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import pt
+
+    sc = textured.decorate(textured.open_scene(12), seed=9)
+    W, H, spp = 96, 64, 2
+    with pt.MultiContext([0, 0, 0]) as m:
+        m.upload_scene(sc)
+        m.frame_begin(W, H)
+        m.render(spp=spp)
+        img = m.download().reshape(-1, 4)
+    ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=spp)
+    assert np.array_equal(img, ref)

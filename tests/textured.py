@@ -62,3 +62,85 @@ def open_scene(res=24):
                  emission=(30, 28, 25))
     b.camera_lookat((0.0, 1.2, 3.6), (0.0, 0.35, 0.0), fov_deg=38.0)
     return b.build()
+
+
+# ---- a Mitsuba scene file that uses the loader's dormant features ----------------------------------------------------
+DORMANT_XML = """<?xml version="1.0" encoding="utf-8"?>
+<!-- build-authored test scene: bitmap / checkerboard textures on the three BSDFs that carry hasTexture, and an envmap
+     emitter (the branches the reference keeps commented out, Loader.cpp:122-143,338-346) -->
+<scene version="0.5.0">
+  <sensor type="perspective">
+    <float name="fov" value="38"/>
+    <transform name="toWorld"><matrix value="-1 0 0 0 0 1 0 1.1 0 0 -1 4.2 0 0 0 1"/></transform>
+  </sensor>
+  <bsdf type="twosided" id="Ground"><bsdf type="diffuse">
+    <texture name="reflectance" type="checkerboard">
+      <float name="uscale" value="2"/><float name="vscale" value="3"/>
+      <rgb name="color0" value="0.8, 0.75, 0.7"/><rgb name="color1" value="0.1, 0.15, 0.3"/>
+    </texture></bsdf></bsdf>
+  <bsdf type="twosided" id="Painted"><bsdf type="diffuse">
+    <rgb name="reflectance" value="0.5, 0.5, 0.5"/>
+    <texture name="reflectance" type="bitmap"><string name="filename" value="tex/paint.png"/></texture></bsdf></bsdf>
+  <bsdf type="twosided" id="Wood"><bsdf type="roughplastic">
+    <float name="alpha" value="0.1"/><float name="intIOR" value="1.5"/>
+    <texture name="diffuseReflectance" type="bitmap"><string name="filename" value="tex/wood.jpg"/></texture></bsdf></bsdf>
+  <bsdf type="twosided" id="Foil"><bsdf type="roughconductor">
+    <float name="alpha" value="0.12"/><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.2"/>
+    <texture name="specularReflectance" type="bitmap"><string name="filename" value="tex/paint.png"/></texture></bsdf></bsdf>
+  <bsdf type="twosided" id="Plain"><bsdf type="plastic">
+    <float name="intIOR" value="1.4"/>
+    <texture name="diffuseReflectance" type="bitmap"><string name="filename" value="tex/wood.jpg"/></texture></bsdf></bsdf>
+  <shape type="rectangle"><transform name="toWorld"><matrix value="4 0 0 0 0 0 1 0 0 -4 0 0 0 0 0 1"/></transform><ref id="Ground"/></shape>
+  <shape type="obj"><string name="filename" value="sphere.obj"/>
+    <transform name="toWorld"><matrix value="0.45 0 0 -1.1 0 0.45 0 0.45 0 0 0.45 0 0 0 0 1"/></transform><ref id="Painted"/></shape>
+  <shape type="obj"><string name="filename" value="sphere.obj"/>
+    <transform name="toWorld"><matrix value="0.45 0 0 0 0 0.45 0 0.45 0 0 0.45 0.3 0 0 0 1"/></transform><ref id="Wood"/></shape>
+  <shape type="obj"><string name="filename" value="sphere.obj"/>
+    <transform name="toWorld"><matrix value="0.45 0 0 1.1 0 0.45 0 0.45 0 0 0.45 0 0 0 0 1"/></transform><ref id="Foil"/></shape>
+  <shape type="cube"><transform name="toWorld"><matrix value="0.25 0 0 0.5 0 0.25 0 0.25 0 0 0.25 1.3 0 0 0 1"/></transform><ref id="Plain"/></shape>
+  <shape type="rectangle">
+    <transform name="toWorld"><matrix value="0.3 0 0 0 0 0 -1 2.2 0 0.3 0 0 0 0 0 1"/></transform>
+    <bsdf type="diffuse"><rgb name="reflectance" value="0,0,0"/></bsdf>
+    <emitter type="area"><rgb name="radiance" value="25, 24, 22"/></emitter>
+  </shape>
+  <emitter type="envmap"><string name="filename" value="tex/sky.pfm"/>
+    <transform name="toWorld"><matrix value="0.8 0 0.6 0 0 1 0 0 -0.6 0 0.8 0 0 0 0 1"/></transform></emitter>
+</scene>
+"""
+
+
+def write_dormant_scene(dirpath):
+    """DORMANT_XML + its assets (sphere with uv, a PNG and a JPEG texture, a PFM sky) under `dirpath`; returns the xml path."""
+    import os
+
+    from PIL import Image
+
+    os.makedirs(os.path.join(dirpath, "tex"), exist_ok=True)
+    nu, nv = 24, 12  # lat-long sphere with vt
+    with open(os.path.join(dirpath, "sphere.obj"), "w") as f:
+        for j in range(nv + 1):
+            for i in range(nu + 1):
+                th, ph = math.pi * j / nv, 2 * math.pi * i / nu
+                p = (math.sin(th) * math.cos(ph), math.cos(th), math.sin(th) * math.sin(ph))
+                f.write("v %.9g %.9g %.9g\nvn %.9g %.9g %.9g\nvt %.9g %.9g\n" % (p + p + (2.0 * i / nu, 1.0 - j / nv)))
+        for j in range(nv):
+            for i in range(nu):
+                a, b = j * (nu + 1) + i + 1, (j + 1) * (nu + 1) + i + 1
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a, a, a + 1, a + 1, a + 1, b, b, b))
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a + 1, a + 1, a + 1, b + 1, b + 1, b + 1, b, b, b))
+    rng = np.random.RandomState(4)
+    y, x = np.mgrid[0:48, 0:80]
+    paint = np.stack([128 + 100 * np.sin(x / 6.0), 128 + 100 * np.cos(y / 4.0), (x * 5 + y * 3) % 256], -1)
+    Image.fromarray(np.clip(paint + rng.normal(0, 5, paint.shape), 0, 255).astype(np.uint8)).save(os.path.join(dirpath, "tex", "paint.png"))
+    wood = np.stack([150 + 60 * np.sin(x / 3.0 + y / 11.0), 100 + 40 * np.sin(x / 3.0 + y / 11.0), 60 + 0 * x], -1)
+    Image.fromarray(np.clip(wood, 0, 255).astype(np.uint8)).save(os.path.join(dirpath, "tex", "wood.jpg"), quality=90, subsampling=2)
+    sky = np.zeros((16, 32, 3), np.float32)  # rows bottom-up in the file: row 0 = nadir
+    sky[8:] = np.linspace(0.3, 1.2, 8)[:, None, None] * np.array([0.5, 0.7, 1.0], np.float32)
+    sky[:8] = 0.1
+    sky[12, 5] = 30.0
+    with open(os.path.join(dirpath, "tex", "sky.pfm"), "wb") as f:
+        f.write(b"PF\n32 16\n-1.0\n" + sky.astype("<f4").tobytes())
+    xml = os.path.join(dirpath, "scene.xml")
+    with open(xml, "w") as f:
+        f.write(DORMANT_XML)
+    return xml
