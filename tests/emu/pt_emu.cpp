@@ -49,13 +49,18 @@ struct Emu {
   std::vector<gsp_triangle_light> lights;
   std::vector<q4> nodes, isect, shade;
   std::vector<uint32_t> slot_to_global;
+  // dormant-feature extension (include/gpuspectral_pt.h)
+  std::vector<float> uvs, tri_uv, decode, env_texels;
+  std::vector<gsp_texture> textures;
+  std::vector<uint32_t> texels;
+  bool textured = false;
   std::vector<float> lo, hi;  // per slot padded boxes
   int32_t root = 0;
   SceneView view;
 
   void bake() {
     std::vector<q4> gi, gs;
-    std::vector<float> glo, ghi;
+    std::vector<float> glo, ghi, guv;
     uint32_t g = 0;
     for (uint32_t a = 0; a < sc.num_instances; ++a) {
       const gsp_instance& I = instances[a];
@@ -78,6 +83,10 @@ struct Emu {
         gs.push_back(mkq(n0.x, n0.y, n0.z, I.emission[0]));
         gs.push_back(mkq(n1.x, n1.y, n1.z, I.emission[1]));
         gs.push_back(mkq(n2.x, n2.y, n2.z, I.emission[2]));
+        if (!uvs.empty()) {
+          const float* U = &uvs[2ull * (I.first_vertex + k)];
+          guv.insert(guv.end(), {U[0], U[1], U[2], U[3], U[4], U[5], 0.0f, 0.0f});
+        }
         const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
         float l3[3], h3[3];
         for (int c = 0; c < 3; ++c) {
@@ -191,6 +200,11 @@ struct Emu {
         for (int k = 0; k < 3; ++k) isect[3ull * s + k] = gi[3ull * gg + k];
         for (int k = 0; k < 4; ++k) shade[4ull * s + k] = gs[4ull * gg + k];
       }
+      if (!guv.empty()) {
+        tri_uv.assign(8ull * (n + 1), 0.0f);
+        for (uint32_t s = 0; s < n; ++s)
+          for (int k = 0; k < 8; ++k) tri_uv[8ull * s + k] = guv[8ull * slots[s] + k];
+      }
       if (nodes.empty()) nodes.assign(4, mkq(0, 0, 0, 0));
     }
     view.nodes = nodes.data();
@@ -207,6 +221,17 @@ struct Emu {
     view.lights = lights.data();
     view.num_lights = sc.num_lights;
     view.root = root;
+    if (textured) {  // what gsp_context::view() fills
+      view.tex.tri_uv = textures.empty() ? nullptr : tri_uv.data();
+      view.tex.textures = textures.data();
+      view.tex.texels = texels.data();
+      view.tex.decode = decode.data();
+      view.tex.num_textures = (uint32_t)textures.size();
+      view.tex.env_texels = env_texels.empty() ? nullptr : env_texels.data();
+      view.tex.env_width = sc.envmap.width;
+      view.tex.env_height = sc.envmap.height;
+      for (int k = 0; k < 16; ++k) view.tex.env_to_local[k] = sc.envmap.to_local[k];
+    }
   }
 };
 
@@ -242,6 +267,18 @@ void* emu_create(const gsp_scene_desc* sc) {
     transpose4(e->instances[i].transform, tr);
     inverse4(tr, &e->inv_t[16ull * i]);
   }
+  if (sc->num_textures && sc->textures && sc->texels && sc->uvs) {  // as gsp_upload_scene
+    copyv(e->uvs, sc->uvs, 2 * (size_t)sc->num_vertices);
+    copyv(e->textures, sc->textures, sc->num_textures);
+    copyv(e->texels, sc->texels, (size_t)sc->num_texels);
+    e->decode.resize(256);
+    for (int b = 0; b < 256; ++b) e->decode[b] = sc->texel_decode ? sc->texel_decode[b] : (float)b / 255.0f;
+    e->textured = true;
+  }
+  if (sc->envmap.texels) {
+    copyv(e->env_texels, sc->envmap.texels, 4 * (size_t)sc->envmap.width * sc->envmap.height);
+    e->textured = true;
+  }
   e->bake();
   return e;
 }
@@ -275,9 +312,13 @@ int emu_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixel_i
         HitRec hit;
         uint32_t aux;
         trace_ray4<false>(S.nodes, S.tri_isect, S.root, p.o, p.d, 0.0f, 1e10f, hit, aux);
-        if (hit.slot < 0 || e->sc.num_vertices == 0) break;  // miss
+        if (hit.slot < 0 || e->sc.num_vertices == 0) {  // miss (k_shade / k_finish: the <TEX> branch)
+          if (e->textured && S.tex.env_texels != nullptr) add_emitted(rc.clamp, miss_emitted(S, p), result);
+          break;
+        }
         ShadeOut out;
-        shade_vertex(S, rc, p, hit, out);
+        if (e->textured) shade_vertex<true>(S, rc, p, hit, out);
+        else shade_vertex<false>(S, rc, p, hit, out);
         if (out.has_shadow) {
           HitRec sh;
           uint32_t aux2;

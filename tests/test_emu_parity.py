@@ -20,6 +20,21 @@ def test_emu_render_full_bsdf_set_bit_exact(emu, oracle_mod, materials_scene):
     assert np.isfinite(img).all()
 
 
+@pytest.mark.parametrize("what", ["textures", "envmap", "both-srgb"])
+def test_emu_dormant_features_bit_exact(emu, oracle_mod, what):
+    """shade_vertex<true>, sample_texture, sample_envmap, det_atan2f of the product headers against the oracle's
+    oracle_texture.h on the CPU (the GPU run of the same comparison is tests/test_gpu_textures.py)."""
+    import textured
+
+    sc = textured.decorate(textured.open_scene(10), seed=7, textures=what != "envmap", envmap=what != "textures",
+                           decode=textured.srgb_table() if what == "both-srgb" else None)
+    img = emu.scene(sc).render(64, 48, spp=3)
+    ref, _ = oracle_mod.Oracle(sc).render(64, 48, spp=3)
+    assert np.array_equal(img, ref)
+    plain, _ = oracle_mod.Oracle(textured.open_scene(10)).render(64, 48, spp=3)
+    assert not np.array_equal(ref, plain)
+
+
 def test_emu_deep_paths_and_russian_roulette(emu, oracle_mod):
     """Dielectric-heavy scene: paths reach the RR regime (depth > 10) and the depth cap."""
     from gpuspectral_amd import abi, scenes
