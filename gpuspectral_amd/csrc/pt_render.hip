@@ -254,6 +254,19 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   }
   // (the barrier behind the s_dead initialisation below also publishes the staged tables)
 #endif
+  // textured scenes: the byte -> value table and the texture headers sit on the dependent chain packet -> BSDF record ->
+  // header -> texels -> decode; from LDS the last and the third hop cost no memory round trip
+  constexpr uint32_t kLdsTextures = 64;
+  __shared__ float s_decode[TEX ? 256 : 1];
+  __shared__ gsp_texture s_textures[TEX ? kLdsTextures : 1];
+  if (TEX && S.tex.num_textures != 0) {
+    for (uint32_t k = threadIdx.x; k < 256u; k += kShadeBlock) s_decode[k] = S.tex.decode[k];
+    S.tex.decode = s_decode;
+    if (S.tex.num_textures <= kLdsTextures) {
+      for (uint32_t k = threadIdx.x; k < S.tex.num_textures; k += kShadeBlock) s_textures[k] = S.tex.textures[k];
+      S.tex.textures = s_textures;
+    }
+  }
   __shared__ uint32_t s_dead[kMaxSlots];
   __shared__ uint32_t s_bin[12];               // counting sort of the tile by BSDF type: counts, then starts
   __shared__ uint16_t s_order[kShadeBlock];    // sorted position -> thread offset inside the tile

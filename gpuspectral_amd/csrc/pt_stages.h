@@ -137,9 +137,10 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   if (TEX) {
     const uint32_t tid = bsdf_texture(S.bsdf, bsdf);
     if (tid != 0u && tid <= S.tex.num_textures && S.tex.tri_uv != nullptr) {
-      const float* uv = S.tex.tri_uv + 8ll * hit.slot;
-      const float tu = (b0 * uv[0] + hit.u * uv[2]) + hit.v * uv[4];
-      const float tv = (b0 * uv[1] + hit.u * uv[3]) + hit.v * uv[5];
+      const q4* uv = (const q4*)S.tex.tri_uv + 2ll * hit.slot;  // {u0 v0 u1 v1}, {u2 v2 - -}
+      const q4 ua = uv[0], ub2 = uv[1];
+      const float tu = (b0 * ua.x + hit.u * ua.z) + hit.v * ub2.x;
+      const float tv = (b0 * ua.y + hit.u * ua.w) + hit.v * ub2.y;
       kd = sample_texture(S.tex, tid - 1u, tu, tv);
       kd_on = true;
     }
