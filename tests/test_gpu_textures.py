@@ -145,3 +145,21 @@ def test_multi_gpu_shares_with_textures(oracle_mod):
         img = m.download().reshape(-1, 4)
     ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=spp)
     assert np.array_equal(img, ref)
+
+
+def test_random_scenes_with_the_extension_match_oracle(oracle_mod):
+    """tests/tools/fuzz_parity.py with `dormant`: random scenes (all eight BSDF types at ordinary and extreme
+    parameters) + random uv / textures / environment map / sRGB table, half of them with an open wall.  2 000 more seeds
+    were run by hand on the final build (profiles/r02_fuzz.txt): 0 differences."""
+    import os
+    import sys
+
+    import gpuspectral_amd as g
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "tools"))
+    import fuzz_parity
+
+    with g.Context(0) as ctx:
+        for seed in range(500, 530):
+            ok, ndiff, tris = fuzz_parity.check(ctx, oracle_mod, seed, dormant=True)
+            assert ok, "seed %d: %d pixels differ (%d triangles)" % (seed, ndiff, tris)

@@ -1,6 +1,8 @@
 """Randomised GPU-vs-oracle parity: small random scenes with every BSDF type at ordinary and extreme parameters
 (alpha -> 0, ior 1, zero / >1 reflectance, huge k), random transforms (mirrored, sheared scale), several lights,
-random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed]"""
+random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed] [dormant]
+`dormant`: every scene also gets the dormant-feature extension (tests/textured.py: random uv, random textures on the
+texturable records, a random environment map; every third scene with an sRGB table, one wall removed so paths escape)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,8 +47,16 @@ def random_scene(seed):
     return b.build()
 
 
-def check(ctx, oracle_mod, seed, W=40, H=28, spp=3):
+def check(ctx, oracle_mod, seed, W=40, H=28, spp=3, dormant=False):
     sc = random_scene(seed)
+    if dormant:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import textured
+
+        sc = textured.decorate(sc, seed=seed, textures=seed % 5 != 0, envmap=seed % 7 != 0,
+                               decode=textured.srgb_table() if seed % 3 == 0 else None)
+        if seed % 2 == 0:  # open the room: drop the last two triangles of the room box (instance 0) so that paths reach the sky
+            sc.instances["vertex_count"][0] -= 6
     ctx.upload_scene(sc)
     ctx.frame_begin(W, H)
     ctx.reset_stats()
@@ -64,11 +74,12 @@ if __name__ == "__main__":
     import oracle as O
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    dormant = len(sys.argv) > 3 and sys.argv[3] == "dormant"
     bad = []
     with g.Context(0) as ctx:
         for seed in range(s0, s0 + n):
-            ok, ndiff, tris = check(ctx, O, seed)
+            ok, ndiff, tris = check(ctx, O, seed, dormant=dormant)
             if not ok:
                 bad.append((seed, ndiff))
                 print("seed %d: MISMATCH (%d pixels, %d tris)" % (seed, ndiff, tris), flush=True)
-    print("%d scenes, %d mismatching: %s" % (n, len(bad), bad))
+    print("%d scenes%s, %d mismatching: %s" % (n, " with the dormant-feature extension" if dormant else "", len(bad), bad))
