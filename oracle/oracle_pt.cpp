@@ -289,6 +289,10 @@ static inline bool slab(const Node& n, vec3 o, vec3 inv, float tmin, float tmax,
 // independent of the BVH topology, so any conforming BVH gives the same hit).
 static Hit closestHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, TravStats* st) {
   Hit best{tmax, 0.0f, 0.0f, -1};
+  if (A.tris.empty()) {  // empty scene: the placeholder root has an inverted box, which a slab test with an infinite 1/d
+    if (st) st->rays += 1;  // component does not reject -- and it has no children to descend into
+    return best;
+  }
   vec3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const Shear rs = makeShear(d);
   uint32_t stack[128];
@@ -338,6 +342,10 @@ static Hit closestHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, Tr
 
 // any hit in (tmin, tmax): TerminateOnFirstHit | SkipClosestHitShader   rayhit.rchit:738-748
 static bool anyHit(const Accel& A, vec3 o, vec3 d, float tmin, float tmax, TravStats* st) {
+  if (A.tris.empty()) {
+    if (st) st->rays += 1;
+    return false;
+  }
   vec3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const Shear rs = makeShear(d);
   uint32_t stack[128];

@@ -163,3 +163,88 @@ def test_random_scenes_with_the_extension_match_oracle(oracle_mod):
         for seed in range(500, 530):
             ok, ndiff, tris = fuzz_parity.check(ctx, oracle_mod, seed, dormant=True)
             assert ok, "seed %d: %d pixels differ (%d triangles)" % (seed, ndiff, tris)
+
+
+@pytest.mark.parametrize("env_size", [(1, 1), (2, 1), (5, 3), (64, 32)])
+def test_environment_only_scene_and_axis_directions(oracle_mod, env_size):
+    """No geometry at all: every primary ray escapes, the image IS the environment lookup -- with cameras that look along
+    the lat-long singularities (straight up / down: atan2(0, 0)), along -z (the u = 0.5 seam partner) and along +z (the
+    wrap seam), a non-orthonormal world-to-envmap matrix, and degenerate map sizes."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi
+
+    rng = np.random.RandomState(11)
+    w, h = env_size
+    looks = {
+        "-z": np.eye(4), "+z": np.diag([-1.0, 1.0, -1.0, 1.0]),
+        "up": np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1.0]]),
+        "down": np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1.0]]),
+    }
+    for name, m in looks.items():
+        sc = abi.SceneArrays()
+        sc.to_world = m.T.reshape(16).astype(np.float32)
+        sc.fov = np.float32(1.2)
+        sc.env_texels = rng.uniform(0.0, 3.0, (h, w, 4)).astype(np.float32)
+        shear = np.eye(4)
+        shear[0, 1], shear[2, 2] = 0.3, 1.7  # not a rotation: directions are not re-normalised, by definition
+        sc.env_to_local = (shear if name == "+z" else np.eye(4)).T.reshape(16).astype(np.float32)
+        with g.Context(0) as ctx:
+            ctx.upload_scene(sc)
+            ctx.frame_begin(33, 33)  # odd size: the centre pixel looks exactly along the axis
+            ctx.render(spp=2)
+            img = ctx.download().reshape(-1, 4)
+            st = ctx.stats()
+        ref, ost = oracle_mod.Oracle(sc).render(33, 33, spp=2)
+        assert np.array_equal(img, ref), (name, env_size)
+        assert st["extension_rays"] == ost["extension_rays"] == 33 * 33 * 2 and st["shadow_rays"] == 0
+        assert np.isfinite(img).all() and img[:, :3].max() > 0
+
+
+def test_texture_coordinate_edge_cases(oracle_mod):
+    """One textured quad in front of the camera whose uv take values a file can carry but a sampler must survive: NaN,
+    +-inf, 1e30, negative, exactly 0 / 1 / integers (texel-centre rule at the wrap seam), with 1x1, 2x2 and 3x1 textures."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import scenes
+
+    rng = np.random.RandomState(2)
+    uv_sets = [
+        [(0, 0), (1, 0), (0, 1), (0, 1), (1, 0), (1, 1)],
+        [(-3.25, 7.5), (2, -1), (0.5, 0.5), (0.5, 0.5), (2, -1), (1e-9, 1 - 1e-7)],
+        [(np.nan, 0.2), (0.3, np.inf), (-np.inf, 0.1), (1e30, -1e30), (0.25, 0.75), (3e9, 0.5)],
+    ]
+    for size in ((1, 1), (2, 2), (3, 1)):
+        for uvs in uv_sets:
+            b = scenes.SceneBuilder()
+            rect = b.add_mesh(*scenes.rect_mesh())
+            b.add_object(rect, scenes.rowmajor([2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 1, -3, 0, 0, 0, 1]), b.diffuse((0.5, 0.5, 0.5)), emission=(0, 0, 0))
+            b.add_object(rect, scenes.rowmajor([0.5, 0, 0, 0, 0, 0, -1, 2.5, 0, 0.5, 0, -2, 0, 0, 0, 1]), b.diffuse((0, 0, 0)), emission=(20, 20, 20))
+            b.camera_lookat((0, 0, 2), (0, 0, -3), fov_deg=50.0)
+            sc = b.build()
+            sc.uvs = np.zeros((len(sc.positions), 2), np.float32)
+            sc.uvs[:6] = np.array(uvs, np.float32)
+            sc.add_texture(rng.randint(0, 256, (size[1], size[0], 4)).astype(np.uint8))
+            sc.bsdfs[0]["has_texture"][0] = 1
+            with g.Context(0) as ctx:
+                ctx.upload_scene(sc)
+                ctx.frame_begin(48, 48)
+                ctx.render(spp=2)
+                img = ctx.download().reshape(-1, 4)
+            ref, _ = oracle_mod.Oracle(sc).render(48, 48, spp=2)
+            assert np.array_equal(img, ref, equal_nan=True), (size, uvs[0])
+            assert np.isfinite(img).all() and img[:, :3].max() > 0.01  # the quad is lit and seen
+
+
+def test_textures_without_uvs_are_rejected(materials_scene):
+    import copy
+
+    import gpuspectral_amd as g
+
+    sc = textured.decorate(copy.deepcopy(materials_scene), seed=1, envmap=False)
+    d = sc.desc()
+    d.uvs = None
+    with g.Context(0) as ctx:
+        L = g.pt.load()
+        import ctypes as C
+
+        assert L.gsp_upload_scene(ctx._h, C.byref(d)) != 0
+        assert b"uvs" in L.gsp_last_error(ctx._h)
