@@ -86,8 +86,9 @@ const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3
 const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
-void inflateBlock(LsbBits& in, const CodeBook& lit, const CodeBook& dist, std::vector<uint8_t>& out) {
+void inflateBlock(LsbBits& in, const CodeBook& lit, const CodeBook& dist, std::vector<uint8_t>& out, size_t limit) {
   for (;;) {
+    if (out.size() > limit) fail("deflate: more data than the image holds");
     const int s = lit.decode(in);
     if (s < 256) {
       out.push_back((uint8_t)s);
@@ -109,7 +110,8 @@ void inflateBlock(LsbBits& in, const CodeBook& lit, const CodeBook& dist, std::v
 std::vector<uint8_t> inflateRaw(const uint8_t* data, size_t size, size_t expected) {
   LsbBits in{data, size};
   std::vector<uint8_t> out;
-  out.reserve(expected);
+  out.reserve(std::min(expected, size * 1032 + 1024));  // deflate expands at most 1032 : 1
+  const size_t limit = expected + 1024;  // a stream that inflates to more than the caller can use is rejected, not stored
   CodeBook fixedLit, fixedDist;
   {
     uint8_t l[288];
@@ -128,11 +130,11 @@ std::vector<uint8_t> inflateRaw(const uint8_t* data, size_t size, size_t expecte
       if (in.pos + 4 > in.n) fail("deflate: stored block header cut");
       const uint32_t len = in.p[in.pos] | (in.p[in.pos + 1] << 8), nlen = in.p[in.pos + 2] | (in.p[in.pos + 3] << 8);
       in.pos += 4;
-      if ((len ^ 0xffffu) != nlen || in.pos + len > in.n) fail("deflate: bad stored block");
+      if ((len ^ 0xffffu) != nlen || in.pos + len > in.n || out.size() + len > limit) fail("deflate: bad stored block");
       out.insert(out.end(), in.p + in.pos, in.p + in.pos + len);
       in.pos += len;
     } else if (type == 1) {
-      inflateBlock(in, fixedLit, fixedDist, out);
+      inflateBlock(in, fixedLit, fixedDist, out, limit);
     } else if (type == 2) {
       const int nlit = (int)in.take(5) + 257, ndist = (int)in.take(5) + 1, ncode = (int)in.take(4) + 4;
       static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -165,7 +167,7 @@ std::vector<uint8_t> inflateRaw(const uint8_t* data, size_t size, size_t expecte
       CodeBook lit, dist;
       lit.build(lengths, nlit);
       dist.build(lengths + nlit, ndist);
-      inflateBlock(in, lit, dist, out);
+      inflateBlock(in, lit, dist, out, limit);
     } else {
       fail("deflate: reserved block type");
     }
@@ -231,6 +233,7 @@ Image8 decodePng(const uint8_t* data, size_t size) {
   if (ctype == 3 && depth == 16) fail("png: bad bit depth");
   const size_t stride = ((size_t)w * channels * depth + 7) / 8;
   const size_t bpp = std::max<size_t>(1, (size_t)channels * depth / 8);
+  if ((stride + 1) * h > idat.size() * 1032 + 1024) fail("png: image data cut");  // (no allocation from a forged header)
   std::vector<uint8_t> raw = inflateZlib(idat.data(), idat.size(), (stride + 1) * h);
   if (raw.size() < (stride + 1) * h) fail("png: image data cut");
   // undo the scanline filters in place (PNG 9.2)
