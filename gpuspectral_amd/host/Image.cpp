@@ -468,6 +468,11 @@ Image8 decodeJpeg(const uint8_t* data, size_t size) {
       if (comps.size() == 1) comps[0].h = comps[0].v = hmax = vmax = 1;  // a single component is never interleaved (A.2.2)
       const int mcuW = 8 * hmax, mcuH = 8 * vmax;
       const int mcusX = ((int)w + mcuW - 1) / mcuW, mcusY = ((int)h + mcuH - 1) / mcuH;
+      {  // a block costs at least two bits of entropy-coded data (DC size 0 + EOB): no allocation from a forged header
+        size_t blocks = 0;
+        for (auto& c : comps) blocks += (size_t)mcusX * mcusY * c.h * c.v;
+        if (size - (pos + len) < blocks / 4) fail("jpeg: image data cut");
+      }
       for (auto& c : comps) {
         c.planeW = mcusX * c.h * 8;
         c.planeH = mcusY * c.v * 8;
@@ -648,6 +653,7 @@ ImageF decodeRgbe(const uint8_t* data, size_t size) {
     if (std::sscanf(res.c_str(), "%cY %ld %cX %ld", &sy, &h, &sx, &w) != 4 || sy != '-' || sx != '+') fail("hdr: only '-Y h +X w' orientation is supported");
   }
   if (w <= 0 || h <= 0 || w > (1 << 15) || h > (1 << 15)) fail("hdr: bad size");
+  if (size - std::min(pos, size) < (size_t)h * (4 + (size_t)w / 16)) fail("hdr: pixel data cut");  // shortest run-length coding
   ImageF img;
   img.width = (uint32_t)w;
   img.height = (uint32_t)h;
