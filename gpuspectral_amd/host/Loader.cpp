@@ -612,7 +612,7 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg, const L
       if (pt == "obj") filename = joinPath(parentPath, obj->string("filename"));
       else if (pt == "rectangle") { filename = joinPath(assetDir, "rect.obj"); builtin = 1; }
       else if (pt == "cube") { filename = joinPath(assetDir, "box.obj"); builtin = 2; }
-      else if (pt == "disk") filename = joinPath(assetDir, "disk.obj");
+      else if (pt == "disk") filename = joinPath(assetDir, "disk.obj");  // (no such asset in the reference tree: skipped below)
       else {
         outScene.warnings.push_back("unsupported shape type '" + pt + "' skipped");
         continue;

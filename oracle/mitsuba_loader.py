@@ -411,7 +411,7 @@ def load_scene(path, asset_dir=None, dormant_features=False, srgb_textures=True)
             else:
                 b.warnings.append("unsupported shape type '%s' skipped" % pt)
                 continue
-            if not (os.path.exists(filename) or os.path.basename(filename) in ("rect.obj", "box.obj")):
+            if not (os.path.exists(filename) or (pt != "obj" and os.path.basename(filename) in ("rect.obj", "box.obj"))):
                 b.warnings.append("missing mesh '%s' skipped" % filename)
                 continue
             first, count = b.mesh(filename)
