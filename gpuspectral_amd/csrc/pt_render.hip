@@ -876,7 +876,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
       }
     }
   }
-  {
+  if (want_tex) {  // (without a textures array the words are ignored, as the reference's shaders ignore them)
     auto bad = [&](int32_t h) { return h < 0 || (uint32_t)h > sc->num_textures; };
     bool oob = false;
     for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_DIFFUSE] && sc->diffuse_bsdfs; ++k) oob |= bad(sc->diffuse_bsdfs[k].has_texture);

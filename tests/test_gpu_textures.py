@@ -53,6 +53,12 @@ def test_extension_changes_the_image_and_only_where_it_should(oracle_mod):
     plain = textured.open_scene(16)
     img0, ref0, _, _ = render_both(g, oracle_mod, plain, 96, 64, 2)
     assert np.array_equal(img0, ref0)
+    flagged = textured.open_scene(16)
+    for recs in flagged.bsdfs:
+        if "has_texture" in (recs.dtype.names or ()):
+            recs["has_texture"] = 7  # set, but no textures array: ignored like the reference's shaders ignore it
+    imgf, reff, _, _ = render_both(g, oracle_mod, flagged, 96, 64, 2)
+    assert np.array_equal(imgf, img0) and np.array_equal(reff, ref0)
     deco = textured.decorate(textured.open_scene(16), seed=3)
     img1, ref1, _, _ = render_both(g, oracle_mod, deco, 96, 64, 2)
     assert np.array_equal(img1, ref1)
