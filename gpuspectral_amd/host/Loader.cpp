@@ -390,6 +390,10 @@ int loadTexture(Scene& scene, LoadContext& lc, const Object& bsdf, const std::st
       const std::string file = joinPath(lc.parentPath, tex.string("filename"));
       auto it = lc.textureCache.find(file);
       if (it != lc.textureCache.end()) return (int)it->second;
+      if (!fileExists(file)) {  // (the reference's own living-room names a WoodFloor.jpg its tree does not hold)
+        scene.warnings.push_back(std::string(what) + ": bitmap '" + file + "' not found, colour default used");
+        return 0;
+      }
       Image8 img = loadBitmap(file);  // throws like the reference's loadTexture (Loader.cpp:70-72)
       const uint32_t id = scene.addTexture(Texture{img.width, img.height, std::move(img.texels)});
       lc.textureCache.emplace(file, id);

@@ -323,6 +323,9 @@ class _Builder:
                 return 0
             if tex.plugin == "bitmap":
                 f = os.path.join(self.parent, tex.string("filename"))
+                if f not in self.texture_cache and not os.path.exists(f):
+                    self.warnings.append("%s: bitmap '%s' not found, colour default used" % (what, f))
+                    return 0
                 if f not in self.texture_cache:
                     self.texture_cache[f] = self.sc.add_texture(read_bitmap(f))
                 return self.texture_cache[f]
