@@ -267,6 +267,15 @@ def test_cpp_loader_dormant_features_match_numpy_restatement(tmp_path, oracle_mo
     assert np.array_equal(i1, i2)
     i0, _ = oracle_mod.Oracle(a0).render(40, 30, spp=2)
     assert not np.array_equal(i0, i1)
+    # a bitmap the scene names but the directory does not hold: warning + colour default (both loaders)
+    xml2 = str(tmp_path / "scene_missing.xml")
+    with open(xml2, "w") as f:
+        f.write(textured.DORMANT_XML.replace("tex/wood.jpg", "tex/absent.jpg"))
+    gone = host.Scene(xml2, dormant_features=True)
+    ag, bg = gone.arrays(), ml.load_scene(xml2, dormant_features=True)
+    same_scene(ag, bg)
+    assert ag.bsdfs[7]["has_texture"].tolist() == [0] and len(ag.textures) == 2
+    assert any("absent.jpg' not found" in w for w in gone.warnings) and any("absent.jpg' not found" in w for w in bg.warnings)
 
 
 def test_cpp_loader_errors_are_reported(tmp_path):
