@@ -254,3 +254,39 @@ def test_textures_without_uvs_are_rejected(materials_scene):
 
         assert L.gsp_upload_scene(ctx._h, C.byref(d)) != 0
         assert b"uvs" in L.gsp_last_error(ctx._h)
+
+
+def test_bench_scene_with_the_extension_at_full_size(oracle_mod):
+    """The headline workload (988 k triangles, 1920x1080) with every texturable record textured from 1024^2 / 512^2 images:
+    the full frame renders (k_shade<true> over 50 M-path pools), and 256 seeded pixels -- rendered as a pixel subset, which
+    reproduces the full frame's values (test_pixel_subset_reproduces_full_frame) -- equal the oracle bit for bit."""
+    import zlib
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi, scenes
+
+    sc = scenes.interior(1_000_000)
+    rng = np.random.RandomState(21)
+    sc.uvs = rng.uniform(-1.0, 3.0, (len(sc.positions), 2)).astype(np.float32)
+    for size in (1024, 512, 333):
+        sc.add_texture(rng.randint(30, 256, (size, size, 4)).astype(np.uint8))
+    for name in ("diffuse", "rough_conductor", "rough_plastic"):
+        recs = sc.bsdfs[abi.BSDF_NAMES.index(name)]
+        recs["has_texture"] = 1 + (np.arange(len(recs)) % 3)
+    sc.texel_decode = textured.srgb_table()
+    W, H, spp = 1920, 1080, 16
+    ids = np.sort(rng.choice(W * H, 256, replace=False)).astype(np.uint32)
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        full = ctx.download().reshape(-1, 4)
+        st = ctx.stats()
+        ctx.frame_begin(W, H, ids)
+        ctx.render(spp=spp)
+        sub = ctx.download_compact()
+    assert np.isfinite(full).all() and st["samples"] == W * H * spp
+    assert np.array_equal(sub, full[ids])
+    ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=spp, pixel_ids=ids)
+    assert np.array_equal(sub, ref), "RMSE %.3e" % rmse(sub, ref)
+    assert zlib.crc32(full.tobytes()) != 0
