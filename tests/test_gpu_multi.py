@@ -139,3 +139,56 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert j1["config"]["extension_rays"] == j2["config"]["extension_rays"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]
     a, b = np.load(f1), np.load(f2)
     assert a.shape == b.shape == (240, 416, 4) and np.array_equal(a, b)
+
+
+_TORCH_PIECES = r"""
+import sys
+import numpy as np
+import torch  # first, as in bench.py: the tracer's library then binds to the HIP runtime torch has loaded
+assert torch.cuda.is_available()
+sys.path.insert(0, %r)
+import gpuspectral_amd as g
+from gpuspectral_amd import multigpu, scenes
+
+sc = scenes.cornell_materials(12)
+W, H, spp, world = 200, 120, 3, 2
+with g.Context(0) as ctx:
+    ctx.upload_scene(sc)
+    ctx.frame_begin(W, H)
+    ctx.render(spp=spp)
+    full = ctx.download().reshape(-1, 4)
+    parts = []
+    for rank in range(world):
+        ids = multigpu.partition(W, H, rank, world)
+        ctx.frame_begin(W, H, ids)
+        ctx.render(spp=spp)
+        t = torch.zeros((len(ids), 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.copy_accum_to_device(t.data_ptr(), len(ids) * 16)
+        assert np.array_equal(t.cpu().numpy(), ctx.download_compact())
+        parts.append(t)
+
+
+class FakeDist:  # rank 0's view of dist.gather: its own padded buffer + the one rank 1 would have sent
+    def gather(self, buf, gather_list, dst=0):
+        counts = [len(multigpu.partition(W, H, r, world)) for r in range(world)]
+        for r in range(world):
+            gather_list[r].zero_()
+            gather_list[r][: counts[r]] = parts[r]
+
+
+frame = multigpu.gather_frame(parts[0], W, H, 0, world, FakeDist())
+assert frame.is_cuda and np.array_equal(frame.cpu().numpy(), full)
+print("torch pieces ok")
+"""
+
+
+def test_device_side_gather_pieces_with_torch_on_the_gpu():
+    """What the RCCL path of bench.py does on each rank besides the collective itself, in one fresh process that imports
+    torch first like bench.py: the tracer's accumulate buffer copied device-to-device into a torch CUDA tensor
+    (gsp_copy_accum_to_device), and rank 0's assembly of the padded per-rank buffers with index tensors on the GPU
+    (multigpu.gather_frame with a stand-in for torch.distributed whose gather hands over the other rank's buffer).
+    torch.cuda and the tracer's own HIP context share the device."""
+    pytest.importorskip("torch")
+    r = subprocess.run([sys.executable, "-c", _TORCH_PIECES % ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "torch pieces ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
