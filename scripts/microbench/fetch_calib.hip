@@ -28,6 +28,19 @@ __global__ void __launch_bounds__(256) k_stream(const uint4* __restrict__ p, siz
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= p[i].x;
   if (acc == 0x12345678u) out[0] = acc;
 }
+// WRITE_SIZE controls: a coalesced 16-B-per-lane streaming write of the table, and scattered 16-B writes (one random
+// quad per lane per iteration: the pattern of the sample-result ring and of k_trace's hit records)
+__global__ void __launch_bounds__(256) k_wstream(uint4* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = make_uint4((uint32_t)i, 1u, 2u, 3u);
+}
+__global__ void __launch_bounds__(256) k_wscatter16(uint4* __restrict__ p, uint32_t mask, int iters) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t idx = (tid * 2654435761u) & mask;
+  for (int i = 0; i < iters; ++i) {
+    p[idx] = make_uint4(idx, tid, (uint32_t)i, 7u);
+    idx = (idx * 2246822519u + tid * 40503u + i * 7919u + 1u) & mask;
+  }
+}
 __global__ void k_fill(uint4* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     uint32_t s = (uint32_t)i * 1664525u + 1013904223u;
@@ -48,5 +61,12 @@ int main() {
   hipLaunchKernelGGL(k_stream, dim3(4096), dim3(256), 0, 0, d, (size_t)N * 4, out);
   CHECK(hipDeviceSynchronize());
   printf("k_stream: %.1f MiB read once, 16 B per lane, coalesced\n", (double)N * 64 / 1048576.0);
+  hipLaunchKernelGGL(k_wstream, dim3(4096), dim3(256), 0, 0, d, (size_t)N * 4);
+  CHECK(hipDeviceSynchronize());
+  printf("k_wstream: %.1f MiB written once, 16 B per lane, coalesced\n", (double)N * 64 / 1048576.0);
+  hipLaunchKernelGGL(k_wscatter16, dim3(blocks), dim3(256), 0, 0, d, 4u * N - 1u, iters);
+  CHECK(hipDeviceSynchronize());
+  printf("k_wscatter16: %d lanes x %d quads x 16 B = %.1f MiB of scattered 16-B writes\n", blocks * 256, iters,
+         (double)blocks * 256 * iters * 16 / 1048576.0);
   return 0;
 }

@@ -24,6 +24,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 # FETCH_SIZE calibration on the traversal's access pattern
 hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_calib $ROOT/scripts/microbench/fetch_calib.hip > $OUT/fetch_calib_build.log 2>&1
 timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib -- /tmp/fetch_calib > $OUT/fetch_calib.txt 2>&1 || echo "calib failed"
+timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/calibw -- /tmp/fetch_calib > $OUT/fetch_calibw.txt 2>&1 || echo "calibw failed"
 python3 $ROOT/scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 # the raw per-dispatch CSVs are tens of MB (gpurun brings back at most 64 MiB): keep the summary, the JSON and the
 # kernel-stats table

@@ -86,6 +86,8 @@ def main(root):
             out["kernels"][k] = {"trace_us": dur.get(k, []), "counters": c}
     # ---- FETCH_SIZE calibration
     cal = read_pass(root, "calib")
+    for k, cs in read_pass(root, "calibw").items():  # WRITE_SIZE pass over the same microbenchmark
+        cal.setdefault(k, {}).update(cs)
     txt = os.path.join(root, "fetch_calib.txt")
     if cal and os.path.exists(txt):
         t = open(txt).read()
@@ -93,18 +95,21 @@ def main(root):
         print(t.strip())
         calib = {}
         m = re.search(r"k_gather64: (\d+) lanes x (\d+) records x 64 B", t)
+        mw = re.search(r"k_wscatter16: (\d+) lanes x (\d+) quads x 16 B", t)
         for k, cs in cal.items():
-            if "FETCH_SIZE" not in cs:
-                continue
-            counter_bytes = sum(cs["FETCH_SIZE"]) * 1024.0
-            if "k_gather64" in k and m:
-                known = float(m.group(1)) * float(m.group(2)) * 64.0
-            elif "k_stream" in k:
-                known = float(1 << 26) * 64.0
+            if "k_gather64" in k and m and "FETCH_SIZE" in cs:
+                known, counter, cname = float(m.group(1)) * float(m.group(2)) * 64.0, "FETCH_SIZE", "fetch_size_bytes"
+            elif "k_stream" in k and "FETCH_SIZE" in cs:
+                known, counter, cname = float(1 << 26) * 64.0, "FETCH_SIZE", "fetch_size_bytes"
+            elif "k_wstream" in k and "WRITE_SIZE" in cs:
+                known, counter, cname = float(1 << 26) * 64.0, "WRITE_SIZE", "write_size_bytes"
+            elif "k_wscatter16" in k and mw and "WRITE_SIZE" in cs:
+                known, counter, cname = float(mw.group(1)) * float(mw.group(2)) * 16.0, "WRITE_SIZE", "write_size_bytes"
             else:
                 continue
-            calib[k] = {"known_bytes": known, "fetch_size_bytes": counter_bytes, "known_over_counter": known / max(1.0, counter_bytes)}
-            print("   %-12s known %.1f MB, FETCH_SIZE %.1f MB -> known / counter = %.3f" % (k, known / 1e6, counter_bytes / 1e6, known / max(1.0, counter_bytes)))
+            counter_bytes = sum(cs[counter]) * 1024.0
+            calib[k] = {"known_bytes": known, cname: counter_bytes, "known_over_counter": known / max(1.0, counter_bytes)}
+            print("   %-12s known %.1f MB, %s %.1f MB -> known / counter = %.3f" % (k, known / 1e6, counter, counter_bytes / 1e6, known / max(1.0, counter_bytes)))
         out["fetch_calibration"] = calib
     # ---- which bench run this was: the JSON line bench.py printed under the kernel-trace pass
     for log in ("trace.log", "grbm.log", "sq1.log"):
