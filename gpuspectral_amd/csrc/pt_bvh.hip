@@ -19,12 +19,10 @@
 //             area, within a window of the cluster array) -- near-SAH quality; the Karras 2012 radix
 //             tree (LBVH) is kept behind GSP_BVH=lbvh for comparison
 //   fit       bottom-up boxes of the binary tree (each binary node holds both child boxes)
-//   collapse  binary tree -> 4-wide BVH (compressed 64-B nodes, pt_trace.h): every binary node at even depth becomes one
-//             node whose children are its grandchildren (leaf children stay), so a ray makes half
-//             as many dependent node fetches; node index = exclusive scan of the even-depth flags
-//             (rocPRIM), which keeps the locality of the binary numbering.  GSP_COLLAPSE=greedy
-//             selects a breadth-first greedy surface-area collapse (always 4 children where
-//             possible): measured within +-3 % of the parity collapse, so it is not the default.
+//   collapse  binary tree -> wide BVH with contiguous children (pt_trace.h), level by level: the children of a 4-wide
+//             node are the grandchildren of its binary node (GSP_COLLAPSE=greedy / the 8-wide variant: greedy
+//             surface-area choice of up to kWide children); inner children of a node = consecutive nodes, leaf
+//             children = consecutive triangle slots: the collapse defines the final triangle order
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -41,6 +39,11 @@ namespace gsp {
 namespace {
 
 constexpr int kBlock = 256;
+
+// leaf of the BINARY tree (the build's intermediate form): ~((first slot << 2) | (count - 1)), count always 1
+__host__ __device__ __forceinline__ int32_t make_leaf(uint32_t first_slot, uint32_t count) {
+  return ~(int32_t)((first_slot << 2) | (count - 1u));
+}
 
 __device__ __forceinline__ uint32_t float_to_ordered(float f) {
   uint32_t b = __float_as_uint(f);
@@ -103,8 +106,9 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     const f3 n2 = xform_dir(T, mk3(Nn[6], Nn[7], Nn[8]));
     const f3 e1 = p1 - p0, e2 = p2 - p0;
     const f3 N = normalize(cross(e1, e2));  // rayhit.rchit:694
-    isect[3ull * g + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float(g));
-    isect[3ull * g + 1] = mkq(p1.x, p1.y, p1.z, __uint_as_float(I.bsdf >> 16));  // BSDF type of the hit, for the shade sort
+    // p0.w: tie-break key of the closest-hit rule (orders like g) + the BSDF type of the hit for the shade sort
+    isect[3ull * g + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float((g << 3) | ((I.bsdf >> 16) & 7u)));
+    isect[3ull * g + 1] = mkq(p1.x, p1.y, p1.z, 0.0f);
     isect[3ull * g + 2] = mkq(p2.x, p2.y, p2.z, 0.0f);
     shade[4ull * g + 0] = mkq(N.x, N.y, N.z, __uint_as_float(pack_material(I.bsdf, I.twofaced)));
     shade[4ull * g + 1] = mkq(n0.x, n0.y, n0.z, I.emission[0]);
@@ -293,23 +297,6 @@ __global__ __launch_bounds__(kBlock) void k_fit(int n, const int32_t* __restrict
   if (node < 0) atomicMax(max_depth, depth);
 }
 
-// depth of the deepest leaf (number of internal nodes above it)
-__global__ __launch_bounds__(kBlock) void k_depth(int n, const int32_t* __restrict__ parent_int,
-                                                  const int32_t* __restrict__ parent_leaf,
-                                                  uint32_t* __restrict__ max_depth) {
-  const int s = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t depth = 0;
-  if (s < n) {
-    int node = parent_leaf[s];
-    while (node >= 0) {
-      ++depth;
-      node = parent_int[node];
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) depth = max(depth, (uint32_t)__shfl_xor((int)depth, o));
-  if ((threadIdx.x & 63) == 0 && depth) atomicMax(max_depth, depth);
-}
 
 // ---- PLOC ------------------------------------------------------------------------------------
 #ifndef GSP_PLOC_RADIUS
@@ -396,76 +383,49 @@ __global__ __launch_bounds__(kBlock) void k_ploc_apply(int n, const int32_t* __r
   hi_out[p] = mkq(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
 }
 
-// flag[i] = 1 when binary node i sits at even depth (root = depth 0)
-__global__ __launch_bounds__(kBlock) void k_flag_even(int n_int, const int32_t* __restrict__ parent_int,
-                                                      uint32_t* __restrict__ flag) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n_int) return;
-  uint32_t depth = 0;
-  for (int node = parent_int[i]; node >= 0; node = parent_int[node]) ++depth;
-  flag[i] = (depth & 1u) ? 0u : 1u;
+// ---- collapse of the binary tree into the wide tree (pt_trace.h), one level per launch pair ---------------------------
+// A work item of a level = the binary node that becomes a wide node; the items of a level are consecutive wide nodes,
+// and so are the inner children of every node (exclusive scan of the per-item inner-child counts), which is what lets
+// a traversal name "the children of node X still to visit" as {base, which ones} instead of one pointer per child.
+// Leaf children likewise take consecutive triangle slots: the collapse defines the final triangle order.
+struct Pick {
+  q4 lo, hi;
+  int32_t code;  // >= 0 binary inner node, < 0 leaf (make_leaf)
+};
+__device__ __forceinline__ void load2(const q4* __restrict__ nodes2, int32_t b, Pick& x, Pick& y) {
+  const q4* m = nodes2 + 4ll * b;
+  const q4 a = m[0], bq = m[1], d = m[2], k = m[3];
+  x.lo = mkq(a.x, a.y, a.z, 0.0f);
+  x.hi = mkq(a.w, bq.x, bq.y, 0.0f);
+  x.code = (int32_t)__float_as_uint(k.x);
+  y.lo = mkq(bq.z, bq.w, d.x, 0.0f);
+  y.hi = mkq(d.y, d.z, d.w, 0.0f);
+  y.code = (int32_t)__float_as_uint(k.y);
 }
-
-// parity collapse: one thread per even-depth binary node
-__global__ __launch_bounds__(kBlock) void k_emit4(int n_int, const q4* __restrict__ nodes2,
-                                                  const uint32_t* __restrict__ flag,
-                                                  const uint32_t* __restrict__ idx4, q4* __restrict__ nodes4,
-                                                  uint32_t dummy_slot) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n_int || !flag[i]) return;
-  Entry4 e[4];
-  int cnt = 0;
-  auto conv = [&](int32_t g) { return g < 0 ? g : (int32_t)((idx4[g] + kTopNodes) * 64u); };  // inner child = byte offset of its node
-  auto expand = [&](int32_t c, q4 lo, q4 hi) {
-    if (c < 0) {
-      e[cnt].lo = lo;
-      e[cnt].hi = hi;
-      e[cnt].code = c;
-      ++cnt;
-    } else {  // odd-depth inner node: absorb it, adopt its two children
-      const q4* m = nodes2 + 4ll * c;
-      const q4 a = m[0], b = m[1], d = m[2], k = m[3];
-      e[cnt].lo = mkq(a.x, a.y, a.z, 0.0f);
-      e[cnt].hi = mkq(a.w, b.x, b.y, 0.0f);
-      e[cnt].code = conv((int32_t)__float_as_uint(k.x));
-      ++cnt;
-      e[cnt].lo = mkq(b.z, b.w, d.x, 0.0f);
-      e[cnt].hi = mkq(d.y, d.z, d.w, 0.0f);
-      e[cnt].code = conv((int32_t)__float_as_uint(k.y));
-      ++cnt;
+// Greedy surface-area collapse: the children of binary node b, then repeatedly the inner child with the largest box is
+// replaced by its own two children until the node is full (kWide) or only leaves are left.
+// mode 1 (GSP_COLLAPSE=parity, 4-wide only; r01 / r02's default): the children are the grandchildren of b.
+__device__ __forceinline__ int gather_children(const q4* __restrict__ nodes2, int32_t b, Pick* e, int mode) {
+  load2(nodes2, b, e[0], e[1]);
+  int cnt = 2;
+  if (mode == 1 && kWide == 4) {
+    const Pick l = e[0], r = e[1];
+    cnt = 0;
+    if (l.code >= 0) {
+      load2(nodes2, l.code, e[0], e[1]);
+      cnt = 2;
+    } else {
+      e[cnt++] = l;
     }
-  };
-  const q4* me = nodes2 + 4ll * i;
-  const q4 a = me[0], b = me[1], d = me[2], k = me[3];
-  expand((int32_t)__float_as_uint(k.x), mkq(a.x, a.y, a.z, 0.0f), mkq(a.w, b.x, b.y, 0.0f));
-  expand((int32_t)__float_as_uint(k.y), mkq(b.z, b.w, d.x, 0.0f), mkq(d.y, d.z, d.w, 0.0f));
-  encode_node4(nodes4 + 4ll * (idx4[i] + kTopNodes), e, cnt, dummy_slot);
-}
-
-// Greedy 4-wide collapse, one thread per output node of the current level.
-// work item = {binary node id, 4-wide node id}
-__global__ __launch_bounds__(kBlock) void k_collapse4(int count, const int2* __restrict__ qin,
-                                                      const q4* __restrict__ nodes2, q4* __restrict__ nodes4,
-                                                      uint32_t* __restrict__ next_id, int2* __restrict__ qout,
-                                                      uint32_t* __restrict__ qout_count, uint32_t dummy_slot) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= count) return;
-  const int2 w = qin[t];
-  Entry4 e[4];
-  int cnt = 0;
-  auto load2 = [&](int32_t b, Entry4& x, Entry4& y) {
-    const q4* m = nodes2 + 4ll * b;
-    const q4 a = m[0], bq = m[1], d = m[2], k = m[3];
-    x.lo = mkq(a.x, a.y, a.z, 0.0f);
-    x.hi = mkq(a.w, bq.x, bq.y, 0.0f);
-    x.code = (int32_t)__float_as_uint(k.x);
-    y.lo = mkq(bq.z, bq.w, d.x, 0.0f);
-    y.hi = mkq(d.y, d.z, d.w, 0.0f);
-    y.code = (int32_t)__float_as_uint(k.y);
-  };
-  load2(w.x, e[0], e[1]);
-  cnt = 2;
-  while (cnt < 4) {
+    if (r.code >= 0) {
+      load2(nodes2, r.code, e[cnt], e[cnt + 1]);
+      cnt += 2;
+    } else {
+      e[cnt++] = r;
+    }
+    return cnt;
+  }
+  while (cnt < kWide) {
     int best = -1;
     float best_area = -1.0f;
     for (int k = 0; k < cnt; ++k) {
@@ -477,26 +437,97 @@ __global__ __launch_bounds__(kBlock) void k_collapse4(int count, const int2* __r
       }
     }
     if (best < 0) break;
-    Entry4 x, y;
-    load2(e[best].code, x, y);
+    Pick x, y;
+    load2(nodes2, e[best].code, x, y);
     e[best] = x;
     e[cnt++] = y;
   }
-  // inner children become work items of the next level; their 4-wide ids are consecutive
-  int inner = 0;
-  for (int k = 0; k < cnt; ++k) inner += e[k].code >= 0 ? 1 : 0;
-  uint32_t id0 = 0, q0 = 0;
-  if (inner) {
-    id0 = atomicAdd(next_id, (uint32_t)inner);
-    q0 = atomicAdd(qout_count, (uint32_t)inner);
+  return cnt;
+}
+
+__global__ __launch_bounds__(kBlock) void k_wide_count(int count, const int32_t* __restrict__ items,
+                                                       const q4* __restrict__ nodes2, uint32_t* __restrict__ n_inner,
+                                                       uint32_t* __restrict__ n_leaf, int mode) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t > count) return;
+  if (t == count) {  // the scans run over count + 1 elements: the last one yields the totals
+    n_inner[t] = 0;
+    n_leaf[t] = 0;
+    return;
   }
+  Pick e[kWide];
+  const int cnt = gather_children(nodes2, items[t], e, mode);
+  uint32_t ni = 0;
+  for (int k = 0; k < cnt; ++k) ni += e[k].code >= 0 ? 1u : 0u;
+  n_inner[t] = ni;
+  n_leaf[t] = (uint32_t)cnt - ni;
+}
+
+// node_first: wide-node index of this level's item 0; child_first / tri_first: index of the first node of the NEXT
+// level / the first triangle slot this level hands out
+__global__ __launch_bounds__(kBlock) void k_wide_emit(int count, const int32_t* __restrict__ items,
+                                                      const q4* __restrict__ nodes2, const uint32_t* __restrict__ inner_off,
+                                                      const uint32_t* __restrict__ leaf_off, uint32_t node_first,
+                                                      uint32_t child_first, uint32_t tri_first, q4* __restrict__ nodes_out,
+                                                      int32_t* __restrict__ next_items, uint32_t* __restrict__ tri_src, int mode) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= count) return;
+  Pick e[kWide];
+  const int cnt = gather_children(nodes2, items[t], e, mode);
+  const uint32_t child_base = child_first + inner_off[t], tri_base = tri_first + leaf_off[t];
+  q4* out = nodes_out + (size_t)kNodeQuads * (node_first + (uint32_t)t);
+#if GSP_WIDE == 8
+  WideChild wc[8], by_slot[8];
+  int slot_of[8];
+  for (int k = 0; k < cnt; ++k) wc[k].lo = e[k].lo, wc[k].hi = e[k].hi;
+  assign_slots_w8(wc, cnt, slot_of);
+  uint32_t imask = 0, lmask = 0;
+  int32_t code_of[8];
+  for (int s = 0; s < 8; ++s) code_of[s] = 0;
   for (int k = 0; k < cnt; ++k) {
-    if (e[k].code >= 0) {
-      qout[q0++] = make_int2(e[k].code, (int)id0);
-      e[k].code = (int32_t)(id0++ * 64u);
-    }
+    by_slot[slot_of[k]] = wc[k];
+    code_of[slot_of[k]] = e[k].code;
+    if (e[k].code >= 0) imask |= 1u << slot_of[k];
+    else lmask |= 1u << slot_of[k];
   }
-  encode_node4(nodes4 + 4ll * w.y, e, cnt, dummy_slot);
+  encode_node_w8(out, by_slot, imask, lmask, child_base, tri_base);
+  uint32_t ri = 0, rl = 0;
+  for (int s = 0; s < 8; ++s) {  // ranks in slot order
+    if ((imask >> s) & 1u) next_items[child_base - child_first + ri++] = code_of[s];
+    else if ((lmask >> s) & 1u) tri_src[tri_base + rl++] = ((uint32_t)~code_of[s]) >> 2;
+  }
+#else
+  WideChild wc[4];
+  int ni = 0, nl = 0;
+  for (int k = 0; k < cnt; ++k)  // inner children first, in the order the collapse found them
+    if (e[k].code >= 0) {
+      wc[ni].lo = e[k].lo, wc[ni].hi = e[k].hi;
+      next_items[child_base - child_first + ni] = e[k].code;
+      ++ni;
+    }
+  for (int k = 0; k < cnt; ++k)
+    if (e[k].code < 0) {
+      wc[ni + nl].lo = e[k].lo, wc[ni + nl].hi = e[k].hi;
+      tri_src[tri_base + nl] = ((uint32_t)~e[k].code) >> 2;
+      ++nl;
+    }
+  encode_node_w4(out, wc, ni, nl, child_base, tri_base);
+#endif
+}
+
+// triangle packets into their final slots: slot s takes what Morton slot tri_src[s] held
+__global__ __launch_bounds__(kBlock) void k_permute_tris(uint32_t n, const uint32_t* __restrict__ tri_src,
+                                                         const q4* __restrict__ isect_in, const q4* __restrict__ shade_in,
+                                                         const uint32_t* __restrict__ s2g_in, q4* __restrict__ isect,
+                                                         q4* __restrict__ shade, uint32_t* __restrict__ s2g) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t m = tri_src[s];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) isect[3ull * s + k] = isect_in[3ull * m + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) shade[4ull * s + k] = shade_in[4ull * m + k];
+  s2g[s] = s2g_in[m];
 }
 
 struct Scratch {
@@ -532,8 +563,8 @@ void free_bvh(DeviceBvh& b) {
 int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::string& err) {
   free_bvh(out);
   const uint32_t n = in.num_tris;
-  const uint32_t slots = n + 1;  // slot n is a degenerate all-zero triangle (det == 0: never hit): the target of
-                                  // empty child slots and the leaf of an empty scene
+  const uint32_t slots = n + 1;  // slot n is a degenerate all-zero triangle (det == 0: never hit): what the single
+                                  // node of an empty scene points at
   out.num_tris = n;
   out.num_nodes = 0;
   size_t b_is = (size_t)slots * 48, b_sh = (size_t)slots * 64, b_map = (size_t)slots * 4;
@@ -544,25 +575,33 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(hipMemsetAsync(out.tri_isect, 0, b_is, stream));
   GSP_HIP_TRY(hipMemsetAsync(out.tri_shade, 0, b_sh, stream));
   GSP_HIP_TRY(hipMemsetAsync(out.slot_to_global, 0, b_map, stream));
-  out.root = make_leaf(0, 1);  // n == 0: slot 0 is the degenerate triangle
-  out.depth = 0;
-  if (n < 2) {  // no inner node: the root is the single (or dummy) triangle's leaf
-    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, 128));
-    GSP_HIP_TRY(hipMemsetAsync(out.nodes, 0, 128, stream));
-    out.bytes += 128;
-  }
-  if (n == 0) {
+  out.root = 0;  // the root is always node 0 (a node exists even for an empty scene)
+  out.depth = 1;
+  if (n == 0) {  // one node without children: every ray misses
+    q4 node[kNodeQuads];
+#if GSP_WIDE == 8
+    encode_node_w8(node, nullptr, 0u, 0u, 0u, 0u);
+#else
+    encode_node_w4(node, nullptr, 0, 0, 0u, 0u);
+#endif
+    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeBytes));
+    GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
+    out.bytes += kNodeBytes;
+    out.num_nodes = 1;
     GSP_HIP_TRY(hipStreamSynchronize(stream));
     return GSP_OK;
   }
 
   Scratch S;
-  q4 *isect_g, *shade_g, *lo_g, *hi_g, *leaf_lo, *leaf_hi, *int_lo, *int_hi, *nodes2;
-  uint32_t *bounds, *vals_in, *vals_out, *arrive, *d_depth, *flag, *idx4;
+  q4 *isect_g, *shade_g, *lo_g, *hi_g, *leaf_lo, *leaf_hi, *int_lo, *int_hi, *nodes2, *isect_m, *shade_m;
+  uint32_t *bounds, *vals_in, *vals_out, *arrive, *d_depth, *flag, *idx4, *s2g_m;
   uint64_t *keys_in, *keys_out;
   int32_t *child_l, *child_r, *parent_int, *parent_leaf;
   GSP_HIP_TRY(S.alloc(&isect_g, 3ull * n));
   GSP_HIP_TRY(S.alloc(&shade_g, 4ull * n));
+  GSP_HIP_TRY(S.alloc(&isect_m, 3ull * n));  // packets in Morton order (the collapse defines the final order)
+  GSP_HIP_TRY(S.alloc(&shade_m, 4ull * n));
+  GSP_HIP_TRY(S.alloc(&s2g_m, n));
   GSP_HIP_TRY(S.alloc(&lo_g, n));
   GSP_HIP_TRY(S.alloc(&hi_g, n));
   GSP_HIP_TRY(S.alloc(&leaf_lo, n));
@@ -584,7 +623,6 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(S.alloc(&flag, n + 1ull));
   GSP_HIP_TRY(S.alloc(&idx4, n + 1ull));
 
-  uint32_t collapse_levels = 0;
   const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
   GSP_HIP_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
   GSP_HIP_TRY(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, stream));
@@ -601,9 +639,35 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 63, stream));
 
   hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, vals_out, isect_g, shade_g, lo_g, hi_g,
-                     out.tri_isect, out.tri_shade, leaf_lo, leaf_hi, out.slot_to_global);
-  if (n >= 2) {
-    int32_t root2 = 0;  // binary root
+                     isect_m, shade_m, leaf_lo, leaf_hi, s2g_m);
+  GSP_HIP_TRY(hipGetLastError());
+  if (n == 1) {  // no binary inner node: one wide node with the triangle as its only child
+    q4 box[2];
+    GSP_HIP_TRY(hipMemcpyAsync(&box[0], leaf_lo, sizeof(q4), hipMemcpyDeviceToHost, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(&box[1], leaf_hi, sizeof(q4), hipMemcpyDeviceToHost, stream));
+    GSP_HIP_TRY(hipStreamSynchronize(stream));
+    q4 node[kNodeQuads];
+    WideChild c[8];
+    c[0].lo = box[0];
+    c[0].hi = box[1];
+#if GSP_WIDE == 8
+    encode_node_w8(node, c, 0u, 1u, 0u, 0u);
+#else
+    encode_node_w4(node, c, 0, 1, 0u, 0u);
+#endif
+    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeBytes));
+    GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(out.tri_isect, isect_m, 48, hipMemcpyDeviceToDevice, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(out.tri_shade, shade_m, 64, hipMemcpyDeviceToDevice, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(out.slot_to_global, s2g_m, 4, hipMemcpyDeviceToDevice, stream));
+    out.bytes += kNodeBytes;
+    out.num_nodes = 1;
+    GSP_HIP_TRY(hipStreamSynchronize(stream));
+    return GSP_OK;
+  }
+
+  int32_t root2 = 0;  // binary root
+  {
     const char* mode = getenv("GSP_BVH");
     if (mode && std::string(mode) == "lbvh") {
       hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(n - 1)), dim3(kBlock), 0, stream, (int)n, keys_out, child_l, child_r,
@@ -652,99 +716,67 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       GSP_HIP_TRY(hipStreamSynchronize(stream));
       // leaf_lo/leaf_hi may have been overwritten by the ping-pong: nothing below reads them again
     }
-    hipLaunchKernelGGL(k_depth, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, parent_int, parent_leaf, d_depth);
-    // ---- collapse to the 4-wide tree ----
-    const int n_int = (int)n - 1;
-    const char* cmode = getenv("GSP_COLLAPSE");
-    if (!(cmode && std::string(cmode) == "greedy")) {
-      GSP_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t) * (n + 1ull), stream));
-      hipLaunchKernelGGL(k_flag_even, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, parent_int, flag);
-      size_t scan_bytes = 0;
-      GSP_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
-      void* scan_tmp = nullptr;
-      GSP_HIP_TRY(S.alloc((char**)&scan_tmp, scan_bytes));
-      GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, flag, idx4, 0u, (size_t)n_int + 1, rocprim::plus<uint32_t>(), stream));
-      uint32_t n4 = 0;
-      GSP_HIP_TRY(hipMemcpyAsync(&n4, idx4 + n_int, sizeof(n4), hipMemcpyDeviceToHost, stream));
-      GSP_HIP_TRY(hipStreamSynchronize(stream));
-      out.num_nodes = n4;
-      if (((uint64_t)n4 + kTopNodes) * 64ull >= 0x7fffff00ull) {
-        err = "scene too large: BVH node offsets exceed 31 bits";
-        return GSP_ERR_INVALID;
-      }
-      const size_t b_nodes = (size_t)(std::max<uint32_t>(n4, 1) + kTopNodes) * 64;
-      GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
-      if (kTopNodes) GSP_HIP_TRY(hipMemsetAsync(out.nodes, 0, (size_t)kTopNodes * 64, stream));
-      out.bytes += b_nodes;
-      hipLaunchKernelGGL(k_emit4, dim3(blocks_for(n_int)), dim3(kBlock), 0, stream, n_int, nodes2, flag, idx4, out.nodes, n);
-      uint32_t root4 = 0;  // the binary root has depth 0, so it owns a 4-wide node
-      GSP_HIP_TRY(hipMemcpyAsync(&root4, idx4 + root2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      GSP_HIP_TRY(hipStreamSynchronize(stream));
-      out.root = (int32_t)((root4 + kTopNodes) * 64u);
-      collapse_levels = 0;
-      if (kTopNodes) {
-        // breadth-first copy of the top of the tree into slots [0, kTopNodes): child links that stay inside the copy
-        // are rewritten, the others keep pointing at the original nodes (which stay in place)
-        std::vector<q4> top(4ull * kTopNodes);
-        std::vector<int32_t> orig(kTopNodes);
-        orig[0] = out.root;
-        uint32_t count = 1;
-        for (uint32_t i = 0; i < count; ++i) {
-          q4* nd = &top[4ull * i];
-          GSP_HIP_TRY(hipMemcpyAsync(nd, (const char*)out.nodes + (uint32_t)orig[i], 64, hipMemcpyDeviceToHost, stream));
-          GSP_HIP_TRY(hipStreamSynchronize(stream));
-          float* link[4] = {&nd[2].z, &nd[2].w, &nd[3].x, &nd[3].y};
-          for (int k = 0; k < 4; ++k) {
-            const int32_t c = (int32_t)f2u(*link[k]);
-            if (c >= 0 && count < kTopNodes) {
-              orig[count] = c;
-              *link[k] = u2f(count * 64u);
-              ++count;
-            }
-          }
-        }
-        GSP_HIP_TRY(hipMemcpyAsync(out.nodes, top.data(), (size_t)count * 64, hipMemcpyHostToDevice, stream));
-        GSP_HIP_TRY(hipStreamSynchronize(stream));
-        out.root = 0;
-      }
-    } else {
-      // greedy SAH collapse, breadth-first; at most n - 1 output nodes
-      q4* all4 = nullptr;
-      GSP_HIP_TRY(hipMalloc((void**)&all4, (size_t)n_int * 64));
-      int2 *qa, *qb;
-      uint32_t* ctr;  // [0] next node id, [1] next-level queue size
-      GSP_HIP_TRY(S.alloc(&qa, (size_t)n_int));
-      GSP_HIP_TRY(S.alloc(&qb, (size_t)n_int));
-      GSP_HIP_TRY(S.alloc(&ctr, 2));
-      const int2 first = make_int2(root2, 0);
-      const uint32_t init[2] = {1u, 0u};
-      GSP_HIP_TRY(hipMemcpyAsync(qa, &first, sizeof(first), hipMemcpyHostToDevice, stream));
-      GSP_HIP_TRY(hipMemcpyAsync(ctr, init, sizeof(init), hipMemcpyHostToDevice, stream));
-      uint32_t count = 1, total = 1;
-      collapse_levels = 0;
-      while (count > 0) {
-        hipLaunchKernelGGL(k_collapse4, dim3(blocks_for(count)), dim3(kBlock), 0, stream, (int)count, qa, nodes2, all4,
-                           ctr, qb, ctr + 1, n);
-        uint32_t h[2];
-        GSP_HIP_TRY(hipMemcpyAsync(h, ctr, sizeof(h), hipMemcpyDeviceToHost, stream));
-        GSP_HIP_TRY(hipStreamSynchronize(stream));
-        GSP_HIP_TRY(hipMemsetAsync(ctr + 1, 0, sizeof(uint32_t), stream));
-        total = h[0];
-        count = h[1];
-        std::swap(qa, qb);
-        ++collapse_levels;
-      }
-      out.nodes = all4;
-      out.num_nodes = total;
-      out.bytes += (size_t)n_int * 64;
-      out.root = 0;
+  }
+  // ---- collapse to the wide tree, level by level ----
+  const uint32_t n_int = n - 1;  // binary inner nodes: an upper bound of the wide nodes
+  q4* wide = nullptr;
+  GSP_HIP_TRY(S.alloc(&wide, (size_t)kNodeQuads * n_int));
+  int32_t *items_a = child_l, *items_b = child_r;  // (free again after the hierarchy pass)
+  uint32_t *n_inner = flag, *n_leaf = idx4, *inner_off, *leaf_off, *tri_src = vals_in;
+  GSP_HIP_TRY(S.alloc(&inner_off, n + 1ull));
+  GSP_HIP_TRY(S.alloc(&leaf_off, n + 1ull));
+  size_t scan_bytes = 0;
+  GSP_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, n_inner, inner_off, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), stream));
+  void* scan_tmp = nullptr;
+  GSP_HIP_TRY(S.alloc((char**)&scan_tmp, scan_bytes));
+  GSP_HIP_TRY(hipMemcpyAsync(items_a, &root2, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  uint32_t count = 1, node_first = 0, tri_done = 0, levels = 0;
+  // 4-wide default: the parity collapse (children = grandchildren).  On PLOC trees it beats the greedy surface-area
+  // collapse -- bench scene 14.7 vs 15.1 nodes per extension ray, 7.5 vs 9.2 per shadow ray (profiles/r03_collapse.txt;
+  // the CPU probe agrees: 10.2 vs 10.4, 7.7 vs 8.3) -- while on top-down SAH trees it is the other way round.
+  const char* cmode = getenv("GSP_COLLAPSE");
+  const int mode = cmode ? (std::string(cmode) == "parity" ? 1 : 0) : (kWide == 4 ? 1 : 0);
+  while (count > 0) {
+    hipLaunchKernelGGL(k_wide_count, dim3(blocks_for(count + 1ull)), dim3(kBlock), 0, stream, (int)count, items_a, nodes2, n_inner, n_leaf, mode);
+    GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, n_inner, inner_off, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
+    GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, n_leaf, leaf_off, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
+    const uint32_t child_first = node_first + count;
+    hipLaunchKernelGGL(k_wide_emit, dim3(blocks_for(count)), dim3(kBlock), 0, stream, (int)count, items_a, nodes2, inner_off, leaf_off,
+                       node_first, child_first, tri_done, wide, items_b, tri_src, mode);
+    uint32_t totals[2] = {0, 0};
+    GSP_HIP_TRY(hipMemcpyAsync(&totals[0], inner_off + count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(&totals[1], leaf_off + count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSP_HIP_TRY(hipStreamSynchronize(stream));
+    GSP_HIP_TRY(hipGetLastError());
+    node_first = child_first;
+    tri_done += totals[1];
+    count = totals[0];
+    std::swap(items_a, items_b);
+    ++levels;
+    if ((uint64_t)node_first + count > n_int || levels > 4096) {
+      err = "wide collapse overran its node bound (internal error)";
+      return GSP_ERR_DEVICE;
     }
   }
+  if (tri_done != n) {
+    err = "wide collapse lost triangles (internal error)";
+    return GSP_ERR_DEVICE;
+  }
+  const uint32_t num_nodes = node_first;
+  if (num_nodes >= kMaxNodes) {
+    err = "scene too large: more BVH nodes than the traversal's node index holds";
+    return GSP_ERR_INVALID;
+  }
+  out.num_nodes = num_nodes;
+  const size_t b_nodes = (size_t)num_nodes * kNodeBytes;
+  GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
+  out.bytes += b_nodes;
+  GSP_HIP_TRY(hipMemcpyAsync(out.nodes, wide, b_nodes, hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(k_permute_tris, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, tri_src, isect_m, shade_m, s2g_m,
+                     out.tri_isect, out.tri_shade, out.slot_to_global);
   GSP_HIP_TRY(hipGetLastError());
-  uint32_t depth = 0;
-  GSP_HIP_TRY(hipMemcpyAsync(&depth, d_depth, sizeof(depth), hipMemcpyDeviceToHost, stream));
   GSP_HIP_TRY(hipStreamSynchronize(stream));
-  out.depth = collapse_levels ? collapse_levels : depth / 2 + 1;  // levels of the 4-wide tree
+  out.depth = levels;  // levels of the wide tree: a traversal stacks at most one node group per level
   return GSP_OK;
 }
 

@@ -21,14 +21,14 @@ namespace gsp {
 
 // Result of the device BVH build; all pointers are device memory owned by the caller's context.
 struct DeviceBvh {
-  q4* nodes = nullptr;      // 4-wide BVH, 4 quads (64 B, compressed) per node
+  q4* nodes = nullptr;      // wide BVH, kNodeQuads quads per node (pt_trace.h); node 0 is the root
   q4* tri_isect = nullptr;  // 3 quads per slot
   q4* tri_shade = nullptr;  // 4 quads per slot
   uint32_t* slot_to_global = nullptr;
   int32_t root = 0;
   uint32_t num_tris = 0;   // real triangles (0 allowed; one dummy slot is still allocated)
   uint32_t num_nodes = 0;
-  uint32_t depth = 0;      // levels of the 4-wide tree (bounds the traversal stack: <= 3 pushes per level)
+  uint32_t depth = 0;      // levels of the wide tree (bounds the traversal stack: <= 1 node group per level)
   size_t bytes = 0;
 };
 

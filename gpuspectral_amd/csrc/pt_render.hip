@@ -4,8 +4,8 @@
 // One render pass handles K consecutive timestamps of every owned pixel
 // (K * num_pixels paths).  Per bounce, three kernels run over dense queues in HBM:
 //
-//   extend  : persistent wave64 state machine over the compressed 4-wide BVH (pt_wavetrace.h; per-lane
-//             stack in LDS), writes a 16-B hit record  (traceRayEXT, raygen.rgen:53-58)
+//   extend  : persistent wave64 state machine over the compressed wide BVH (pt_wavetrace.h; per-lane
+//             stack of node groups in LDS), writes a 16-B hit record  (traceRayEXT, raygen.rgen:53-58)
 //   shade   : one shading vertex per lane (rayhit.rchit:666-797 + the raygen
 //             bookkeeping of raygen.rgen:59-80); each 256-path tile is counting-sorted by BSDF type in
 //             LDS, survivors are compacted into the next queue with a wave64 ballot + an LDS scan +
@@ -20,9 +20,16 @@
 //
 // Queue records (SoA of 16-B quads, coalesced 1 KiB per wave-load):
 //   P0 = {o.x, o.y, o.z, d.x}   P1 = {d.y, d.z, bits(seed), bits(sid)}
-//   P2 = {w.r, w.g, w.b, directWeight}   FL = flags word
+//   P2 = {w.r, w.g, w.b, directWeight}   P3 = {sum.r, sum.g, sum.b, bits(flags)}
 //   HIT = {t, u, v, bits(slot)}
 //   S0 = {o.xyz, tmax}  S1 = {d.xyz, bits(sid)}  S2 = {nee.rgb, dw_nee}  S3 = {emis.rgb, bits(next)}
+//   S4 = {sum.rgb, bits(flags of the continuing path)}
+// `sum` = the radiance the sample has collected so far (raygen.rgen:60-63 `result`).  It TRAVELS WITH THE PATH (r03): a
+// bounce adds to the copy it read with its path record and hands the new value to the continuing path's record, and
+// only the bounce that ends the path stores it in the sample-result ring.  Until r02 every bounce read-modify-wrote the
+// ring entry of its sample instead -- a scattered 16-B load on the dependent chain of k_trace<ConnectIO>'s commit
+// (three loads -> load -> add -> store), 26 % of that kernel's time (profiles/r03_ab_connect_ablation.txt).  The
+// additions per sample and their order are the same, so the images are.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -46,13 +53,14 @@ struct PathQueue {
   q4* P0;
   q4* P1;
   q4* P2;
-  uint32_t* FL;
+  q4* P3;
 };
 struct ShadowQueue {
   q4* S0;
   q4* S1;
   q4* S2;
   q4* S3;
+  q4* S4;
 };
 
 // Device counter words of a pipeline lane.  Two TAIL SETS of 32 words (one 128-B line each), used alternately by
@@ -132,13 +140,13 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
     qst(&q.P0[j], mkq(p.o.x, p.o.y, p.o.z, p.d.x));
     qst(&q.P1[j], mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid)));
     qst(&q.P2[j], mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight));
-    qst(&q.FL[j], p.flags);
-    result[sid] = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+    qst(&q.P3[j], mkq(0.0f, 0.0f, 0.0f, ub(p.flags)));  // (the ring entry is written once, by the bounce that ends the path)
   }
 }
 
 // ---- extend / connect / test hook: ray sources and result sinks of k_trace -----------------
 struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
+  static constexpr float kTmin = 0.0f, kTmax = 1e10f;
   PathQueue q;
   q4* hits;
   __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
@@ -155,8 +163,10 @@ struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
 };
 
 struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any hit
+  static constexpr float kTmin = 0.01f, kTmax = -1.0f;
   ShadowQueue sq;
   q4* next_P2;
+  q4* next_P3;
   q4* result;
   float clampv;
   __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
@@ -166,22 +176,30 @@ struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any h
     tmin = 0.01f;
     tmax = s0.w;
   }
+  // The bounce's emitted radiance joins the sample's sum (`(0 + nee) + emis` behind the firefly test) and the sum moves
+  // on: into the continuing path's record, or -- the path ended at this vertex -- into the sample-result ring.  Four
+  // independent loads of the ray's own record and two or three stores; nothing is read back from where it is written.
   __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t) const {
-    const q4 s1 = sq.S1[i], s2 = sq.S2[i], s3 = sq.S3[i];
+    const q4 s1 = sq.S1[i], s2 = sq.S2[i], s3 = sq.S3[i], s4 = sq.S4[i];
     ShadowRay r;
     r.nee = mk3(s2.x, s2.y, s2.z);
     r.emis = mk3(s3.x, s3.y, s3.z);
-    const uint32_t sid = fb(s1.w);
-    q4 res = result[sid];
+    q4 res = s4;
     bool nee_done;
     connect_vertex(clampv, r, h.slot >= 0, res, nee_done);
-    result[sid] = res;
     const uint32_t nx = fb(s3.w);
-    if (nee_done && nx != 0xffffffffu) next_P2[nx].w = s2.w;  // rayhit.rchit:785-787
+    if (nx != 0xffffffffu) {
+      next_P3[nx] = res;                          // (.w = the continuing path's flags, put there by k_shade)
+      if (nee_done) next_P2[nx].w = s2.w;         // rayhit.rchit:785-787
+    } else {
+      res.w = 0.0f;
+      result[fb(s1.w)] = res;
+    }
   }
 };
 
 struct TestIO {  // gsp_trace
+  static constexpr float kTmin = -1.0f, kTmax = -1.0f;
   const float* rays;
   q4* hits;
   const uint32_t* slot_to_global;
@@ -272,8 +290,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   __shared__ uint16_t s_order[kShadeBlock];    // sorted position -> thread offset inside the tile
   __shared__ uint32_t s_cnt[2][kShadeWaves];   // per-wave survivor / shadow counts of this iteration
   __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave start in the global queues
-  __shared__ q4 s_hq[kShadeBlock], s_p0[kShadeBlock], s_p1[kShadeBlock], s_p2[kShadeBlock];
-  __shared__ uint32_t s_fl[kShadeBlock];
+  __shared__ q4 s_hq[kShadeBlock], s_p0[kShadeBlock], s_p1[kShadeBlock], s_p2[kShadeBlock], s_p3[kShadeBlock];
   for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxSlots; k += kShadeBlock) s_dead[k] = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
         s_p0[threadIdx.x] = qld(&cur.P0[i0]);
         s_p1[threadIdx.x] = qld(&cur.P1[i0]);
         s_p2[threadIdx.x] = qld(&cur.P2[i0]);
-        s_fl[threadIdx.x] = qld(&cur.FL[i0]);
+        s_p3[threadIdx.x] = qld(&cur.P3[i0]);
         const uint32_t w = fb(hq0.w);
         key = (w == 0xffffffffu) ? 8u : ((w >> 28) & 7u);
       }
@@ -323,10 +340,12 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     bool alive = false, has_shadow = false;
     uint32_t my_sid = 0;
     ShadeOut out;
+    q4 sum = mkq(0.0f, 0.0f, 0.0f, 0.0f);
     if (i < n) {
       const q4 hq = s_hq[src];
       const q4 p0 = s_p0[src], p1 = s_p1[src], p2 = s_p2[src];
-      const uint32_t fl = s_fl[src];
+      sum = s_p3[src];  // the sample's sum so far + the flags word
+      const uint32_t fl = fb(sum.w);
       my_sid = fb(p1.w);
       HitRec h;
       h.t = hq.x;
@@ -349,19 +368,15 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
         alive = out.alive;
         has_shadow = out.has_shadow;
         ++shaded;
-        if (!has_shadow) {
-          q4 r = result[in.sid];
-          add_emitted(rc.clamp, out.emitted, r);
-          result[in.sid] = r;
-        }
+        if (!has_shadow) add_emitted(rc.clamp, out.emitted, sum);  // (else k_trace<ConnectIO> adds the bounce's terms)
       } else if (TEX && S.tex.env_texels != nullptr) {  // escaped: environment radiance, then the path ends
         PathState in;
         in.d = mk3(p0.w, p1.x, p1.y);
         in.weight = mk3(p2.x, p2.y, p2.z);
-        q4 r = result[my_sid];
-        add_emitted(rc.clamp, miss_emitted(S, in), r);
-        result[my_sid] = r;
+        add_emitted(rc.clamp, miss_emitted(S, in), sum);
       }
+      // the path ends here and no shadow ray is pending: its sum is the sample
+      if (!alive && !has_shadow) result[my_sid] = mkq(sum.x, sum.y, sum.z, 0.0f);
     }
     // paths that ended here leave their sample slot's live count (a slot is resolved when it
     // reaches 0): summed per block in LDS, flushed once at the end of the kernel
@@ -403,7 +418,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       qst(&nxt.P0[j], mkq(p.o.x, p.o.y, p.o.z, p.d.x));
       qst(&nxt.P1[j], mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid)));
       qst(&nxt.P2[j], mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight));
-      qst(&nxt.FL[j], p.flags);
+      // (with a shadow ray pending the sum is not final yet: the connect pass writes P3 of the continuing path)
+      if (!has_shadow) qst(&nxt.P3[j], mkq(sum.x, sum.y, sum.z, ub(p.flags)));
     }
     if (has_shadow) {
       const uint32_t s = s_base[1][wave] + (uint32_t)__popcll(sm & lt_mask);
@@ -412,6 +428,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(r.sid)));
       qst(&sq.S2[s], mkq(r.nee.x, r.nee.y, r.nee.z, r.dw_nee));
       qst(&sq.S3[s], mkq(r.emis.x, r.emis.y, r.emis.z, ub(alive ? j : 0xffffffffu)));
+      qst(&sq.S4[s], mkq(sum.x, sum.y, sum.z, ub(out.next.flags)));
     }
   }
   __syncthreads();
@@ -428,12 +445,27 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
 // only its own chain of dependent loads.  Same stage functions (shade_vertex, connect_vertex, add_emitted) and the
 // same per-sample order of additions as k_shade / ConnectIO, so the arithmetic per path is unchanged.
 constexpr uint32_t kFinishPaths = 262144;  // scan 0 / 64 k / 256 k / 1 M: 8-spp call 62 / 56 / 54 / 56 ms, 500x500 1-spp frames 88 / 138 / 182 / 184 per s
+// the traversal stack of a k_finish lane: one node group per tree level, in LDS ([word][thread]; r02 kept 96 entries per
+// lane in scratch memory, 400 B).  Trees deeper than this leave the tail of a drain to the wavefront kernels.
+constexpr uint32_t kFinishLevels = 36;
+struct FinishStack {
+  lds_u32* col;  // this thread's column
+  uint32_t top;  // words in use
+  __device__ __forceinline__ void push(uint32_t v) { col[(top++) * kBlock] = v; }
+  __device__ __forceinline__ uint32_t pop() { return col[(--top) * kBlock]; }
+};
 
 template <bool TEX>
 __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc, uint32_t n, PathQueue q,
                                                     q4* __restrict__ result, uint32_t* __restrict__ tails,
                                                     uint32_t* __restrict__ live,
                                                     uint32_t slot_paths, DevStats* __restrict__ stats) {
+  __shared__ uint32_t s_stack[kFinishLevels * kStackWords * kBlock];
+  __shared__ uint32_t s_table[kStepTableBytes / 4];
+  stage_step_table(s_table, threadIdx.x, kBlock);
+  __syncthreads();
+  const LdsStepTable tab{(const __attribute__((address_space(3))) char*)s_table};
+  FinishStack stk{(lds_u32*)s_stack + threadIdx.x, 0u};
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   unsigned long long ext = 0, sh = 0, shaded = 0;
   if (i < n) {
@@ -445,14 +477,16 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
     in.sid = fb(p1.w);
     in.weight = mk3(p2.x, p2.y, p2.z);
     in.directWeight = p2.w;
-    in.flags = q.FL[i];
+    const q4 p3 = q.P3[i];
+    in.flags = fb(p3.w);
     const uint32_t sid = in.sid;
-    q4 res = result[sid];  // single owner of this sample slot from here on
+    q4 res = mkq(p3.x, p3.y, p3.z, 0.0f);  // the sample's sum so far
     for (;;) {
       HitRec h;
       uint32_t aux;
       ++ext;
-      if (!trace_ray4<false>(S.nodes, S.tri_isect, S.root, in.o, in.d, 0.0f, 1e10f, h, aux)) {  // miss.rmiss:15-18
+      stk.top = 0;
+      if (!trace_ray<false>(S.nodes, S.tri_isect, in.o, in.d, 0.0f, 1e10f, h, aux, stk, tab)) {  // miss.rmiss:15-18
         if (TEX && S.tex.env_texels != nullptr) add_emitted(rc.clamp, miss_emitted(S, in), res);
         break;
       }
@@ -465,7 +499,8 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
         HitRec hs;
         uint32_t aux2;
         ++sh;
-        const bool occluded = trace_ray4<true>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2);
+        stk.top = 0;
+        const bool occluded = trace_ray<true>(S.nodes, S.tri_isect, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2, stk, tab);
         bool nee_done;
         connect_vertex(rc.clamp, out.shadow, occluded, res, nee_done);
         if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;  // rayhit.rchit:785-787
@@ -628,10 +663,9 @@ struct gsp_context {
     hipStream_t stream = nullptr;
     uint64_t num_pixels = 0;
     uint64_t pool_cap = 0, result_cap = 0;
-    DevBuf<q4> P0[2], P1[2], P2[2], hits, result, S0, S1, S2, S3;
-    DevBuf<uint32_t> FL[2];
+    DevBuf<q4> P0[2], P1[2], P2[2], P3[2], hits, result, S0, S1, S2, S3, S4;
     DevBuf<uint32_t> counters;
-    DevBuf<int32_t> spill;
+    DevBuf<uint32_t> spill;
     uint32_t* h_counters = nullptr;  // pinned: one read-back buffer of C_READBACK words per iteration parity
     hipEvent_t done[2] = {nullptr, nullptr};  // that read-back has landed
     std::vector<hipEvent_t> ev;      // 2 x 4 kernel-timing events (collect_kernel_times)
@@ -689,7 +723,7 @@ struct gsp_context {
     return v;
   }
 #ifndef GSP_BLOCKS_PER_CU
-#define GSP_BLOCKS_PER_CU 7  // 7 x 22 KB LDS stack, 7 waves per SIMD (A/B: 5 -> -4 %, 6 -> -1 %, 8 spills)
+#define GSP_BLOCKS_PER_CU 7  // 7 x 22 KB LDS (stack + step table), 7 waves per SIMD (A/B: 5 -> -4 %, 6 -> -1 %, 8 spills)
 #endif
   uint32_t max_blocks() const { return (uint32_t)num_cus * GSP_BLOCKS_PER_CU; }  // resident 256-thread blocks per CU
   uint32_t grid_for(uint64_t n) const {
@@ -706,9 +740,9 @@ struct gsp_context {
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, max_blocks()));
   }
   int ensure_spill() {
-    // ordered descent pushes at most 3 siblings per level of the 4-wide tree (+ sentinel, slack)
-    const uint32_t bound = 3 * bvh.depth + 4;
-    const uint32_t need = bound > (uint32_t)kLdsStackDepth ? bound - kLdsStackDepth : 1;
+    // a descent pushes at most one node group per level of the wide tree (+ sentinel, slack)
+    const uint32_t bound = bvh.depth + 2;
+    const uint32_t need = (bound > (uint32_t)kLdsStackDepth ? bound - kLdsStackDepth : 1) * kStackWords;
     spill_stride = max_blocks() * kBlock;
     for (uint32_t l = 0; l < num_lanes; ++l) GSP_HIP_TRY(lanes[l].spill.ensure((size_t)need * spill_stride, &bytes));
     return GSP_OK;
@@ -1046,13 +1080,14 @@ static int ensure_pool(gsp_context* ctx, gsp_context::Lane& L, uint64_t cap, uin
     CTX_TRY(ctx, L.P0[k].ensure(cap, &ctx->bytes));
     CTX_TRY(ctx, L.P1[k].ensure(cap, &ctx->bytes));
     CTX_TRY(ctx, L.P2[k].ensure(cap, &ctx->bytes));
-    CTX_TRY(ctx, L.FL[k].ensure(cap, &ctx->bytes));
+    CTX_TRY(ctx, L.P3[k].ensure(cap, &ctx->bytes));
   }
   CTX_TRY(ctx, L.hits.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S0.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S1.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S2.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S3.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, L.S4.ensure(cap, &ctx->bytes));
   L.pool_cap = cap;
   return GSP_OK;
 }
@@ -1107,8 +1142,8 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   uint32_t* live = L.counters.p + C_LIVE;
   hipEvent_t* ev = timing ? &L.ev[4 * t] : nullptr;
   PathQueue Q[2];
-  for (int k = 0; k < 2; ++k) Q[k] = PathQueue{L.P0[k].p, L.P1[k].p, L.P2[k].p, L.FL[k].p};
-  ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p};
+  for (int k = 0; k < 2; ++k) Q[k] = PathQueue{L.P0[k].p, L.P1[k].p, L.P2[k].p, L.P3[k].p};
+  ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p, L.S4.p};
   const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
   const uint64_t n = P.n;  // exact, or an upper bound of what this iteration traces
@@ -1118,7 +1153,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
 
   CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
   if (drain && exact && P.remaining == 0 && n > 0 && n <= ctx->finish_paths && !stats_mode &&
-      3 * ctx->bvh.depth + 4 <= (uint32_t)kLaneStackDepth) {
+      ctx->bvh.depth + 2 <= kFinishLevels) {
     // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
     // on its own lane (not when gsp_render merely queues work: those paths ride along with the next call's)
     if (ctx->textured)
@@ -1170,11 +1205,11 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
         uint32_t* work = L.counters.p + C_WORK_EXT;
         if (stats_mode)
           hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                             view.root, (const uint32_t*)(tails_in + T_NEXT), 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
+                             (const uint32_t*)(tails_in + T_NEXT), 0u, 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
                              so_ext);
         else
           hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                             view.root, (const uint32_t*)(tails_in + T_NEXT), 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
+                             (const uint32_t*)(tails_in + T_NEXT), 0u, 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
                              so_ext);
         CTX_TRY(ctx, hipGetLastError());
       }
@@ -1191,15 +1226,15 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       CTX_TRY(ctx, hipGetLastError());
       if (timing) CTX_TRY(ctx, hipEventRecord(ev[2], st));
       {
-        const ConnectIO io{SQ, Q[cur ^ 1].P2, L.result.p, rcst.clamp};
+        const ConnectIO io{SQ, Q[cur ^ 1].P2, Q[cur ^ 1].P3, L.result.p, rcst.clamp};
         uint32_t* work = L.counters.p + C_WORK_SH;
         if (stats_mode)
           hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                             view.root, (const uint32_t*)(tails_out + T_SHADOW), 0u, chunk, io, work, L.spill.p,
+                             (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, io, work, L.spill.p,
                              ctx->spill_stride, so_sh);
         else
           hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                             view.root, (const uint32_t*)(tails_out + T_SHADOW), 0u, chunk, io, work, L.spill.p,
+                             (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, io, work, L.spill.p,
                              ctx->spill_stride, so_sh);
         CTX_TRY(ctx, hipGetLastError());
       }
@@ -1379,7 +1414,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     // order, once its live count has dropped to zero.
     // paths in flight over all lanes: per-launch fixed costs (drained wave tails, launch gaps) amortise over the pool
     // size -- r01 bench scan: 8 M 5.35, 12 M 5.76, 24 M 6.11, 48 M 6.16, 96 M 6.25 Grays/s; r02 (final kernels): 32 M 7.48,
-    // 48 M 7.63, 64 M 7.64 (profiles/r02_ab_pool_size.txt).  48 M paths: 18 GB of queues (capacity 2 x the target)
+    // 48 M 7.63, 64 M 7.64 (profiles/r02_ab_pool_size.txt).  48 M paths: 22 GB of queues (capacity 2 x the target)
     uint64_t total_target = 48ull << 20;
     if (const char* e = getenv("GSP_POOL_PATHS")) total_target = std::max<uint64_t>(1ull << 16, strtoull(e, nullptr, 10));
     for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
@@ -1401,15 +1436,15 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
       {
         // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline
-        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  184 B of queues per
-        // path of capacity (2 x 52-B path records, 16-B hit, 64-B shadow record), capacity = 2 x the pool target.
+        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  224 B of queues per
+        // path of capacity (2 x 64-B path records, 16-B hit, 80-B shadow record), capacity = 2 x the pool target.
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          const uint64_t have = L.pool_cap * 184ull + L.result_cap * sizeof(q4);
+          const uint64_t have = L.pool_cap * 224ull + L.result_cap * sizeof(q4);
           const uint64_t budget = (uint64_t)((double)free_b * 0.4) + have;
-          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 184ull;
+          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 224ull;
           if (queues > budget / 2) {
-            const uint64_t fit = budget / 2 / 184ull;  // paths of capacity that fit
+            const uint64_t fit = budget / 2 / 224ull;  // paths of capacity that fit
             P.pool_target = std::max<uint64_t>(2 * P.batch_paths, fit > P.batch_paths ? (fit - P.batch_paths) / 2 : 0);
           }
           ring_bytes = std::min<uint64_t>(ring_bytes, std::max<uint64_t>(budget / 2, 4 * P.batch_paths * sizeof(q4)));
@@ -1596,11 +1631,11 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   const TraceStatsOut none{nullptr, nullptr, nullptr};
   if (any_hit)
     hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
-                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, kChunkSmall, io, d_work.p,
+                       view.nodes, view.tri_isect, (const uint32_t*)nullptr, (uint32_t)n, 0u, kChunkSmall, io, d_work.p,
                        ctx->lanes[0].spill.p, ctx->spill_stride, none);
   else
     hipLaunchKernelGGL((k_trace<false, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
-                       view.nodes, view.tri_isect, view.root, (const uint32_t*)nullptr, (uint32_t)n, kChunkSmall, io, d_work.p,
+                       view.nodes, view.tri_isect, (const uint32_t*)nullptr, (uint32_t)n, 0u, kChunkSmall, io, d_work.p,
                        ctx->lanes[0].spill.p, ctx->spill_stride, none);
   CTX_TRY(ctx, hipGetLastError());
   CTX_TRY(ctx, hipMemcpyAsync(hits, d_hits.p, n * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,32 +1,61 @@
-// pt_trace.h -- BVH node / triangle packet layouts in HBM, the node encoder, the 4-wide node step and the
-// triangle test every traversal shares (wave kernel pt_wavetrace.h, k_finish, host test harness tests/emu).
+// pt_trace.h -- BVH node / triangle packet layouts in HBM, the node encoder, the wide-node step and the triangle
+// test every traversal shares (wave kernel pt_wavetrace.h, k_finish, host test harness tests/emu).
 //
 // Replaces the driver's acceleration-structure traversal behind traceRayEXT
 // (S/assets/shaders/raygen.rgen:58, rayhit.rchit:738-748; build call sites
 // S/backend/vulkan/VulkanRays.cpp:6-181).
 //
+// r03: the tree is a wide BVH with CONTIGUOUS CHILDREN traversed in a STATIC per-octant order, so that a node step
+// has no sort network and pushes at most ONE stack entry (the rest of the node's hit children: a "node group"):
+//   * the inner children of a node are consecutive nodes, its leaf children are consecutive triangle slots (one
+//     triangle per leaf child), so a group of children is {base, which ones, in which order} in 32 bits (4-wide) /
+//     64 bits (8-wide) instead of one pointer per child;
+//   * the visiting order of a node's children is fixed at build time for each of the 8 sign octants of the ray
+//     direction (children sorted by the projection of their box centre, in units of the node's extent, on the
+//     octant's diagonal).  Measured on the CPU (scripts/experiments/wide_bvh_probe.cpp, 200 k-triangle interior,
+//     quantised boxes): 10.46 node visits per ray against 10.46 with an exact distance sort per node.
+// GSP_WIDE selects the node width: 4 (default) or 8 (A/B variant).
+//
 // HBM layout (all records are whole float4s so one lane moves 16 B per load):
-//   4-wide node (64 B, compressed; the kernels are bound by the number of divergent 16-B load
-//   instructions per node step, so a node is 4 loads instead of the 7 an uncompressed one needs):
+//   4-wide node, "W4T" (64 B):
 //                  q0 = {origin.x, origin.y, origin.z, scale.x}
 //                       plane = origin + q * scale, q in 0..255, scale = a power of two per axis
 //                  q1 = {qlo.x[child0..3], qlo.y[0..3], qlo.z[0..3], qhi.x[0..3]}   one byte per child
-//                  q2 = {qhi.y[0..3], qhi.z[0..3], bits(child0), bits(child1)}
-//                  q3 = {bits(child2), bits(child3), scale.y, scale.z}
-//           child boxes are quantised outward (floor / ceil, verified against the decode), so they
-//           contain the exact boxes: culling stays conservative and results do not change
-//           child >= 0 : inner node, BYTE offset of the node (index * 64) from the node array
-//           unused slot: inverted box (qlo = 255, qhi = 0) + the leaf of the degenerate triangle kept
-//                        in slot num_tris, so the traversal has no empty-slot test
-//           child <  0 : leaf, c = ~child, first slot = c >> 2, count = (c & 3) + 1
-//   triangle packet (48 B, in BVH leaf order):
-//                  p0 = {v0.x, v0.y, v0.z, bits(global triangle id)}
-//                  p1 = {v1.x, v1.y, v1.z, bits(BSDF type of the owning instance)}
+//                  q2 = {qhi.y[0..3], qhi.z[0..3], bits(child_base), bits(tri_base - ni)}
+//                  q3 = {bits(order_lo), bits(order_hi), scale.y, scale.z}
+//           children: the ni inner children first (positions 0..ni-1: nodes child_base + position), then the leaf
+//           children (position p >= ni: triangle slot (tri_base - ni) + p); unused positions carry an inverted box
+//           (qlo = 255, qhi = 0: never hit), so the traversal has no empty-slot test.
+//           order_lo / order_hi: 7 bits per ray octant (0..3 / 4..7) = 2 * the code of {ni, visiting order of the
+//           inner children}; the sequence table (SeqTable4, staged in LDS by the kernels) maps {miss mask, code} to
+//           the hit inner children in visiting order + the hit leaf children.  order_lo bits 28..31 = mask of the
+//           inner positions: any-hit rays, for which the order hardly matters (scripts/experiments/
+//           wide_bvh_probe.cpp: 7.64 vs 7.74 node visits) but the latency of a step does, take the hit children in
+//           position order straight from the miss mask instead of through the table.
+//   8-wide node, "W8X" (80 B), after Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs through
+//   compressed wide BVHs" (HPG 2017):
+//                  q0 = {origin.xyz, bits(scale.x[31:16] | scale.y[31:16] >> 16)}     (powers of two: the upper half is all of them)
+//                  q1 = {bits(scale.z[31:16] | imask << 8 | lmask), bits(child_base), bits(tri_base), -}
+//                  q2 = {qlo.x[0..3], qlo.x[4..7], qlo.y[0..3], qlo.y[4..7]}
+//                  q3 = {qlo.z[0..3], qlo.z[4..7], qhi.x[0..3], qhi.x[4..7]}
+//                  q4 = {qhi.y[0..3], qhi.y[4..7], qhi.z[0..3], qhi.z[4..7]}
+//           a child sits in the slot whose octant its centre lies in (greedy assignment on centre . diagonal); a ray
+//           of sign octant `oct` visits the hit slots in increasing slot ^ oct.  imask / lmask: slots holding inner
+//           nodes / triangles; inner child in slot s = node child_base + popcount(imask below s), leaf likewise.
+//   child boxes are quantised outward (floor / ceil, verified against the decode), so they contain the exact
+//   boxes: culling stays conservative and results do not change.
+//   triangle packet (48 B, in the order the collapse emits leaf children):
+//                  p0 = {v0.x, v0.y, v0.z, bits(global triangle id << 3 | BSDF type of the owning instance)}
+//                  p1 = {v1.x, v1.y, v1.z, -}
 //                  p2 = {v2.x, v2.y, v2.z, -}
-//   Closest hit = smallest t, ties broken by the smaller global triangle id, so
+//   Closest hit = smallest t, ties broken by the smaller global triangle id (the p0.w words order like the ids), so
 //   the result does not depend on the BVH topology or traversal order.
 #pragma once
 #include "pt_math.h"
+
+#ifndef GSP_WIDE
+#define GSP_WIDE 4
+#endif
 
 namespace gsp {
 
@@ -39,16 +68,11 @@ struct HitRec {
   int32_t slot;  // triangle slot in BVH leaf order; -1 = miss
 };
 
-constexpr int kLeafMaxTris = 4;
-// A/B variant ("BVH top levels through LDS"): the first GSP_LDS_TOP slots of the node array hold a
-// breadth-first copy of the top of the tree (root = slot 0; 21 = three levels, 85 = four), which k_trace stages into
-// LDS once per block and reads with ds_read_b128 instead of global loads.  0 = off.
-#ifndef GSP_LDS_TOP
-#define GSP_LDS_TOP 0
-#endif
-constexpr uint32_t kTopNodes = GSP_LDS_TOP;
-constexpr int32_t kEmptyChild = 0x7ffffffe;  // unused slot of a 4-wide node
-GSP_HD int32_t make_leaf(uint32_t first_slot, uint32_t count) { return ~(int32_t)((first_slot << 2) | (count - 1u)); }
+constexpr int kWide = GSP_WIDE;
+constexpr uint32_t kNodeQuads = kWide == 8 ? 5u : 4u;  // 16-B quads per node
+constexpr uint32_t kNodeBytes = 16u * kNodeQuads;
+// child_base travels through the packed 32-bit stack entries of the 4-wide traversal in 23 bits
+constexpr uint32_t kMaxNodes = kWide == 8 ? (1u << 25) : (1u << 23);
 
 // Watertight ray/triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle
 // Intersection", JCGT 2013), no back-face culling: the ray is sheared so that it
@@ -112,11 +136,6 @@ GSP_HD bool intersect_tri(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t
 GSP_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
 GSP_HD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 
-// ---- compressed 4-wide node: encoder (device BVH build, pt_bvh.hip; host test harness, tests/emu) --------------
-struct Entry4 {
-  q4 lo, hi;
-  int32_t code;
-};
 GSP_HD q4 make_q4(float x, float y, float z, float w) {
   q4 r;
   r.x = x;
@@ -125,15 +144,108 @@ GSP_HD q4 make_q4(float x, float y, float z, float w) {
   r.w = w;
   return r;
 }
-// Writes one compressed 4-wide node (64 B, layout at the top of this file) from up to four child entries.
-// Child boxes are quantised outward and checked against the decode (plane = fma(q, scale, origin)).
-GSP_HD void encode_node4(q4* __restrict__ o, const Entry4* e, int cnt, uint32_t dummy_slot) {
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+
+// ---- static tables of the traversal -----------------------------------------------------------------------------
+// 4-wide: the order code c of a node for one ray octant names {ni, visiting order of the inner children 0..ni-1}:
+//   c = 0: ni 0 | 1: ni 1 | 2..3: ni 2 | 4..9: ni 3 | 10..33: ni 4, permutations in lexicographic order.
+// SeqTable4[miss][c] (16 rows of 64 entries, 2 KB) = seq | leaf_hits << 9, where seq lists the positions of the hit
+// inner children in visiting order, two bits each, first one lowest, under a marker bit (seq == 1: none), and
+// leaf_hits bit p = the leaf child at position p (>= ni) is hit.
+constexpr uint32_t kSeqEmpty = 1u;
+constexpr int kOrderCodes = 34;
+struct OrderCode {
+  int ni;
+  int perm[4];
+};
+constexpr OrderCode decode_order(int c) {
+  OrderCode r{0, {0, 0, 0, 0}};
+  int idx = 0;
+  if (c == 0) return r;
+  if (c == 1) r.ni = 1, idx = 0;
+  else if (c < 4) r.ni = 2, idx = c - 2;
+  else if (c < 10) r.ni = 3, idx = c - 4;
+  else r.ni = 4, idx = c - 10;
+  int avail[4] = {0, 1, 2, 3};
+  int left = r.ni;
+  for (int i = 0; i < r.ni; ++i) {
+    int f = 1;
+    for (int k = 2; k < left; ++k) f *= k;  // (left - 1)!
+    const int k = idx / f;
+    idx %= f;
+    r.perm[i] = avail[k];
+    for (int j = k; j + 1 < left; ++j) avail[j] = avail[j + 1];
+    --left;
+  }
+  return r;
+}
+// inverse of decode_order: the code of {ni, perm[0..ni)}
+constexpr int encode_order(int ni, const int* perm) {
+  if (ni == 0) return 0;
+  const int base = ni == 1 ? 1 : (ni == 2 ? 2 : (ni == 3 ? 4 : 10));
+  int avail[4] = {0, 1, 2, 3};
+  int left = ni, idx = 0;
+  for (int i = 0; i < ni; ++i) {
+    int f = 1;
+    for (int k = 2; k < left; ++k) f *= k;
+    int k = 0;
+    while (avail[k] != perm[i]) ++k;
+    idx += k * f;
+    for (int j = k; j + 1 < left; ++j) avail[j] = avail[j + 1];
+    --left;
+  }
+  return base + idx;
+}
+struct SeqTable4 {
+  uint16_t v[16 * 64];
+  constexpr SeqTable4() : v() {
+    for (int m = 0; m < 16; ++m)
+      for (int c = 0; c < 64; ++c) {
+        uint32_t e = kSeqEmpty;
+        if (c < kOrderCodes) {
+          const OrderCode oc = decode_order(c);
+          const uint32_t hit = ~(uint32_t)m & 15u;
+          uint32_t seq = kSeqEmpty;
+          for (int i = oc.ni - 1; i >= 0; --i)
+            if ((hit >> oc.perm[i]) & 1u) seq = (seq << 2) | (uint32_t)oc.perm[i];
+          e = seq | ((hit & ~((1u << oc.ni) - 1u)) << 9);
+        }
+        v[m * 64 + c] = (uint16_t)e;
+      }
+  }
+};
+// 8-wide: FirstTable8[oct][mask] = the slot s of `mask` with the smallest s ^ oct (2 KB); mask 0 -> 0.
+struct FirstTable8 {
+  uint8_t v[8 * 256];
+  constexpr FirstTable8() : v() {
+    for (int o = 0; o < 8; ++o)
+      for (int m = 0; m < 256; ++m) {
+        int best = 0, bk = 8;
+        for (int s = 0; s < 8; ++s)
+          if (((m >> s) & 1) && (s ^ o) < bk) bk = s ^ o, best = s;
+        v[o * 256 + m] = (uint8_t)best;
+      }
+  }
+};
+constexpr uint32_t kStepTableBytes = 2048;  // either table
+#if GSP_WIDE == 8
+constexpr FirstTable8 kStepTable{};
+#else
+constexpr SeqTable4 kStepTable{};
+#endif
+
+// ---- node encoder (device BVH build, pt_bvh.hip; host test harness, tests/emu) --------------------------------------
+struct WideChild {
+  q4 lo, hi;  // box (xyz)
+};
+// common part: origin, per-axis power-of-two scale, and the quantised planes q[plane][child] (plane: lo.x lo.y lo.z hi.x hi.y hi.z)
+GSP_HD void quantise_children(const WideChild* e, int cnt, float* lo, float* scale, uint8_t q[6][8]) {
+  float hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  lo[0] = lo[1] = lo[2] = 3.0e38f;
   for (int k = 0; k < cnt; ++k) {
     lo[0] = fmin_(lo[0], e[k].lo.x); lo[1] = fmin_(lo[1], e[k].lo.y); lo[2] = fmin_(lo[2], e[k].lo.z);
     hi[0] = fmax_(hi[0], e[k].hi.x); hi[1] = fmax_(hi[1], e[k].hi.y); hi[2] = fmax_(hi[2], e[k].hi.z);
   }
-  float scale[3];
+  if (cnt == 0) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
   for (int a = 0; a < 3; ++a) {
     const float ext = hi[a] - lo[a];
     int ex = -100;
@@ -144,7 +256,8 @@ GSP_HD void encode_node4(q4* __restrict__ o, const Entry4* e, int cnt, uint32_t 
     while (eb < 254 && __builtin_fmaf(255.0f, u2f((uint32_t)eb << 23), lo[a]) < hi[a]) ++eb;
     scale[a] = u2f((uint32_t)eb << 23);
   }
-  uint32_t q[6] = {0, 0, 0, 0, 0, 0};  // qlo.x, qlo.y, qlo.z, qhi.x, qhi.y, qhi.z : one byte per child
+  for (int k = 0; k < 8; ++k)  // unused: inverted box (near plane beyond the far plane: misses)
+    for (int a = 0; a < 3; ++a) q[a][k] = 255, q[3 + a][k] = 0;
   for (int k = 0; k < cnt; ++k) {
     const float cl[3] = {e[k].lo.x, e[k].lo.y, e[k].lo.z}, ch[3] = {e[k].hi.x, e[k].hi.y, e[k].hi.z};
     for (int a = 0; a < 3; ++a) {
@@ -152,29 +265,113 @@ GSP_HD void encode_node4(q4* __restrict__ o, const Entry4* e, int cnt, uint32_t 
       while (ql > 0.0f && __builtin_fmaf(ql, scale[a], lo[a]) > cl[a]) ql -= 1.0f;  // decoded plane must not exceed the box
       float qh = fmin_(fmax_(__builtin_ceilf((ch[a] - lo[a]) / scale[a]), 0.0f), 255.0f);
       while (qh < 255.0f && __builtin_fmaf(qh, scale[a], lo[a]) < ch[a]) qh += 1.0f;
-      q[a] |= (uint32_t)ql << (8 * k);
-      q[3 + a] |= (uint32_t)qh << (8 * k);
+      q[a][k] = (uint8_t)ql;
+      q[3 + a][k] = (uint8_t)qh;
     }
   }
-  // unused slots: inverted box (near plane beyond the far plane: misses) that leads to the degenerate
-  // triangle, so the traversal needs no empty-slot test and a rounding fluke costs one triangle test
-  for (int k = cnt; k < 4; ++k)
-    for (int a = 0; a < 3; ++a) q[a] |= 255u << (8 * k);
-  int32_t code[4];
-  for (int k = 0; k < 4; ++k) code[k] = k < cnt ? e[k].code : make_leaf(dummy_slot, 1);
+}
+// the key that orders the children of a node for the rays of one sign octant (bit a of `oct` set = direction negative
+// on axis a): centre of the child box in units of the node's extent, projected on the octant's diagonal
+GSP_HD float order_key(const WideChild& c, const float* ext, int oct) {
+  const float cx = ext[0] > 0.0f ? (c.lo.x + c.hi.x) / ext[0] : 0.0f;
+  const float cy = ext[1] > 0.0f ? (c.lo.y + c.hi.y) / ext[1] : 0.0f;
+  const float cz = ext[2] > 0.0f ? (c.lo.z + c.hi.z) / ext[2] : 0.0f;
+  return ((oct & 1 ? -cx : cx) + (oct & 2 ? -cy : cy)) + (oct & 4 ? -cz : cz);
+}
+GSP_HD uint32_t pack4(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
+
+// 4-wide node: e[0..ni) inner children (nodes child_base + k), e[ni..ni+nl) leaf children (triangle slots tri_base + j)
+GSP_HD void encode_node_w4(q4* __restrict__ o, const WideChild* e, int ni, int nl, uint32_t child_base, uint32_t tri_base) {
+  float lo[3], scale[3];
+  uint8_t q[6][8];
+  quantise_children(e, ni + nl, lo, scale, q);
+  float ext[3] = {0.0f, 0.0f, 0.0f};
+  for (int k = 0; k < ni + nl; ++k) {
+    ext[0] = fmax_(ext[0], e[k].hi.x - lo[0]);
+    ext[1] = fmax_(ext[1], e[k].hi.y - lo[1]);
+    ext[2] = fmax_(ext[2], e[k].hi.z - lo[2]);
+  }
+  uint32_t order[2] = {0u, 0u};
+  for (int oct = 0; oct < 8; ++oct) {
+    float key[4];
+    int perm[4] = {0, 1, 2, 3};
+    for (int k = 0; k < ni; ++k) key[k] = order_key(e[k], ext, oct);
+    for (int i = 1; i < ni; ++i)  // insertion sort, ties keep the position order
+      for (int j = i; j > 0 && key[perm[j]] < key[perm[j - 1]]; --j) {
+        const int t = perm[j];
+        perm[j] = perm[j - 1];
+        perm[j - 1] = t;
+      }
+    const uint32_t c2 = 2u * (uint32_t)encode_order(ni, perm);
+    order[oct >> 2] |= c2 << (7 * (oct & 3));
+  }
+  order[0] |= ((1u << ni) - 1u) << 28;
   o[0] = make_q4(lo[0], lo[1], lo[2], scale[0]);
-  o[1] = make_q4(u2f(q[0]), u2f(q[1]), u2f(q[2]), u2f(q[3]));
-  o[2] = make_q4(u2f(q[4]), u2f(q[5]), u2f((uint32_t)code[0]), u2f((uint32_t)code[1]));
-  o[3] = make_q4(u2f((uint32_t)code[2]), u2f((uint32_t)code[3]), scale[1], scale[2]);
+  o[1] = make_q4(u2f(pack4(q[0])), u2f(pack4(q[1])), u2f(pack4(q[2])), u2f(pack4(q[3])));
+  o[2] = make_q4(u2f(pack4(q[4])), u2f(pack4(q[5])), u2f(child_base), u2f(tri_base - (uint32_t)ni));
+  o[3] = make_q4(u2f(order[0]), u2f(order[1]), scale[1], scale[2]);
 }
 
-// ---- compressed 4-wide node: one traversal step (the ONE decode + slab test + ordering every traversal uses:
-// k_trace and k_finish on the device, tests/emu on the host) ------------------------------------------------------
+// 8-wide node: children in any order; kind[k] != 0: inner.  Returns through slot_of[k] the slot each child was given
+// (the caller numbers the inner / leaf children in SLOT order: rank = popcount of the mask below the slot).
+GSP_HD void assign_slots_w8(const WideChild* e, int cnt, int* slot_of) {
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = 0; k < cnt; ++k) {
+    lo[0] = fmin_(lo[0], e[k].lo.x); lo[1] = fmin_(lo[1], e[k].lo.y); lo[2] = fmin_(lo[2], e[k].lo.z);
+    hi[0] = fmax_(hi[0], e[k].hi.x); hi[1] = fmax_(hi[1], e[k].hi.y); hi[2] = fmax_(hi[2], e[k].hi.z);
+  }
+  const float c0[3] = {lo[0] + hi[0], lo[1] + hi[1], lo[2] + hi[2]};  // 2 * centre
+  float cost[8][8];
+  for (int k = 0; k < cnt; ++k) {
+    const float d[3] = {(e[k].lo.x + e[k].hi.x) - c0[0], (e[k].lo.y + e[k].hi.y) - c0[1], (e[k].lo.z + e[k].hi.z) - c0[2]};
+    for (int s = 0; s < 8; ++s) cost[k][s] = ((s & 1 ? d[0] : -d[0]) + (s & 2 ? d[1] : -d[1])) + (s & 4 ? d[2] : -d[2]);
+  }
+  bool cu[8] = {false, false, false, false, false, false, false, false}, su[8] = {false, false, false, false, false, false, false, false};
+  for (int it = 0; it < cnt; ++it) {
+    float best = -3.0e38f;
+    int bk = 0, bs = 0;
+    bool any = false;
+    for (int k = 0; k < cnt; ++k)
+      if (!cu[k])
+        for (int s = 0; s < 8; ++s)
+          if (!su[s] && (!any || cost[k][s] > best)) best = cost[k][s], bk = k, bs = s, any = true;
+    cu[bk] = su[bs] = true;
+    slot_of[bk] = bs;
+  }
+}
+// e[s] = the child in slot s (s in 0..7) for the slots set in imask | lmask
+GSP_HD void encode_node_w8(q4* __restrict__ o, const WideChild* e, uint32_t imask, uint32_t lmask, uint32_t child_base, uint32_t tri_base) {
+  WideChild packed[8];
+  int where[8], cnt = 0;
+  for (int s = 0; s < 8; ++s)
+    if (((imask | lmask) >> s) & 1u) packed[cnt] = e[s], where[cnt++] = s;
+  float lo[3], scale[3];
+  uint8_t qp[6][8], q[6][8];
+  quantise_children(packed, cnt, lo, scale, qp);
+  for (int p = 0; p < 6; ++p)
+    for (int s = 0; s < 8; ++s) q[p][s] = p < 3 ? 255 : 0;
+  for (int k = 0; k < cnt; ++k)
+    for (int p = 0; p < 6; ++p) q[p][where[k]] = qp[p][k];
+  const uint32_t sx = f2u(scale[0]), sy = f2u(scale[1]), sz = f2u(scale[2]);  // powers of two: mantissa 0
+  o[0] = make_q4(lo[0], lo[1], lo[2], u2f((sx & 0xffff0000u) | (sy >> 16)));
+  o[1] = make_q4(u2f((sz & 0xffff0000u) | (imask << 8) | lmask), u2f(child_base), u2f(tri_base), 0.0f);
+  o[2] = make_q4(u2f(pack4(q[0])), u2f(pack4(q[0] + 4)), u2f(pack4(q[1])), u2f(pack4(q[1] + 4)));
+  o[3] = make_q4(u2f(pack4(q[2])), u2f(pack4(q[2] + 4)), u2f(pack4(q[3])), u2f(pack4(q[3] + 4)));
+  o[4] = make_q4(u2f(pack4(q[4])), u2f(pack4(q[4] + 4)), u2f(pack4(q[5])), u2f(pack4(q[5] + 4)));
+}
+
+// ---- the node step ------------------------------------------------------------------------------------------------
 // Per-ray constants of the step.
 struct RayBox {
   f3 o, inv;               // origin, 1 / direction
   f3 invc;                 // inv clamped to +-2^64 (box tests only; the triangle test uses the exact ray)
   bool negx, negy, negz;   // sign of 1/d per axis: which plane of a slab is the near one
+#if GSP_WIDE == 8
+  uint32_t octrow;         // 256 * sign octant: row of FirstTable8
+#else
+  bool octhi;              // sign octant >= 4: the node's order_hi word
+  uint32_t octshift;       // 7 * (octant & 3): position of the octant's order code in that word
+#endif
 };
 GSP_HD RayBox make_raybox(f3 o, f3 d) {
   RayBox r;
@@ -185,12 +382,31 @@ GSP_HD RayBox make_raybox(f3 o, f3 d) {
   r.negz = r.inv.z < 0.0f;
   const float big = 18446744073709551616.0f;  // 2^64
   r.invc = mk3(fmin_(fmax_(r.inv.x, -big), big), fmin_(fmax_(r.inv.y, -big), big), fmin_(fmax_(r.inv.z, -big), big));
+#if GSP_WIDE == 8
+  r.octrow = ((r.negx ? 1u : 0u) | (r.negy ? 2u : 0u) | (r.negz ? 4u : 0u)) * 256u;
+#else
+  r.octhi = r.negz;
+  r.octshift = (r.negx ? 7u : 0u) + (r.negy ? 14u : 0u);
+#endif
   return r;
 }
-// Tests the four child boxes of the node {n0..n3} against the ray segment [tmin, tfar] and returns the children
-// ordered by entry distance: e0 nearest .. e3, of which the first `hits` are hit (the rest are unspecified).
-// The return value is hits * UNIT (the wave kernel keeps the count in stack-offset units).
-//   decode: plane = origin + q * scale (per-axis power of two, stored as a float); its ray parameter is
+
+// m = (m << 1) | (x < 0): one v_alignbit_b32 on the device (the sign bit of x is shifted into the mask)
+GSP_HD uint32_t shift_in_sign(uint32_t m, float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(m, __float_as_uint(x), 31);
+#else
+  return (m << 1) | (f2u(x) >> 31);
+#endif
+}
+
+// (float)((q >> 8k) & 0xff) compiles to v_cvt_f32_ubyteK
+#define GSP_UB0(q) ((float)((q) & 0xffu))
+#define GSP_UB1(q) ((float)(((q) >> 8) & 0xffu))
+#define GSP_UB2(q) ((float)(((q) >> 16) & 0xffu))
+#define GSP_UB3(q) ((float)((q) >> 24))
+// One child box against the ray segment [tmin, tfar]; a miss shifts a 1 into M.
+//   decode: plane = origin + q * scale (per-axis power of two); its ray parameter is
 //   t = fma(q, scale / d, (origin - o) / d): one fma per plane after six multiplies per node (scale / d is exact up to
 //   the rounding of 1/d: scale is a power of two).  1/d is CLAMPED to +-2^64 for this: with an infinite 1/d (a zero
 //   direction component) every plane of that axis would be fma(q, inf, +-inf) = NaN, the slab would stop
@@ -199,88 +415,179 @@ GSP_HD RayBox make_raybox(f3 o, f3 d) {
 //   far beyond tmax <= 1e10 on the same side (culled, correctly: the ray never enters), a slab it is inside of gives
 //   -huge / +huge (unconstrained), and no product can overflow (|scale|, |origin - o| < 2^40).  The rounding error of
 //   t is of the same order as with an uncompressed (b - o) * (1/d) test -- 2^-24 |origin - o| / |d| -- and is covered
-//   by the outward quantisation, the padded leaf boxes and the 8-ulp slack on the far bound.  r02 A/B against
-//   (fma(q, scale, origin - o)) * (1/d): closest-hit kernel -3.4 %, any-hit -1.4 %, bit-identical images
-//   (profiles/r02_ab_fold_ldstop.txt).
+//   by the outward quantisation, the padded leaf boxes and the 8-ulp slack on the far bound.
 //   Near / far planes are picked by the sign of 1/d instead of min / max per child: for inv > 0
 //   (lo - o) * inv <= (hi - o) * inv by monotonic rounding, so the values are the ones min / max would return; a
-//   NaN (0 * inf) is dropped by max / min and leaves that side unconstrained.  The far bound is relaxed by 8 ulp on
-//   top of the padded boxes.  Unused slots carry an inverted box and the degenerate triangle's leaf: no test needed.
-template <uint32_t UNIT>
-GSP_HD uint32_t node4_step(const q4& n0, const q4& n1, const q4& n2, const q4& n3, const RayBox& rb, float tmin, float tfar,
-                           int32_t& e0, int32_t& e1, int32_t& e2, int32_t& e3) {
+//   NaN (0 * inf) is dropped by max / min and leaves that side unconstrained.
+//   hit  <=>  lo <= hi * (1 + 8 ulp)  <=>  fma(hi, 1.000001, -lo) >= 0 (an fma and the sign bit instead of a multiply,
+//   a compare and a select; lo and hi are never NaN: tmin and tfar are not).
+#define GSP_CHILD(M, CVT, QNX, QFX, QNY, QFY, QNZ, QFZ)                                            \
+  {                                                                                                 \
+    const float tnx = __builtin_fmaf(CVT(QNX), sx, dx), tfx = __builtin_fmaf(CVT(QFX), sx, dx);     \
+    const float tny = __builtin_fmaf(CVT(QNY), sy, dy), tfy = __builtin_fmaf(CVT(QFY), sy, dy);     \
+    const float tnz = __builtin_fmaf(CVT(QNZ), sz, dz), tfz = __builtin_fmaf(CVT(QFZ), sz, dz);     \
+    const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));                                      \
+    const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, tfar));                                      \
+    M = shift_in_sign(M, __builtin_fmaf(hi, 1.000001f, -lo));                                       \
+  }
+
+#if GSP_WIDE == 8
+// bit s of the result = the child in slot s is MISSED
+GSP_HD uint32_t node_test(const q4* n, const RayBox& rb, float tmin, float tfar) {
+  const uint32_t w0 = f2u(n[0].w);
+  const float sx = u2f(w0 & 0xffff0000u) * rb.invc.x, sy = u2f(w0 << 16) * rb.invc.y, sz = u2f(f2u(n[1].x) & 0xffff0000u) * rb.invc.z;
+  const float dx = (n[0].x - rb.o.x) * rb.invc.x, dy = (n[0].y - rb.o.y) * rb.invc.y, dz = (n[0].z - rb.o.z) * rb.invc.z;
+  const uint32_t lx0 = f2u(n[2].x), lx1 = f2u(n[2].y), ly0 = f2u(n[2].z), ly1 = f2u(n[2].w);
+  const uint32_t lz0 = f2u(n[3].x), lz1 = f2u(n[3].y), hx0 = f2u(n[3].z), hx1 = f2u(n[3].w);
+  const uint32_t hy0 = f2u(n[4].x), hy1 = f2u(n[4].y), hz0 = f2u(n[4].z), hz1 = f2u(n[4].w);
+  const uint32_t nx0 = rb.negx ? hx0 : lx0, nx1 = rb.negx ? hx1 : lx1, fx0 = rb.negx ? lx0 : hx0, fx1 = rb.negx ? lx1 : hx1;
+  const uint32_t ny0 = rb.negy ? hy0 : ly0, ny1 = rb.negy ? hy1 : ly1, fy0 = rb.negy ? ly0 : hy0, fy1 = rb.negy ? ly1 : hy1;
+  const uint32_t nz0 = rb.negz ? hz0 : lz0, nz1 = rb.negz ? hz1 : lz1, fz0 = rb.negz ? lz0 : hz0, fz1 = rb.negz ? lz1 : hz1;
+  uint32_t m = 0;  // slot 7 first, so that slot s ends at bit s
+  GSP_CHILD(m, GSP_UB3, nx1, fx1, ny1, fy1, nz1, fz1)
+  GSP_CHILD(m, GSP_UB2, nx1, fx1, ny1, fy1, nz1, fz1)
+  GSP_CHILD(m, GSP_UB1, nx1, fx1, ny1, fy1, nz1, fz1)
+  GSP_CHILD(m, GSP_UB0, nx1, fx1, ny1, fy1, nz1, fz1)
+  GSP_CHILD(m, GSP_UB3, nx0, fx0, ny0, fy0, nz0, fz0)
+  GSP_CHILD(m, GSP_UB2, nx0, fx0, ny0, fy0, nz0, fz0)
+  GSP_CHILD(m, GSP_UB1, nx0, fx0, ny0, fy0, nz0, fz0)
+  GSP_CHILD(m, GSP_UB0, nx0, fx0, ny0, fy0, nz0, fz0)
+  return m;
+}
+#else
+// bit k of the result = child k is MISSED
+GSP_HD uint32_t node_test(const q4* n, const RayBox& rb, float tmin, float tfar) {
   // per-node constants of the decode: scale / d and (origin - o) / d per axis (6 multiplies), then ONE fma per plane
-  const float sx = n0.w * rb.invc.x, sy = n3.z * rb.invc.y, sz = n3.w * rb.invc.z;
-  const float dx = (n0.x - rb.o.x) * rb.invc.x, dy = (n0.y - rb.o.y) * rb.invc.y, dz = (n0.z - rb.o.z) * rb.invc.z;
-  const uint32_t qlx = f2u(n1.x), qly = f2u(n1.y), qlz = f2u(n1.z), qhx = f2u(n1.w), qhy = f2u(n2.x), qhz = f2u(n2.y);
+  const float sx = n[0].w * rb.invc.x, sy = n[3].z * rb.invc.y, sz = n[3].w * rb.invc.z;
+  const float dx = (n[0].x - rb.o.x) * rb.invc.x, dy = (n[0].y - rb.o.y) * rb.invc.y, dz = (n[0].z - rb.o.z) * rb.invc.z;
+  const uint32_t qlx = f2u(n[1].x), qly = f2u(n[1].y), qlz = f2u(n[1].z), qhx = f2u(n[1].w), qhy = f2u(n[2].x), qhz = f2u(n[2].y);
   const uint32_t qnx = rb.negx ? qhx : qlx, qfx = rb.negx ? qlx : qhx;
   const uint32_t qny = rb.negy ? qhy : qly, qfy = rb.negy ? qly : qhy;
   const uint32_t qnz = rb.negz ? qhz : qlz, qfz = rb.negz ? qlz : qhz;
-  float lo4[4];
-  bool hit4[4];
-// (float)((q >> 8k) & 0xff) compiles to v_cvt_f32_ubyteK
-#define GSP_UB0(q) ((float)((q) & 0xffu))
-#define GSP_UB1(q) ((float)(((q) >> 8) & 0xffu))
-#define GSP_UB2(q) ((float)(((q) >> 16) & 0xffu))
-#define GSP_UB3(q) ((float)((q) >> 24))
-#define GSP_CHILD(K, CVT)                                                                                         \
-  {                                                                                                               \
-    const float tnx = __builtin_fmaf(CVT(qnx), sx, dx), tfx = __builtin_fmaf(CVT(qfx), sx, dx);                   \
-    const float tny = __builtin_fmaf(CVT(qny), sy, dy), tfy = __builtin_fmaf(CVT(qfy), sy, dy);                   \
-    const float tnz = __builtin_fmaf(CVT(qnz), sz, dz), tfz = __builtin_fmaf(CVT(qfz), sz, dz);                   \
-    const float lo = fmax_(fmax_(tnx, tny), fmax_(tnz, tmin));                                                    \
-    const float hi = fmin_(fmin_(tfx, tfy), fmin_(tfz, tfar));                                                    \
-    lo4[K] = lo;                                                                                                  \
-    hit4[K] = lo <= hi * 1.000001f;                                                                               \
-  }
-  GSP_CHILD(0, GSP_UB0)
-  GSP_CHILD(1, GSP_UB1)
-  GSP_CHILD(2, GSP_UB2)
-  GSP_CHILD(3, GSP_UB3)
+  uint32_t m = 0;  // child 3 first, so that child k ends at bit k
+  GSP_CHILD(m, GSP_UB3, qnx, qfx, qny, qfy, qnz, qfz)
+  GSP_CHILD(m, GSP_UB2, qnx, qfx, qny, qfy, qnz, qfz)
+  GSP_CHILD(m, GSP_UB1, qnx, qfx, qny, qfy, qnz, qfz)
+  GSP_CHILD(m, GSP_UB0, qnx, qfx, qny, qfy, qnz, qfz)
+  return m;
+}
+#endif
 #undef GSP_CHILD
 #undef GSP_UB0
 #undef GSP_UB1
 #undef GSP_UB2
 #undef GSP_UB3
-  const bool h0 = hit4[0], h1 = hit4[1], h2 = hit4[2], h3 = hit4[3];
-  // order the hit children by entry distance: 5-comparator network on {distance bits, child}
-  // (entry distances are >= tmin >= 0, so their bit patterns order like unsigned integers; a miss sorts last)
-  uint32_t k0 = h0 ? f2u(lo4[0]) : 0xffffffffu, k1 = h1 ? f2u(lo4[1]) : 0xffffffffu;
-  uint32_t k2 = h2 ? f2u(lo4[2]) : 0xffffffffu, k3 = h3 ? f2u(lo4[3]) : 0xffffffffu;
-  e0 = (int32_t)f2u(n2.z);
-  e1 = (int32_t)f2u(n2.w);
-  e2 = (int32_t)f2u(n3.x);
-  e3 = (int32_t)f2u(n3.y);
-#define GSP_CSWAP(ka, kb, ea, eb)   \
-  {                                 \
-    const bool sw = kb < ka;        \
-    const uint32_t tk = sw ? kb : ka; \
-    kb = sw ? ka : kb;              \
-    ka = tk;                        \
-    const int32_t te = sw ? eb : ea; \
-    eb = sw ? ea : eb;              \
-    ea = te;                        \
-  }
-  GSP_CSWAP(k0, k1, e0, e1)
-  GSP_CSWAP(k2, k3, e2, e3)
-  GSP_CSWAP(k0, k2, e0, e2)
-  GSP_CSWAP(k1, k3, e1, e3)
-  GSP_CSWAP(k1, k2, e1, e2)
-#undef GSP_CSWAP
-  return (h0 ? UNIT : 0u) + (h1 ? UNIT : 0u) + (h2 ? UNIT : 0u) + (h3 ? UNIT : 0u);
-}
 
-// One ray against the 4-wide BVH on one thread, start to finish: the traversal of k_finish (which runs the last few
+// A node group = the children of ONE node that a ray still has to visit: {gb, gs}.
+//   4-wide, closest hit: gb = child_base, gs = their positions in visiting order (2 bits each under a marker bit;
+//                        kSeqEmpty: none)
+//   4-wide, any hit:     gb = child_base, gs = mask of their positions (taken in position order)
+//   8-wide:              gb = child_base, gs = hit inner slots | imask << 8
+// A triangle group = the hit leaf children of one node: {tb, tm}.
+//   4-wide: tb = tri_base - ni, tm = hit leaf positions (bit p = slot tb + p)
+//   8-wide: tb = tri_base, tm = hit leaf slots | lmask << 8
+// `TAB(byte offset)` reads the step table (LDS copy on the device, kStepTable on the host).
+#if GSP_WIDE == 8
+template <bool ANY>
+GSP_HD bool group_empty(uint32_t gs) { return (gs & 0xffu) == 0u; }
+GSP_HD bool tris_empty(uint32_t tm) { return (tm & 0xffu) == 0u; }
+template <bool ANY>
+constexpr uint32_t root_group() { return 0x101u; }  // node 0 as "slot 0 of a node whose only inner slot is 0"
+template <bool ANY>
+constexpr uint32_t no_group() { return 0u; }
+template <bool ANY, class TAB>
+GSP_HD void node_step(const q4* n, const RayBox& rb, float tmin, float tfar, const TAB& tab, uint32_t& gb, uint32_t& gs, uint32_t& tb,
+                      uint32_t& tm) {
+  const uint32_t miss = node_test(n, rb, tmin, tfar);
+  const uint32_t w = f2u(n[1].x);
+  const uint32_t imask = (w >> 8) & 0xffu, lmask = w & 0xffu;
+  gs = (imask & ~miss) | (imask << 8);
+  tm = (lmask & ~miss) | (lmask << 8);
+  gb = f2u(n[1].y);
+  tb = f2u(n[1].z);
+}
+// takes the nearest child out of a non-empty group; returns the BYTE offset of its node
+template <bool ANY, class TAB>
+GSP_HD uint32_t group_next(uint32_t gb, uint32_t& gs, const RayBox& rb, const TAB& tab) {
+  const uint32_t slot = tab(rb.octrow + (gs & 0xffu));
+  const uint32_t bit = 1u << slot;
+  gs ^= bit;
+  const uint32_t rank = (uint32_t)__builtin_popcount((gs >> 8) & (bit - 1u));
+  return (gb + rank) * kNodeBytes;
+}
+// takes one triangle out of a non-empty triangle group; returns its slot
+GSP_HD uint32_t tris_next(uint32_t tb, uint32_t& tm) {
+  const uint32_t slot = (uint32_t)__builtin_ctz(tm);
+  const uint32_t bit = 1u << slot;
+  tm ^= bit;
+  return tb + (uint32_t)__builtin_popcount((tm >> 8) & (bit - 1u));
+}
+#else
+template <bool ANY>
+GSP_HD bool group_empty(uint32_t gs) { return ANY ? gs == 0u : gs <= kSeqEmpty; }
+GSP_HD bool tris_empty(uint32_t tm) { return tm == 0u; }
+template <bool ANY>
+constexpr uint32_t root_group() { return ANY ? 1u : 4u; }  // {base 0, one child at position 0}
+template <bool ANY>
+constexpr uint32_t no_group() { return ANY ? 0u : kSeqEmpty; }
+template <bool ANY, class TAB>
+GSP_HD void node_step(const q4* n, const RayBox& rb, float tmin, float tfar, const TAB& tab, uint32_t& gb, uint32_t& gs, uint32_t& tb,
+                      uint32_t& tm) {
+  const uint32_t miss = node_test(n, rb, tmin, tfar);
+  if (ANY) {  // position order, no table (and no LDS round trip on the dependent chain of the step)
+    const uint32_t hit = ~miss & 15u;
+    gs = hit & (f2u(n[3].x) >> 28);
+    tm = hit ^ gs;
+  } else {
+    const uint32_t pw = rb.octhi ? f2u(n[3].y) : f2u(n[3].x);
+    const uint32_t c2 = (pw >> rb.octshift) & 127u;
+    const uint32_t e = tab((miss << 7) | c2);
+    gs = e & 511u;
+    tm = e >> 9;
+  }
+  gb = f2u(n[2].z);
+  tb = f2u(n[2].w);
+}
+template <bool ANY, class TAB>
+GSP_HD uint32_t group_next(uint32_t gb, uint32_t& gs, const RayBox&, const TAB&) {
+  uint32_t r;
+  if (ANY) {
+    r = (uint32_t)__builtin_ctz(gs);
+    gs &= gs - 1u;
+  } else {
+    r = gs & 3u;
+    gs >>= 2;
+  }
+  return (gb + r) << 6;
+}
+GSP_HD uint32_t tris_next(uint32_t tb, uint32_t& tm) {
+  const uint32_t p = (uint32_t)__builtin_ctz(tm);
+  tm &= tm - 1u;
+  return tb + p;
+}
+#endif
+
+// host / k_finish view of the step table
+struct StepTableRef {
+  const void* base;
+  GSP_HD uint32_t operator()(uint32_t byte_off) const {
+#if GSP_WIDE == 8
+    return ((const uint8_t*)base)[byte_off];
+#else
+    return ((const uint16_t*)base)[byte_off >> 1];
+#endif
+  }
+};
+
+// One ray against the wide BVH on one thread, start to finish: the traversal of k_finish (which runs the last few
 // thousand paths of a drain to completion without the wavefront queues) and of the host test harness.  Same node
 // step, same triangle test and the same min-t / min-id rule as the wave kernel (pt_wavetrace.h), so the hit is the
 // same; the visiting order is not (and need not be).  ANY = true: return at the first accepted triangle
-// (TerminateOnFirstHit | SkipClosestHitShader).  aux = p1.w of the accepted triangle (BSDF type).
-constexpr int kLaneStackDepth = 96;
-template <bool ANY>
-GSP_HD bool trace_ray4(const q4* __restrict__ nodes, const q4* __restrict__ tris, int32_t root, f3 o, f3 d, float tmin,
-                       float tmax, HitRec& h, uint32_t& aux) {
-  int32_t stack[kLaneStackDepth];
-  int sp = 0;
+// (TerminateOnFirstHit | SkipClosestHitShader).  aux = BSDF type of the accepted triangle (low 3 bits of p0.w).
+// STACK: push(uint32_t) / pop() of 32-bit words; at most one group (1 word 4-wide, 2 words 8-wide) per tree level.
+template <bool ANY, class STACK, class TAB>
+GSP_HD bool trace_ray(const q4* __restrict__ nodes, const q4* __restrict__ tris, f3 o, f3 d, float tmin, float tmax, HitRec& h,
+                      uint32_t& aux, STACK& stk, const TAB& tab) {
   const RayBox rb = make_raybox(o, d);
   RayShear rs = make_shear(d);
   rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
@@ -289,44 +596,62 @@ GSP_HD bool trace_ray4(const q4* __restrict__ nodes, const q4* __restrict__ tris
   h.slot = -1;
   aux = 0;
   uint32_t best_id = 0xffffffffu;
-  int32_t cur = root;
+  uint32_t gb = 0, gs = root_group<ANY>();
+  int depth = 0;
   for (;;) {
-    if (cur >= 0) {
-      const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
-      int32_t e[4];
-      const uint32_t hits = node4_step<1u>(nd[0], nd[1], nd[2], nd[3], rb, tmin, h.t, e[0], e[1], e[2], e[3]);
-      for (uint32_t k = hits; k-- > 1u;) stack[sp++] = e[k];  // farthest first
-      if (hits != 0u) {
-        cur = e[0];
-        continue;
-      }
-    } else {
-      const uint32_t cc = (uint32_t)~cur;
-      const uint32_t first = cc >> 2, count = (cc & 3u) + 1u;
-      for (uint32_t k = 0; k < count; ++k) {
-        const q4* p = tris + 3ll * (first + k);
-        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
-        float t, u, v;
-        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u, v)) {
-          if (ANY) {
-            h.t = t;
-            h.slot = (int32_t)(first + k);
-            return true;
-          }
-          const uint32_t id = f2u(p0.w);
-          if (t < h.t || (t == h.t && id < best_id)) {
-            h.t = t;
-            h.u = u;
-            h.v = v;
-            h.slot = (int32_t)(first + k);
-            best_id = id;
-            aux = f2u(p1.w);
-          }
+    if (group_empty<ANY>(gs)) {
+      if (depth == 0) break;
+      --depth;
+#if GSP_WIDE == 8
+      gs = stk.pop();
+      gb = stk.pop();
+#else
+      const uint32_t e = stk.pop();
+      gb = e >> 9;
+      gs = e & 511u;
+#endif
+      continue;
+    }
+    const q4* nd = (const q4*)((const char*)nodes + group_next<ANY>(gb, gs, rb, tab));
+    q4 n[kNodeQuads];
+    for (uint32_t k = 0; k < kNodeQuads; ++k) n[k] = nd[k];
+    uint32_t ngb, ngs, tb, tm;
+    node_step<ANY>(n, rb, tmin, h.t, tab, ngb, ngs, tb, tm);
+    while (!tris_empty(tm)) {
+      const uint32_t slot = tris_next(tb, tm);
+      const q4* p = tris + 3ll * slot;
+      const q4 p0 = p[0], p1 = p[1], p2 = p[2];
+      float t, u, v;
+      if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), o, rs, tmin, tmax, t, u, v)) {
+        if (ANY) {
+          h.t = t;
+          h.slot = (int32_t)slot;
+          return true;
+        }
+        const uint32_t id = f2u(p0.w);
+        if (t < h.t || (t == h.t && id < best_id)) {
+          h.t = t;
+          h.u = u;
+          h.v = v;
+          h.slot = (int32_t)slot;
+          best_id = id;
+          aux = id & 7u;
         }
       }
     }
-    if (sp == 0) break;
-    cur = stack[--sp];
+    if (!group_empty<ANY>(ngs)) {
+      if (!group_empty<ANY>(gs)) {
+#if GSP_WIDE == 8
+        stk.push(gb);
+        stk.push(gs);
+#else
+        stk.push((gb << 9) | gs);
+#endif
+        ++depth;
+      }
+      gb = ngb;
+      gs = ngs;
+    }
   }
   return h.slot >= 0;
 }

@@ -9,17 +9,18 @@
 // lanes in a leaf wait for lanes in inner nodes.  The kernel is VALU-issue bound, so the
 // lever is lanes doing useful work per issued instruction.  Hence a flat, wave-uniform
 // state machine (every decision is a ballot + scalar branch, no divergent loops):
-//   * each lane owns a ray state {cur node, postponed leaf, stack}; per loop iteration the
-//     wave runs a few node steps for all lanes that sit on an inner node, and a leaf step
-//     (ONE triangle test per lane; longer leaves stay pending) only when kLeafBatch lanes have
-//     a leaf pending or nothing else can run -- triangle tests execute with many lanes enabled
+//   * each lane owns a ray state {node group, up to two postponed triangle groups, stack}; per loop iteration the
+//     wave runs a few node steps for all lanes that have a child node to visit, and a leaf step
+//     (ONE triangle test per lane; longer groups stay pending) only when kLeafBatch lanes have
+//     triangles pending or nothing else can run -- triangle tests execute with many lanes enabled
 //     (leaf postponing after Aila & Laine 2009, re-tuned for 64 lanes);
 //   * lanes whose ray finished commit their result and are refilled from a wave-local pool
 //     as soon as kRefillLanes of them are idle; the pool takes 256-ray chunks from 8
 //     hand-out counters (one per blockIdx % 8 label = per XCD under round-robin placement;
 //     speed only), i.e. one atomic per 256 rays on a line no other XCD touches;
-//   * per-lane stack in LDS ([level][lane]: conflict-free) with an HBM spill region behind
-//     it; a sentinel at the bottom removes the empty-stack test.
+//   * per-lane stack of node groups in LDS ([level][lane]: conflict-free) with an HBM spill region behind
+//     it; a node step pushes at most ONE entry (the rest of the group it descends from: r03, pt_trace.h), so the
+//     stack is as deep as the tree, not three times that; a sentinel at the bottom removes the empty-stack test.
 #pragma once
 #include "pt_trace.h"
 
@@ -27,12 +28,13 @@ namespace gsp {
 
 constexpr int kTraceBlock = 256;
 #ifndef GSP_LDS_LEVELS
-#define GSP_LDS_LEVELS 22
+#define GSP_LDS_LEVELS (GSP_WIDE == 8 ? 10 : 20)
 #endif
 #ifndef GSP_TRACE_WAVES
 #define GSP_TRACE_WAVES 7  // waves per SIMD the register allocator must allow (<= 72 VGPRs; 8 would spill)
 #endif
-constexpr int kLdsStackDepth = GSP_LDS_LEVELS;  // LDS levels per lane (1 KB per level per block)
+constexpr int kStackWords = GSP_WIDE == 8 ? 2 : 1;   // 32-bit words per stack entry (one node group)
+constexpr int kLdsStackDepth = GSP_LDS_LEVELS;       // LDS levels (entries) per lane
 #ifndef GSP_REFILL_LANES
 #define GSP_REFILL_LANES 16
 #endif
@@ -48,6 +50,14 @@ constexpr int kLdsStackDepth = GSP_LDS_LEVELS;  // LDS levels per lane (1 KB per
 #ifndef GSP_BATCH_COMMIT
 #define GSP_BATCH_COMMIT (ANY ? 32 : 24)
 #endif
+// triangle groups a lane may hold while it keeps taking node steps (0: it waits for the leaf step as soon as it has
+// triangles to test; 1: it descends on until a second group arrives)
+#ifndef GSP_POSTPONE_ANY
+#define GSP_POSTPONE_ANY 1
+#endif
+#ifndef GSP_POSTPONE_CLOSEST
+#define GSP_POSTPONE_CLOSEST 1
+#endif
 constexpr int kRefillLanes = GSP_REFILL_LANES;  // idle lanes that trigger a refill
 constexpr int kLeafBatch = GSP_LEAF_BATCH;      // pending leaves that trigger a leaf step
 #ifndef GSP_CHUNK_LARGE
@@ -57,71 +67,98 @@ constexpr uint32_t kChunkLarge = GSP_CHUNK_LARGE;  // rays per hand-out (big que
 constexpr uint32_t kChunkSmall = 64;        // ... when the queue is small: one ray per lane, all waves busy
 constexpr int kWorkShards = 8;
 constexpr int kWorkStride = 32;             // counters sit on separate 128-B lines
-constexpr int32_t kSentinel = 0x7fffffff;
 
 // Explicit address spaces: a generic pointer that may be LDS or HBM compiles to flat_load /
 // flat_store on every push and pop; with typed pointers the LDS levels are ds_read/ds_write.
-typedef __attribute__((address_space(3))) int32_t lds_i32;
-typedef __attribute__((address_space(1))) int32_t glb_i32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+
+// the step table (pt_trace.h) in LDS
+struct LdsStepTable {
+  const __attribute__((address_space(3))) char* base;
+  __device__ __forceinline__ uint32_t operator()(uint32_t byte_off) const {
+#if GSP_WIDE == 8
+    return *(const lds_u8*)(base + byte_off);
+#else
+    return *(const lds_u16*)(base + byte_off);
+#endif
+  }
+};
+__device__ __forceinline__ void stage_step_table(uint32_t* lds_words, uint32_t tid, uint32_t threads) {
+  const uint32_t* src = (const uint32_t*)&kStepTable;
+  for (uint32_t i = tid; i < kStepTableBytes / 4; i += threads) lds_words[i] = src[i];
+}
 
 struct WaveStack {
-  lds_i32* lds;    // &lds_stack[threadIdx.x]; level L of this lane lives at lds + L * kTraceBlock
-  glb_i32* spill;  // &spill[global thread], stride spill_stride
+  lds_u32* lds;    // &lds_stack[threadIdx.x]; word L of this lane lives at lds + L * kTraceBlock
+  glb_u32* spill;  // &spill[global thread], stride spill_stride
   uint32_t spill_stride;
-  // BYTE offset of the next free level from `lds` (level * kLevelBytes): a push or pop is one add and a
+  // BYTE offset of the next free word from `lds` (word * kWordBytes): a push or pop is one add and a
   // ds access with an immediate offset -- no per-access shifts (v_lshl_or_b32 issues at half the rate
   // of v_add_u32 on this chip, profiles/r01_h_microbench/valu_rate.txt)
   uint32_t sp;
-  static constexpr uint32_t kLevelBytes = 4u * kTraceBlock;
-  static constexpr uint32_t kLdsBytes = (uint32_t)kLdsStackDepth * kLevelBytes;
-  __device__ __forceinline__ lds_i32* at(uint32_t off) const {
-    return (lds_i32*)((__attribute__((address_space(3))) char*)lds + off);
+  static constexpr uint32_t kWordBytes = 4u * kTraceBlock;
+  static constexpr uint32_t kEntryBytes = kWordBytes * kStackWords;
+  static constexpr uint32_t kLdsBytes = (uint32_t)kLdsStackDepth * kEntryBytes;
+  __device__ __forceinline__ lds_u32* at(uint32_t off) const {
+    return (lds_u32*)((__attribute__((address_space(3))) char*)lds + off);
   }
-  // Slow, per-lane form: LDS level or HBM spill level.
-  __device__ __forceinline__ void store_at(uint32_t off, int32_t v) {
+  // Slow, per-lane form: LDS word or HBM spill word.
+  __device__ __forceinline__ void store_at(uint32_t off, uint32_t v) {
     if (off < kLdsBytes) *at(off) = v;
-    else spill[(size_t)((off - kLdsBytes) / kLevelBytes) * spill_stride] = v;
+    else spill[(size_t)((off - kLdsBytes) / kWordBytes) * spill_stride] = v;
   }
-  __device__ __forceinline__ int32_t load_at(uint32_t off) {
-    int32_t v;
+  __device__ __forceinline__ uint32_t load_at(uint32_t off) {
+    uint32_t v;
     if (off < kLdsBytes) v = *at(off);
-    else v = spill[(size_t)((off - kLdsBytes) / kLevelBytes) * spill_stride];
+    else v = spill[(size_t)((off - kLdsBytes) / kWordBytes) * spill_stride];
     return v;
   }
-  __device__ __forceinline__ void push(int32_t v) {
-    store_at(sp, v);
-    sp += kLevelBytes;
-  }
   // Hot path: the LDS-or-spill decision is taken once per wave (a ballot and a scalar branch);
-  // almost always every lane is inside the LDS levels and the access is a bare ds_read/ds_write.
-  __device__ __forceinline__ int32_t pop() {
-    sp -= kLevelBytes;
-    if (__builtin_expect(__ballot(sp >= kLdsBytes) == 0, 1)) return *at(sp);
-    return load_at(sp);
-  }
-  // Pushes the m = mb / kLevelBytes (0..3) entries e1 (nearest of the three) .. e3 (farthest), farthest
-  // first.  Hot path: three stores at FIXED offsets from the old top -- which value goes where depends on m,
-  // and whatever lands above the new top is never read.
-  __device__ __forceinline__ void push_sorted(uint32_t mb, int32_t e1, int32_t e2, int32_t e3) {
-    if (__builtin_expect(__ballot(sp + 3u * kLevelBytes > kLdsBytes) == 0, 1)) {
-      const int32_t w0 = mb == 3u * kLevelBytes ? e3 : (mb == 2u * kLevelBytes ? e2 : e1);
-      const int32_t w1 = mb == 3u * kLevelBytes ? e2 : e1;
-      lds_i32* p = at(sp);
-      p[0] = w0;
-      p[kTraceBlock] = w1;
-      p[2 * kTraceBlock] = e1;
+  // almost always every lane is inside the LDS levels and the access is a bare ds_read / ds_write.
+  __device__ __forceinline__ void push_group(uint32_t gb, uint32_t gs) {
+    if (__builtin_expect(__ballot(sp + kEntryBytes > kLdsBytes) == 0, 1)) {
+#if GSP_WIDE == 8
+      at(sp)[0] = gb;
+      at(sp)[kTraceBlock] = gs;
+#else
+      at(sp)[0] = (gb << 9) | gs;
+#endif
     } else {
-      if (mb > 2u * kLevelBytes) store_at(sp + mb - 3u * kLevelBytes, e3);
-      if (mb > kLevelBytes) store_at(sp + mb - 2u * kLevelBytes, e2);
-      if (mb > 0u) store_at(sp + mb - kLevelBytes, e1);
+#if GSP_WIDE == 8
+      store_at(sp, gb);
+      store_at(sp + kWordBytes, gs);
+#else
+      store_at(sp, (gb << 9) | gs);
+#endif
     }
-    sp += mb;
+    sp += kEntryBytes;
+  }
+  __device__ __forceinline__ void pop_group(uint32_t& gb, uint32_t& gs) {
+    sp -= kEntryBytes;
+#if GSP_WIDE == 8
+    if (__builtin_expect(__ballot(sp + kEntryBytes > kLdsBytes) == 0, 1)) {
+      gb = at(sp)[0];
+      gs = at(sp)[kTraceBlock];
+    } else {
+      gb = load_at(sp);
+      gs = load_at(sp + kWordBytes);
+    }
+#else
+    uint32_t e;
+    if (__builtin_expect(__ballot(sp >= kLdsBytes) == 0, 1)) e = at(sp)[0];
+    else e = load_at(sp);
+    gb = e >> 9;
+    gs = e & 511u;
+#endif
   }
 };
 
 #ifdef GSP_WAVE_PROFILE
 // [0] node steps (per wave) [1] lanes enabled in them [2] leaf steps [3] lanes enabled [4] loop passes
-// [5] refill passes [6] lanes refilled [7] lanes idle (no ray) summed over node steps [8] lanes stalled (leaf pending, no node) over node steps
+// [5] refill passes [6] lanes refilled [7] lanes idle (no ray) summed over node steps [8] lanes stalled (triangles pending, no node step possible) over node steps
 // [9] node steps after the hand-out ran dry [10] lanes enabled in them
 __device__ unsigned long long g_wave_profile[16];
 #endif
@@ -146,29 +183,30 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // IO contract:
 //   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const;
 //   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux) const;   // h.slot < 0: miss / unoccluded;
-//                                                  aux = p1.w of the accepted triangle (BSDF type)
+//                                                  aux = BSDF type of the accepted triangle
+//   static constexpr float kTmin, kTmax: >= 0 = every ray of this source has that bound (load() returns the same
+//                                                  value): the kernel keeps it out of the registers
+// Rays [first, n) of the queue are traced (first > 0: the leading entries carry memoised results, pt_render.hip).
 template <bool ANY, bool STATS, class IO>
 __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
-                                                        int32_t root, const uint32_t* __restrict__ n_ptr,
-                                                        uint32_t n_imm, uint32_t chunk, IO io,
+                                                        const uint32_t* __restrict__ n_ptr,
+                                                        uint32_t n_imm, uint32_t first, uint32_t chunk, IO io,
                                                         uint32_t* __restrict__ work,
-                                                        int32_t* __restrict__ spill, uint32_t spill_stride,
+                                                        uint32_t* __restrict__ spill, uint32_t spill_stride,
                                                         TraceStatsOut so) {
-  __shared__ int32_t lds_stack[kLdsStackDepth * kTraceBlock];
-#if GSP_LDS_TOP && !defined(GSP_TOP_GLOBAL_ONLY)
-  __shared__ q4 lds_top[4 * kTopNodes];
-  for (uint32_t i = threadIdx.x; i < 4 * kTopNodes; i += kTraceBlock) lds_top[i] = nodes[i];
+  __shared__ uint32_t lds_stack[kLdsStackDepth * kStackWords * kTraceBlock];
+  __shared__ uint32_t lds_table[kStepTableBytes / 4];
+  stage_step_table(lds_table, threadIdx.x, kTraceBlock);
   __syncthreads();
-#endif
+  const LdsStepTable tab{(const __attribute__((address_space(3))) char*)lds_table};
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
   const uint32_t lane = threadIdx.x & 63;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t shard = blockIdx.x % kWorkShards;
   uint32_t* my_work = work + shard * kWorkStride;
 
   WaveStack stk;
-  stk.lds = (lds_i32*)lds_stack + threadIdx.x;
-  stk.spill = (glb_i32*)spill + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
+  stk.lds = (lds_u32*)lds_stack + threadIdx.x;
+  stk.spill = (glb_u32*)spill + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
   stk.spill_stride = spill_stride;
   stk.sp = 0;
 
@@ -176,14 +214,17 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
 
-  // per-lane ray state
-  int32_t cur = kSentinel, leaf = 0;
-  uint32_t ri = 0xffffffffu, best_id = 0xffffffffu, best_aux = 0;
+  // per-lane ray state: the node group being worked on {gb, gs}, the triangle group(s) waiting for a leaf step
+  // {tb, tm} (+ {tb2, tm2}: the lane stalls when both are taken)
+  uint32_t gb = 0, gs = no_group<ANY>(), tb = 0, tm = 0, tb2 = 0, tm2 = 0;
+  uint32_t ri = 0xffffffffu, best_id = 0xffffffffu;  // best_id: p0.w of the closest hit so far (id << 3 | BSDF type)
   RayBox rb = make_raybox(mk3(0, 0, 0), mk3(1, 1, 1));
   RayShear rs;
   rs.kx = rs.ky = rs.kz = 0;
   rs.Sx = rs.Sy = rs.Sz = 0.0f;
-  float tmin = 0.0f, tmax = 0.0f;
+  float tmin_v = 0.0f, tmax_v = 0.0f;
+#define tmin (IO::kTmin >= 0.0f ? IO::kTmin : tmin_v)
+#define tmax (IO::kTmax >= 0.0f ? IO::kTmax : tmax_v)
   HitRec h;
   h.t = 0.0f;
   h.u = h.v = 0.0f;
@@ -202,13 +243,13 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
     // issued for the whole wave, so it waits until enough lanes are out of work (A/B: any-hit kernel -13 % at 32,
     // closest-hit -1.6 % at 24; 40+ starves the wave)
     {
-      const bool pending = ri != 0xffffffffu && cur == kSentinel && leaf == 0;
+      const bool pending = ri != 0xffffffffu && group_empty<ANY>(gs) && tris_empty(tm);
       const uint64_t pend_m = __ballot(pending);
       if (pend_m) {
         const uint64_t out_m = pend_m | __ballot(ri == 0xffffffffu);
         if (wave_count(out_m) >= GSP_BATCH_COMMIT || out_m == ~0ull) {
           if (pending) {
-            io.store(ri, h, best_aux);
+            io.store(ri, h, best_id & 7u);
             ri = 0xffffffffu;
           }
         }
@@ -226,7 +267,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           uint32_t k = 0;
           if (lane == 0) k = atomicAdd(my_work, 1u);
           k = __shfl(k, 0);
-          const uint64_t start = ((uint64_t)k * kWorkShards + shard) * chunk;
+          const uint64_t start = ((uint64_t)k * kWorkShards + shard) * chunk + first;
           if (start >= n) {
             exhausted = true;
             break;
@@ -234,13 +275,14 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           pool_next = (uint32_t)start;
           pool_end = (uint32_t)(start + chunk < n ? start + chunk : n);
         }
-        const uint32_t rank = (uint32_t)__popcll(idle_m & lt_mask);
+        // set bits of idle_m below this lane (v_mbcnt: no per-lane mask register)
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
         const uint32_t avail = pool_end - pool_next;
         if (((idle_m >> lane) & 1ull) && rank < avail) {
           ri = pool_next + rank;
           f3 d;
           f3 o;
-          io.load(ri, o, d, tmin, tmax);
+          io.load(ri, o, d, tmin_v, tmax_v);
           rb = make_raybox(o, d);
           rs = make_shear(d);
           rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
@@ -249,14 +291,10 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           h.slot = -1;
           best_id = 0xffffffffu;
           stk.sp = 0;
-          stk.push(kSentinel);
-          cur = root;
-          leaf = 0;
-          if (cur < 0) {  // the root itself is a leaf (single-triangle or empty scene)
-            leaf = cur;
-            cur = kSentinel;
-            stk.sp = 0;
-          }
+          stk.push_group(0u, no_group<ANY>());  // sentinel: popping it leaves the lane without node work
+          gb = 0u;
+          gs = root_group<ANY>();
+          tm = tm2 = 0u;
           if (STATS) ++c_rays;
         }
         const uint32_t want = (uint32_t)__popcll(idle_m);
@@ -265,15 +303,17 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
       }
     }
     // ---- what can run? -------------------------------------------------------------------------
-    const bool on_node = (uint32_t)cur < (uint32_t)kSentinel;
+    // a lane takes a node step when it has a child node to visit and room for the triangle group the step may produce
+    constexpr bool kPostpone = (ANY ? GSP_POSTPONE_ANY : GSP_POSTPONE_CLOSEST) != 0;
+    const bool on_node = !group_empty<ANY>(gs) && tris_empty(kPostpone ? tm2 : tm);
     const uint64_t node_m = __ballot(on_node);
-    const uint64_t leaf_m = __ballot(leaf < 0);
+    const uint64_t leaf_m = __ballot(!tris_empty(tm));
     if ((node_m | leaf_m) == 0) {
       if (exhausted || idle_m == 0) break;  // nothing in flight and nothing left to hand out
       continue;                             // (all lanes idle: the refill above runs next)
     }
-    // ---- one inner-node step for every lane that sits on an inner node ---------------------------
-    // closest hit: lanes that cannot advance without a leaf step (leaf pending, no inner node to work on)
+    // ---- one node step for every lane that can take one ------------------------------------------
+    // closest hit: lanes that cannot advance without a leaf step (triangles pending, no node step possible)
     // trigger it early; lanes that still descend can wait for a fuller batch
     const uint64_t stall_m = leaf_m & ~node_m;
     const bool leaf_step = (!ANY && wave_count(stall_m) >= GSP_STALL_BATCH) ||
@@ -288,9 +328,9 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
 #define GSP_REP_LANES (ANY ? 24 : 32)
 #endif
       // up to GSP_NODE_REPS node steps per pass through the bookkeeping above, as long as most
-      // lanes are still on inner nodes
+      // lanes can still take one
       for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
-        const bool on = (uint32_t)cur < (uint32_t)kSentinel;
+        const bool on = !group_empty<ANY>(gs) && tris_empty(kPostpone ? tm2 : tm);
         if (rep > 0 && wave_count(__ballot(on)) < GSP_REP_LANES) break;
 #ifdef GSP_WAVE_PROFILE
         ++wp[0];
@@ -302,50 +342,47 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           wp[10] += __popcll(__ballot(on));
         }
 #endif
-      if (on) {
-          // compressed 4-wide node: 4 quads (pt_trace.h, built by pt_bvh.hip through encode_node4)
-          // (`cur` is the node's byte offset: 32-bit offset + uniform base, no 64-bit address arithmetic)
-#if GSP_LDS_TOP && !defined(GSP_TOP_GLOBAL_ONLY)
-          q4 n0, n1, n2, n3;
-          if ((uint32_t)cur < kTopNodes * 64u) {  // top of the tree: the block's LDS copy
-            const q4* nd = (const q4*)((const char*)lds_top + (uint32_t)cur);
-            n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-          } else {
-            const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
-            n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-          }
-#else
-          const q4* nd = (const q4*)((const char*)nodes + (uint32_t)cur);
-          const q4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-#endif
+        if (on) {
+          // the nearest child of the current group (32-bit offset + uniform base, no 64-bit address arithmetic)
+          const q4* nd = (const q4*)((const char*)nodes + group_next<ANY>(gb, gs, rb, tab));
+          q4 nq[kNodeQuads];
+#pragma unroll
+          for (uint32_t k = 0; k < kNodeQuads; ++k) nq[k] = nd[k];
           if (STATS) ++c_nodes;
-          constexpr uint32_t L = WaveStack::kLevelBytes;  // hit count kept in stack-offset units
-          int32_t e0, e1, e2, e3;
-          const uint32_t nb = node4_step<L>(n0, n1, n2, n3, rb, tmin, h.t, e0, e1, e2, e3);
-          stk.push_sorted(nb > 0u ? nb - L : 0u, e1, e2, e3);
-          if (nb > 0u) cur = e0;
-          else cur = stk.pop();
-          if (cur < 0 && leaf == 0) {  // first leaf: postpone it and keep descending
-            leaf = cur;
-            cur = stk.pop();
+          uint32_t ngb, ngs, ntb, ntm;
+          node_step<ANY>(nq, rb, tmin, h.t, tab, ngb, ngs, ntb, ntm);
+          if (!group_empty<ANY>(ngs)) {  // descend: the rest of the current group waits on the stack
+            if (!group_empty<ANY>(gs)) stk.push_group(gb, gs);
+            gb = ngb;
+            gs = ngs;
+          } else if (group_empty<ANY>(gs)) {
+            stk.pop_group(gb, gs);
+          }
+          if (!tris_empty(ntm)) {  // hit leaf children: postponed to the next leaf step
+            if (tris_empty(tm)) {
+              tb = ntb;
+              tm = ntm;
+            } else {
+              tb2 = ntb;
+              tm2 = ntm;
+            }
           }
         }
       }
       continue;
     }
-    // ---- leaf step: triangle tests for every lane with a postponed leaf -----------------------------
+    // ---- leaf step: one triangle test for every lane with a pending triangle group ---------------------
 #ifdef GSP_WAVE_PROFILE
     ++wp[2];
-    wp[3] += __popcll(__ballot(leaf < 0));
+    wp[3] += __popcll(__ballot(!tris_empty(tm)));
 #endif
-    // one triangle per lane per step: a leaf with more triangles stays pending (first + 1, count - 1), so
-    // short leaves do not idle while long ones finish and leaves that arrive in between join the next step
-    if (leaf < 0) {
-      const uint32_t c = (uint32_t)~leaf;
-      const uint32_t first = c >> 2;
+    // one triangle per lane per step: a group with more triangles stays pending, so short groups do not idle
+    // while long ones finish and groups that arrive in between join the next step
+    if (!tris_empty(tm)) {
+      const uint32_t slot = tris_next(tb, tm);
       bool stop = false;
       {
-        const q4* p = tris + 3ll * first;
+        const q4* p = tris + 3ll * slot;
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
         if (STATS) ++c_tris;
         float t, u, v;
@@ -353,7 +390,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
                           v)) {
           if (ANY) {
             h.t = t;
-            h.slot = (int32_t)first;
+            h.slot = (int32_t)slot;
             stop = true;
           } else {
             const uint32_t id = __float_as_uint(p0.w);
@@ -361,26 +398,24 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
               h.t = t;
               h.u = u;
               h.v = v;
-              h.slot = (int32_t)first;
+              h.slot = (int32_t)slot;
               best_id = id;
-              best_aux = __float_as_uint(p1.w);
             }
           }
         }
       }
-      if ((c & 3u) != 0u && !(ANY && stop)) {
-        leaf = ~(int32_t)(c + 3u);  // first + 1 (bits 2..), count - 1 (bits 0..1): +4 - 1
-      } else {
-        leaf = 0;
-        if (ANY && stop) {
-          cur = kSentinel;
-        } else if (cur < 0) {  // a second leaf was waiting in `cur`
-          leaf = cur;
-          cur = stk.pop();
-        }
+      if (ANY && stop) {  // the ray is done
+        gs = no_group<ANY>();
+        tm = tm2 = 0u;
+      } else if (tris_empty(tm)) {  // the second group, if any, moves up
+        tb = tb2;
+        tm = tm2;
+        tm2 = 0u;
       }
     }
   }
+#undef tmin
+#undef tmax
 #ifdef GSP_WAVE_PROFILE
   if (lane == 0 && !ANY)
     for (int k = 0; k < 12; ++k) atomicAdd(&g_wave_profile[k], wp[k]);

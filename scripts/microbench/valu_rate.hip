@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -13,9 +14,9 @@
 
 #define DEFINE_KERNEL(NAME, ASM)                                                                    \
   __global__ void __launch_bounds__(1024) NAME(int loops_in, unsigned long long* out, float* sink) {    \
-    __shared__ float lds_buf[4096]; int loops = loops_in; if (loops == 123456789) lds_buf[threadIdx.x] = 1.0f; float a = threadIdx.x * 1.0f, b = 1.0001f, c = 0.5f;                                            \
+    __shared__ float lds_buf[8192]; int loops = loops_in; if (loops == 123456789) lds_buf[threadIdx.x] = 1.0f; float a = threadIdx.x * 1.0f, b = 1.0001f, c = 0.5f;                                            \
     float r0 = a, r1 = a + 1, r2 = a + 2, r3 = a + 3; \
-    if (loops < 0) { r0 = __int_as_float((int)(threadIdx.x * 4)); loops = -loops; }                                               \
+    if (loops < -(1 << 24)) { r0 = __int_as_float((int)(threadIdx.x * 8)); loops = -loops - (1 << 24); } else if (loops < 0) { r0 = __int_as_float((int)(threadIdx.x * 4)); loops = -loops; }                                               \
     unsigned long long t0 = __builtin_readcyclecounter();                                           \
     for (int i = 0; i < loops; ++i) {                                                               \
       asm volatile(REP8(ASM) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(b), "v"(c) : "vcc", "scc", "s20", "s21", "s22", "s23", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107"); \
@@ -83,6 +84,26 @@ DEFINE_KERNEL(k_cnd_vccw, "v_cmp_lt_u32_e32 vcc, %0, %4\n v_cndmask_b32_e32 %1, 
 DEFINE_KERNEL(k_dswrite, "ds_write_b32 %0, %4\n ds_write_b32 %0, %5 offset:1024\n ds_write_b32 %0, %4 offset:2048\n ds_write_b32 %0, %5 offset:3072\n")
 DEFINE_KERNEL(k_dsread, "ds_read_b32 v100, %0\n ds_read_b32 v101, %0 offset:1024\n ds_read_b32 v102, %0 offset:2048\n ds_read_b32 v103, %0 offset:3072\n s_waitcnt lgkmcnt(0)\n")
 
+// r03 additions: candidates for an 8-wide / octant-ordered node step
+DEFINE_KERNEL(k_bitop3, "v_bitop3_b32 %0, %0, %4, %5 bitop3:0x20\n v_bitop3_b32 %1, %1, %4, %5 bitop3:0x20\n v_bitop3_b32 %2, %2, %4, %5 bitop3:0x20\n v_bitop3_b32 %3, %3, %4, %5 bitop3:0x20\n")
+K4(k_bcnt, "v_bcnt_u32_b32")
+K4_1(k_ffbl, "v_ffbl_b32_e32")
+K4(k_bfm, "v_bfm_b32")
+K4_3(k_addlshl, "v_add_lshl_u32")
+K4_3(k_fmamix, "v_fma_mix_f32")
+DEFINE_KERNEL(k_fmamix_hi, "v_fma_mix_f32 %0, %0, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %1, %4, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %2, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %3, %4, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n")
+DEFINE_KERNEL(k_cvtpkfp8, "v_cvt_pk_f32_fp8 v[100:101], %0\n v_cvt_pk_f32_fp8 v[102:103], %1\n v_cvt_pk_f32_fp8 v[104:105], %2\n v_cvt_pk_f32_fp8 v[106:107], %3\n")
+K4_3(k_pkfmaf16, "v_pk_fma_f16")
+K4(k_pkmaxf16, "v_pk_max_f16")
+K4(k_pkminf16, "v_pk_min_f16")
+K4(k_mullo, "v_mul_lo_u32")
+K4_3(k_dot2, "v_dot2_f32_f16")
+K4_1(k_not, "v_not_b32_e32")
+DEFINE_KERNEL(k_dsread_u8, "ds_read_u8 v100, %0\n ds_read_u8 v101, %0 offset:1024\n ds_read_u8 v102, %0 offset:2048\n ds_read_u8 v103, %0 offset:3072\n s_waitcnt lgkmcnt(0)\n")
+DEFINE_KERNEL(k_dsread_u16, "ds_read_u16 v100, %0\n ds_read_u16 v101, %0 offset:1024\n ds_read_u16 v102, %0 offset:2048\n ds_read_u16 v103, %0 offset:3072\n s_waitcnt lgkmcnt(0)\n")
+DEFINE_KERNEL(k_dswrite_b64, "ds_write_b64 %0, v[100:101]\n ds_write_b64 %0, v[102:103] offset:2048\n ds_write_b64 %0, v[100:101] offset:4096\n ds_write_b64 %0, v[102:103] offset:6144\n")
+DEFINE_KERNEL(k_dsread_b64, "ds_read_b64 v[100:101], %0\n ds_read_b64 v[102:103], %0 offset:2048\n ds_read_b64 v[104:105], %0 offset:4096\n ds_read_b64 v[106:107], %0 offset:6144\n s_waitcnt lgkmcnt(0)\n")
+
 typedef void (*kern_t)(int, unsigned long long*, float*);
 struct Entry { const char* name; kern_t k; };
 
@@ -99,7 +120,12 @@ int main() {
                       {"v_min3_u32", k_min3u}, {"v_alignbit_b32", k_alignbit}, {"v_cvt_f32_u32_e32", k_cvtu32}, {"v_cvt_f32_ubyte0_e32", k_cvtub0},
                       {"v_rcp_f32_e32", k_rcp}, {"v_cvt_f32_f16_e32", k_cvtf16}, {"v_cvt_f32_u32_sdwa BYTE_n", k_cvt_sdwa}, {"v_mul_f32_sdwa", k_mul_sdwa},
                       {"v_fmac_f32_e32", k_fmac}, {"v_fmamk_f32", k_fmamk}, {"v_cmp_le_f32_e32 -> vcc", k_cmp_f_e32}, {"cmp_e32 + cndmask_e32 pairs", k_cnd_vccw},
-                      {"ds_write_b32 (lane-private)", k_dswrite}, {"ds_read_b32 (lane-private)", k_dsread}};
+                      {"ds_write_b32 (lane-private)", k_dswrite}, {"ds_read_b32 (lane-private)", k_dsread},
+                      {"v_bitop3_b32", k_bitop3}, {"v_bcnt_u32_b32", k_bcnt}, {"v_ffbl_b32", k_ffbl}, {"v_bfm_b32", k_bfm}, {"v_add_lshl_u32", k_addlshl},
+                      {"v_fma_mix_f32 (f32 srcs)", k_fmamix}, {"v_fma_mix_f32 (f16 src0 hi/lo)", k_fmamix_hi}, {"v_cvt_pk_f32_fp8", k_cvtpkfp8},
+                      {"v_pk_fma_f16", k_pkfmaf16}, {"v_pk_max_f16", k_pkmaxf16}, {"v_pk_min_f16", k_pkminf16}, {"v_mul_lo_u32", k_mullo},
+                      {"v_dot2_f32_f16", k_dot2}, {"v_not_b32", k_not}, {"ds_read_u8 (lane-private)", k_dsread_u8}, {"ds_read_u16 (lane-private)", k_dsread_u16},
+                      {"ds_write_b64 (lane-private)", k_dswrite_b64}, {"ds_read_b64 (lane-private)", k_dsread_b64}};
   const int loops = 20000;
   unsigned long long* out; float* sink;
   CHECK(hipMalloc(&out, 1 << 20)); CHECK(hipMalloc(&sink, 4));
@@ -113,9 +139,9 @@ int main() {
       const int threads = w <= 4 ? 256 * w : 1024;
       const int blocks = w <= 4 ? 256 : 512;
       hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, (e.name[0] == 'd' ? -loops : loops), out, sink);
+      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, (e.name[0] == 'd' ? (strstr(e.name, "b64") ? -loops - (1 << 24) : -loops) : loops), out, sink);
       CHECK(hipEventRecord(e0));
-      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, (e.name[0] == 'd' ? -loops : loops), out, sink);
+      hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, (e.name[0] == 'd' ? (strstr(e.name, "b64") ? -loops - (1 << 24) : -loops) : loops), out, sink);
       CHECK(hipEventRecord(e1));
       CHECK(hipDeviceSynchronize());
       float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));

@@ -8,10 +8,10 @@
 // and is never imported by the gpuspectral_amd package, bench.py's timed path
 // or anything shipped: the product renders on the GPU only.
 //
-// The BVH here is a plain median-split 4-wide tree written with the product's own node
-// encoder (encode_node4, pt_trace.h) and walked with the product's own per-ray traversal
-// (trace_ray4: the node step node4_step + intersect_tri that k_trace and k_finish run);
-// closest-hit results do not depend on the BVH topology (pt_trace.h).
+// The BVH here is a plain median-split wide tree (kWide children per node, contiguous children) written with the
+// product's own node encoder (encode_node_w4 / _w8, pt_trace.h) and walked with the product's own per-ray
+// traversal (trace_ray: the node step node_step + intersect_tri that k_trace and k_finish run, with the product's
+// step table); closest-hit results do not depend on the BVH topology (pt_trace.h).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -55,7 +55,6 @@ struct Emu {
   std::vector<uint32_t> texels;
   bool textured = false;
   std::vector<float> lo, hi;  // per slot padded boxes
-  int32_t root = 0;
   SceneView view;
 
   void bake() {
@@ -76,7 +75,7 @@ struct Emu {
         f3 n2 = xform_dir(T, mk3(Nn[6], Nn[7], Nn[8]));
         f3 e1 = p1 - p0, e2 = p2 - p0;
         f3 N = normalize(cross(e1, e2));
-        gi.push_back(mkq(p0.x, p0.y, p0.z, u2f(g)));
+        gi.push_back(mkq(p0.x, p0.y, p0.z, u2f((g << 3) | ((I.bsdf >> 16) & 7u))));  // as k_bake (pt_bvh.hip)
         gi.push_back(mkq(p1.x, p1.y, p1.z, 0));
         gi.push_back(mkq(p2.x, p2.y, p2.z, 0));
         gs.push_back(mkq(N.x, N.y, N.z, u2f(pack_material(I.bsdf, I.twofaced))));
@@ -104,12 +103,10 @@ struct Emu {
     const uint32_t n = g;
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    // median split into a 4-wide tree, leaves of 1-2 triangles; nodes written by the product's encoder
+    // median split into a kWide-wide tree with one triangle per leaf child; the nodes are numbered breadth-first so
+    // that the inner children of a node are consecutive nodes and its leaf children consecutive triangle slots
+    // (pt_trace.h), and written by the product's encoder
     nodes.clear();
-    struct Rec {
-      int32_t code;
-      float lo[3], hi[3];
-    };
     std::vector<uint32_t> slots;  // final slot order
     auto split = [&](uint32_t first, uint32_t count) -> uint32_t {  // returns the size of the left part
       float cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
@@ -129,83 +126,91 @@ struct Emu {
                        });
       return mid - first;
     };
-    std::function<Rec(uint32_t, uint32_t)> build = [&](uint32_t first, uint32_t count) -> Rec {
-      Rec r;
-      if (count <= 2) {
-        uint32_t slot = (uint32_t)slots.size();
+    auto range_box = [&](uint32_t first, uint32_t count, WideChild& w) {
+      float lo3[3] = {3e38f, 3e38f, 3e38f}, hi3[3] = {-3e38f, -3e38f, -3e38f};
+      for (uint32_t i = first; i < first + count; ++i)
         for (int c = 0; c < 3; ++c) {
-          r.lo[c] = 3e38f;
-          r.hi[c] = -3e38f;
+          lo3[c] = std::min(lo3[c], glo[3ull * order[i] + c]);
+          hi3[c] = std::max(hi3[c], ghi[3ull * order[i] + c]);
         }
-        for (uint32_t i = first; i < first + count; ++i) {
-          slots.push_back(order[i]);
-          for (int c = 0; c < 3; ++c) {
-            r.lo[c] = std::min(r.lo[c], glo[3ull * order[i] + c]);
-            r.hi[c] = std::max(r.hi[c], ghi[3ull * order[i] + c]);
-          }
-        }
-        r.code = make_leaf(slot, count);
-        return r;
-      }
-      // up to four ranges: halves of halves
-      uint32_t rf[4], rc[4];
-      int nr = 0;
-      const uint32_t l = split(first, count);
-      const uint32_t halves[2][2] = {{first, l}, {first + l, count - l}};
-      for (int hh = 0; hh < 2; ++hh) {
-        if (halves[hh][1] >= 3) {
-          const uint32_t ll = split(halves[hh][0], halves[hh][1]);
-          rf[nr] = halves[hh][0]; rc[nr++] = ll;
-          rf[nr] = halves[hh][0] + ll; rc[nr++] = halves[hh][1] - ll;
-        } else {
-          rf[nr] = halves[hh][0]; rc[nr++] = halves[hh][1];
-        }
-      }
-      const int32_t me = (int32_t)(nodes.size() / 4);
-      nodes.resize(nodes.size() + 4);
-      Entry4 e[4];
-      for (int c = 0; c < 3; ++c) {
-        r.lo[c] = 3e38f;
-        r.hi[c] = -3e38f;
-      }
-      for (int k = 0; k < nr; ++k) {
-        const Rec ch = build(rf[k], rc[k]);
-        e[k].lo = mkq(ch.lo[0], ch.lo[1], ch.lo[2], 0);
-        e[k].hi = mkq(ch.hi[0], ch.hi[1], ch.hi[2], 0);
-        e[k].code = ch.code;
-        for (int c = 0; c < 3; ++c) {
-          r.lo[c] = std::min(r.lo[c], ch.lo[c]);
-          r.hi[c] = std::max(r.hi[c], ch.hi[c]);
-        }
-      }
-      encode_node4(&nodes[4ull * me], e, nr, n);  // unused slots lead to the degenerate triangle in slot n
-      r.code = me * 64;                             // inner child = byte offset of its node
-      return r;
+      w.lo = mkq(lo3[0], lo3[1], lo3[2], 0);
+      w.hi = mkq(hi3[0], hi3[1], hi3[2], 0);
     };
-    if (n == 0) {
-      isect.assign(3, mkq(0, 0, 0, 0));
-      shade.assign(4, mkq(0, 0, 0, 0));
-      slot_to_global.assign(1, 0);
-      nodes.assign(4, mkq(0, 0, 0, 0));
-      root = make_leaf(0, 1);
-    } else {
-      Rec r = build(0, n);
-      root = r.code;
-      isect.assign(3ull * (n + 1), mkq(0, 0, 0, 0));  // slot n: the all-zero triangle (det == 0: never hit)
-      shade.assign(4ull * (n + 1), mkq(0, 0, 0, 0));
-      slot_to_global.assign(n + 1, 0);
-      for (uint32_t s = 0; s < n; ++s) {
-        uint32_t gg = slots[s];
-        slot_to_global[s] = gg;
-        for (int k = 0; k < 3; ++k) isect[3ull * s + k] = gi[3ull * gg + k];
-        for (int k = 0; k < 4; ++k) shade[4ull * s + k] = gs[4ull * gg + k];
+    struct Range {
+      uint32_t first, count;
+    };
+    std::vector<Range> queue;  // node i of the output = queue[i]
+    queue.push_back(Range{0, n});
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+      const Range me = queue[qi];
+      // up to kWide ranges: split the largest range until the node is full or only single triangles are left
+      std::vector<Range> ch;
+      ch.push_back(me);
+      if (me.count >= 2) {
+        const uint32_t l = split(me.first, me.count);
+        ch[0] = Range{me.first, l};
+        ch.push_back(Range{me.first + l, me.count - l});
       }
-      if (!guv.empty()) {
-        tri_uv.assign(8ull * (n + 1), 0.0f);
-        for (uint32_t s = 0; s < n; ++s)
-          for (int k = 0; k < 8; ++k) tri_uv[8ull * s + k] = guv[8ull * slots[s] + k];
+      while ((int)ch.size() < kWide) {
+        int best = -1;
+        for (int k = 0; k < (int)ch.size(); ++k)
+          if (ch[k].count >= 2 && (best < 0 || ch[k].count > ch[best].count)) best = k;
+        if (best < 0) break;
+        const Range r = ch[best];
+        const uint32_t l = split(r.first, r.count);
+        ch[best] = Range{r.first, l};
+        ch.push_back(Range{r.first + l, r.count - l});
       }
-      if (nodes.empty()) nodes.assign(4, mkq(0, 0, 0, 0));
+      const uint32_t child_base = (uint32_t)queue.size(), tri_base = (uint32_t)slots.size();
+      nodes.resize(nodes.size() + kNodeQuads);
+      q4* out = &nodes[(size_t)kNodeQuads * qi];
+      if (n == 0) ch.clear();
+#if GSP_WIDE == 8
+      WideChild wc[8], by_slot[8];
+      int slot_of[8];
+      for (size_t k = 0; k < ch.size(); ++k) range_box(ch[k].first, ch[k].count, wc[k]);
+      assign_slots_w8(wc, (int)ch.size(), slot_of);
+      uint32_t imask = 0, lmask = 0;
+      Range in_slot[8];
+      for (size_t k = 0; k < ch.size(); ++k) {
+        by_slot[slot_of[k]] = wc[k];
+        in_slot[slot_of[k]] = ch[k];
+        (ch[k].count >= 2 ? imask : lmask) |= 1u << slot_of[k];
+      }
+      for (int sl = 0; sl < 8; ++sl) {  // ranks in slot order
+        if ((imask >> sl) & 1u) queue.push_back(in_slot[sl]);
+        else if ((lmask >> sl) & 1u) slots.push_back(order[in_slot[sl].first]);
+      }
+      encode_node_w8(out, by_slot, imask, lmask, child_base, tri_base);
+#else
+      WideChild wc[4];
+      int ni = 0, nl = 0;
+      for (const Range& r : ch)
+        if (r.count >= 2) {
+          range_box(r.first, r.count, wc[ni++]);
+          queue.push_back(r);
+        }
+      for (const Range& r : ch)
+        if (r.count == 1) {
+          range_box(r.first, r.count, wc[ni + nl++]);
+          slots.push_back(order[r.first]);
+        }
+      encode_node_w4(out, wc, ni, nl, child_base, tri_base);
+#endif
+    }
+    isect.assign(3ull * (n + 1), mkq(0, 0, 0, 0));  // slot n: the all-zero triangle (det == 0: never hit)
+    shade.assign(4ull * (n + 1), mkq(0, 0, 0, 0));
+    slot_to_global.assign(n + 1, 0);
+    for (uint32_t s = 0; s < n; ++s) {
+      uint32_t gg = slots[s];
+      slot_to_global[s] = gg;
+      for (int k = 0; k < 3; ++k) isect[3ull * s + k] = gi[3ull * gg + k];
+      for (int k = 0; k < 4; ++k) shade[4ull * s + k] = gs[4ull * gg + k];
+    }
+    if (!guv.empty()) {
+      tri_uv.assign(8ull * (n + 1), 0.0f);
+      for (uint32_t s = 0; s < n; ++s)
+        for (int k = 0; k < 8; ++k) tri_uv[8ull * s + k] = guv[8ull * slots[s] + k];
     }
     view.nodes = nodes.data();
     view.tri_isect = isect.data();
@@ -220,7 +225,7 @@ struct Emu {
     view.bsdf.rough_plastic = b7.data();
     view.lights = lights.data();
     view.num_lights = sc.num_lights;
-    view.root = root;
+    view.root = 0;
     if (textured) {  // what gsp_context::view() fills
       view.tex.tri_uv = textures.empty() ? nullptr : tri_uv.data();
       view.tex.textures = textures.data();
@@ -234,6 +239,19 @@ struct Emu {
     }
   }
 };
+
+struct HostStack {  // the per-lane stack of trace_ray (k_finish keeps it in LDS)
+  uint32_t w[4096];
+  uint32_t top = 0;
+  void push(uint32_t v) { w[top++] = v; }
+  uint32_t pop() { return w[--top]; }
+};
+const StepTableRef kTab{&kStepTable};
+template <bool ANY>
+bool trace1(const SceneView& S, f3 o, f3 d, float tmin, float tmax, HitRec& h, uint32_t& aux) {
+  HostStack stk;
+  return trace_ray<ANY>(S.nodes, S.tri_isect, o, d, tmin, tmax, h, aux, stk, kTab);
+}
 
 template <class T>
 void copyv(std::vector<T>& d, const T* s, size_t n) {
@@ -311,7 +329,7 @@ int emu_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixel_i
       while (alive) {
         HitRec hit;
         uint32_t aux;
-        trace_ray4<false>(S.nodes, S.tri_isect, S.root, p.o, p.d, 0.0f, 1e10f, hit, aux);
+        trace1<false>(S, p.o, p.d, 0.0f, 1e10f, hit, aux);
         if (hit.slot < 0 || e->sc.num_vertices == 0) {  // miss (k_shade / k_finish: the <TEX> branch)
           if (e->textured && S.tex.env_texels != nullptr) add_emitted(rc.clamp, miss_emitted(S, p), result);
           break;
@@ -322,7 +340,7 @@ int emu_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixel_i
         if (out.has_shadow) {
           HitRec sh;
           uint32_t aux2;
-          bool occ = trace_ray4<true>(S.nodes, S.tri_isect, S.root, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, sh, aux2);
+          bool occ = trace1<true>(S, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, sh, aux2);
           bool nee_done;
           connect_vertex(rc.clamp, out.shadow, occ, result, nee_done);
           if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;
@@ -357,9 +375,9 @@ int emu_trace(void* h, const float* rays, uint64_t n, int any_hit, void* hits_ou
     uint32_t aux;
     bool hit;
     if (any_hit)
-      hit = trace_ray4<true>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], hh, aux);
+      hit = trace1<true>(S, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], hh, aux);
     else
-      hit = trace_ray4<false>(S.nodes, S.tri_isect, S.root, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], hh, aux);
+      hit = trace1<false>(S, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], hh, aux);
     if (empty) hit = false;
     if (any_hit) out[i] = HR{0, 0, 0, hit ? 0 : -1};
     else out[i] = hit ? HR{hh.t, hh.u, hh.v, (int32_t)e->slot_to_global[hh.slot]} : HR{0, 0, 0, -1};

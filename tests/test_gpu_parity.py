@@ -225,7 +225,7 @@ def test_size_independent_properties_at_scale(ctx):
     assert st["extension_rays"] >= st["samples"] and st["shaded_vertices"] <= st["extension_rays"]
     assert st["shadow_rays"] <= st["shaded_vertices"]
     assert st["num_triangles"] == sc.num_triangles
-    assert sc.num_triangles / 3 < st["num_bvh_nodes"] < sc.num_triangles  # 4-wide nodes: 2..4 children each
+    assert sc.num_triangles / 8 < st["num_bvh_nodes"] < sc.num_triangles  # wide nodes: 2..4 (2..8) children each
 
 
 def test_render_interior_parity_with_oracle(ctx, oracle_mod):
