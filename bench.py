@@ -25,7 +25,11 @@ profiles/pmc_bench_*.json) over this run's HIP-event kernel time, against 1024 S
 memory side is reported next to it: counter HBM bytes per launch (`traffic`, FETCH_SIZE / WRITE_SIZE with the
 calibration of scripts/microbench/fetch_calib.hip) as a fraction of the 8 TB/s peak (`hbm_frac`), and the SURVEY 8(d)
 algorithmic bytes (every node / triangle record the traversal reads, mostly served by L2 / Infinity Cache) as
-`algorithmic_gbs` -- informational, not a fraction of anything.  `cpu_baseline` times the scalar CPU oracle on this
+`algorithmic_gbs` -- informational, not a fraction of anything.  `frac` is an issue-rate UTILISATION (a build that
+executes more instructions per ray scores higher), so the work-normalised figures stand next to it: `effective` =
+frac x lanes enabled per instruction, `valu_instr_per_ray`, `valu_lane_instr_per_ray`; `other_kernels` carries the same
+figures for k_trace<ConnectIO> and k_shade.  The PMC file must carry the source digest of the loaded library
+(`config.library_digest`): a file from another build is refused and the fields stay null.  `cpu_baseline` times the scalar CPU oracle on this
 box's host cores on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
@@ -46,59 +50,90 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 PMC_GLOB = os.path.join(ROOT, "profiles", "pmc_bench_*.json")  # one file per profiled command line (steps / warmup)
 
 
-def pmc_for_run(config, timed_launches):
-    """Counters of the timed k_trace<ExtendIO> launches from the committed rocprofv3 --pmc passes (scripts/pmc_bench.sh)
-    over THIS command: the passes ran the same workload, so their last `timed_launches` dispatches of the kernel are the
-    launches of the timed region (it is the tail of the run).  None when the file is absent or was taken on another
-    workload / launch sequence."""
+def pmc_for_run(config, timed_launches, digest):
+    """Counters of the timed launches of the three render kernels from the committed rocprofv3 --pmc passes
+    (scripts/pmc_bench.sh) over THIS command with THIS build: the passes ran the same workload, so their last
+    `timed_launches` dispatches of a kernel are the launches of the timed region (it is the tail of the run).
+    -> ({kernel: {counter: sum over the timed launches}}, source string) or (None, reason): a file taken on another
+    workload, or with a library whose source digest differs from the loaded one, is refused -- the fields stay null
+    rather than describe another binary."""
     import glob
 
     want = {k: config[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
-    pm = None
+    cands, stale = [], 0
     for path in sorted(glob.glob(PMC_GLOB)):
         try:
             cand = json.load(open(path))
         except (OSError, ValueError):
             continue
         have = cand.get("bench_config", {})
-        if all(have.get(k) == v for k, v in want.items()) and cand.get("timed_launches") == timed_launches and \
-                cand.get("steps") == config.get("steps") and cand.get("warmup") == config.get("warmup"):
-            pm, pm_path = cand, path
-            break
-    scale = None
-    if pm is None:
-        # no pass over exactly this command line (other --steps / --warmup): fall back to the per-launch averages of a pass
-        # over the same workload, scaled to this run's launch count -- steady-state launches trace the same ~52 M rays, so
-        # the fractions hold to a few per cent; the line says so (`pmc` ends in "scaled")
-        for path in sorted(glob.glob(PMC_GLOB)):
-            try:
-                cand = json.load(open(path))
-            except (OSError, ValueError):
-                continue
-            have = cand.get("bench_config", {})
-            if all(have.get(k) == v for k, v in want.items()) and cand.get("timed_launches", 0) > (pm or {}).get("timed_launches", 0):
-                pm, pm_path = cand, path  # the longest profiled run of this workload
-        if pm is not None:
-            scale = float(timed_launches) / float(pm["timed_launches"])
-    if pm is None:
-        return None
-    k = pm["kernels"].get("k_trace_extend")
-    if not k:
-        return None
+        if not all(have.get(k) == v for k, v in want.items()):
+            continue
+        if cand.get("library_digest") != digest:
+            stale += 1
+            continue
+        cands.append((path, cand))
+    if not cands:
+        return None, ("stale build: %d PMC file(s) of this workload were taken with another library digest" % stale) if stale else "no PMC file for this workload"
+    exact = [(p, c) for p, c in cands if c.get("timed_launches") == timed_launches and c.get("steps") == config.get("steps")
+             and c.get("warmup") == config.get("warmup")]
+    if exact:
+        pm_path, pm = exact[0]
+        scale = None
+    else:
+        # no pass over exactly this command line (other --steps / --warmup, or a pool the free memory sized differently):
+        # the per-launch averages of the longest pass over the same workload, scaled to this run's launch count --
+        # steady-state launches trace the same ~52 M rays, so the fractions hold to a few per cent; the line says so
+        pm_path, pm = max(cands, key=lambda pc: pc[1].get("timed_launches", 0))
+        scale = float(timed_launches) / float(max(1, pm["timed_launches"]))
     take = timed_launches if scale is None else int(pm["timed_launches"])
-    out = {"source": "profiles/%s (%s)%s" % (os.path.basename(pm_path), pm.get("source", "?"),
-                                             "" if scale is None else ", per-launch averages of its %d timed launches scaled" % take),
-           "calibration": pm.get("fetch_calibration", {})}
-    for name, vals in k["counters"].items():
-        if len(vals) < take:
-            return None
-        out[name] = float(sum(vals[-take:])) * (1.0 if scale is None else scale)
-    return out
+    out = {}
+    for kname, k in pm["kernels"].items():
+        vals_out = {}
+        for name, vals in k["counters"].items():
+            # connect / shade launch once per extend launch in the timed region
+            if len(vals) < take:
+                return None, "PMC file has fewer dispatches than the timed region"
+            vals_out[name] = float(sum(vals[-take:])) * (1.0 if scale is None else scale)
+        out[kname] = vals_out
+    src = "profiles/%s (%s, library %s)%s" % (os.path.basename(pm_path), pm.get("source", "?"), digest,
+                                              "" if scale is None else ", per-launch averages of its %d timed launches scaled" % take)
+    return out, src
+
+
+def kernel_rates(c, ms, launches, coalesced_read_bytes):
+    """Issue rate, lane use, waiting share and memory-side traffic of one kernel from its counters (sums over the timed
+    launches) and this run's HIP-event time.  FETCH_SIZE (KiB) reads 1.000 x the bytes of divergent 16-B gathers and 0.5 x
+    those of coalesced 16-B-per-lane reads (scripts/microbench/fetch_calib.hip, calibration stored in the PMC file), so
+    the missing half of the kernel's coalesced reads is added back; WRITE_SIZE is exact for streaming writes and an
+    upper bound (x 2) for scattered 16-B ones."""
+    r = {"valu_ginstr_s": None, "issue_frac": None, "lanes_per_instr": None, "effective": None, "wait_share": None,
+         "traffic": None, "hbm_gbs": None, "hbm_frac": None, "l2_hit_rate": None}
+    if not c or ms <= 0:
+        return r
+    insts = c.get("SQ_INSTS_VALU", 0.0)
+    if insts > 0:
+        r["valu_ginstr_s"] = insts / (ms * 1e-3) / 1e9
+        r["issue_frac"] = r["valu_ginstr_s"] / VALU_PEAK_GINST
+        if "SQ_THREAD_CYCLES_VALU" in c:
+            r["lanes_per_instr"] = c["SQ_THREAD_CYCLES_VALU"] / insts / 64.0
+            r["effective"] = r["issue_frac"] * r["lanes_per_instr"]  # share of the chip's lane-slots doing enabled work
+    if c.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_WAIT_ANY" in c:
+        r["wait_share"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        rd = c["FETCH_SIZE"] * 1024.0 + 0.5 * coalesced_read_bytes
+        wr = c["WRITE_SIZE"] * 1024.0
+        r["traffic"] = (rd + wr) / max(1, launches)
+        r["hbm_gbs"] = (rd + wr) / (ms * 1e-3) / 1e9
+        r["hbm_frac"] = r["hbm_gbs"] / HBM_PEAK_GBS
+    if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
+        r["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    return r
 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks of the job (default: WORLD_SIZE, or 1 without a launcher)")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=64)
@@ -186,11 +221,17 @@ def _launch_ranks(args):
 
 def main():
     args = parse()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:  # (before any process group exists: nothing to tear down)
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE %d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     dist = None
     torch = None
     if world > 1:
@@ -202,10 +243,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    if args.gpus != world:
-        if rank == 0:
-            print("bench.py: --gpus %d but the launcher started WORLD_SIZE %d ranks" % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
 
     import gpuspectral_amd as g
     from gpuspectral_amd import multigpu, scenes  # noqa: F401
@@ -302,37 +339,43 @@ def main():
         alg_bytes = st["extension_rays"] * b_ray
         cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S,
                    "steps": args.steps, "warmup": args.warmup}
-        pmc = pmc_for_run(cfg_key, int(st["extend_launches"])) if world == 1 else None
+        digest = g.pt.build_info()["digest"]
+        pmc, pmc_src = pmc_for_run(cfg_key, int(st["extend_launches"]), digest) if world == 1 else (None, "N > 1: counters are a single-GPU measurement")
+        vertices = float(tot[8])
+        ext = kernel_rates((pmc or {}).get("k_trace_extend"), ext_ms, launches, 32.0 * st["extension_rays"])
+        # k_trace<ConnectIO> streams the 32-B shadow ray in and 64 B of its record at the commit; k_shade streams the hit
+        # + the path record in (80 B per vertex)
+        con = kernel_rates((pmc or {}).get("k_trace_connect"), st["connect_kernel_ms"], launches, 96.0 * st["shadow_rays"])
+        shd = kernel_rates((pmc or {}).get("k_shade"), st["shade_kernel_ms"], launches, 80.0 * vertices)
+        # k_shade's compulsory queue traffic: hit + path record in, the survivor's record and the shadow record out
+        shade_bytes = 80.0 * vertices + 64.0 * max(0.0, st["extension_rays"] - samples) + 80.0 * st["shadow_rays"]
+        shd["queue_bytes_per_vertex"] = shade_bytes / max(1.0, vertices)
+        shd["queue_gbs"] = shade_bytes / (st["shade_kernel_ms"] * 1e-3) / 1e9 if st["shade_kernel_ms"] > 0 else None
+        shd["queue_frac_of_hbm_peak"] = shd["queue_gbs"] / HBM_PEAK_GBS if shd["queue_gbs"] else None
         roof = {
-            "kernel": "k_trace<ExtendIO> (closest-hit traversal of the 4-wide BVH)",
+            "kernel": "k_trace<ExtendIO> (closest-hit traversal of the wide BVH)",
             "bound": "valu_issue",
-            "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instr/s", "frac": None,
-            "lanes_per_instr": None, "traffic": None, "hbm_gbs": None, "hbm_frac": None, "l2_hit_rate": None,
+            "achieved": ext["valu_ginstr_s"], "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instr/s", "frac": ext["issue_frac"],
+            "lanes_per_instr": ext["lanes_per_instr"],
+            # work-normalised: a build that issues MORE instructions per ray scores higher on `frac`; these do not
+            "effective": ext["effective"],
+            "valu_instr_per_ray": None, "valu_lane_instr_per_ray": None,
+            "wait_share": ext["wait_share"],
+            "traffic": ext["traffic"], "hbm_gbs": ext["hbm_gbs"], "hbm_frac": ext["hbm_frac"], "l2_hit_rate": ext["l2_hit_rate"],
             "algorithmic_bytes_per_launch": alg_bytes / launches,
             "algorithmic_gbs": alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else None,
             "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
             "launches": int(launches), "avg_launch_ms": ext_ms / launches,
             "extend_ms": ext_ms, "shade_ms": st["shade_kernel_ms"], "connect_ms": st["connect_kernel_ms"],
-            "pmc": None,
+            "other_kernels": {"k_trace<ConnectIO>": con, "k_shade": shd},
+            "pmc": pmc_src,
         }
-        if pmc and ext_ms > 0:
-            insts = pmc.get("SQ_INSTS_VALU", 0.0)
-            roof["achieved"] = insts / (ext_ms * 1e-3) / 1e9
-            roof["frac"] = roof["achieved"] / VALU_PEAK_GINST
-            if insts > 0 and "SQ_THREAD_CYCLES_VALU" in pmc:
-                roof["lanes_per_instr"] = pmc["SQ_THREAD_CYCLES_VALU"] / insts / 64.0
-            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                # FETCH_SIZE (KiB) reads 1.000 x the bytes of the traversal's divergent 16-B gathers and 0.5 x those of
-                # coalesced 16-B-per-lane reads (fetch_calib.hip, in the PMC file); the only coalesced reads of this
-                # kernel are the 32-B ray records, so the missing half of those is added back.  WRITE_SIZE is exact.
-                rd = pmc["FETCH_SIZE"] * 1024.0 + 0.5 * 32.0 * st["extension_rays"]
-                wr = pmc["WRITE_SIZE"] * 1024.0
-                roof["traffic"] = (rd + wr) / launches
-                roof["hbm_gbs"] = (rd + wr) / (ext_ms * 1e-3) / 1e9
-                roof["hbm_frac"] = roof["hbm_gbs"] / HBM_PEAK_GBS
-            if pmc.get("TCC_HIT_sum", 0) + pmc.get("TCC_MISS_sum", 0) > 0:
-                roof["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
-            roof["pmc"] = pmc["source"]
+        if pmc and pmc.get("k_trace_extend") and st["extension_rays"] > 0:
+            c = pmc["k_trace_extend"]
+            if "SQ_INSTS_VALU" in c:
+                roof["valu_instr_per_ray"] = c["SQ_INSTS_VALU"] / st["extension_rays"]
+            if "SQ_THREAD_CYCLES_VALU" in c:
+                roof["valu_lane_instr_per_ray"] = c["SQ_THREAD_CYCLES_VALU"] / st["extension_rays"]
         out = {
             "metric": "Mrays/s (extension + shadow rays), ~1M-tri Mitsuba-style scene at 1080p",
             "value": rays / elapsed / 1e6,
@@ -360,7 +403,7 @@ def main():
                 "shadow_rays": int(sh_rays),
                 "bvh_build_ms": st["bvh_build_ms"],
                 "scene_upload_ms": upload_s * 1e3,
-                "library_digest": g.pt.build_info()["digest"],
+                "library_digest": digest,
             },
             "roofline": roof,
         }

@@ -122,6 +122,7 @@ def main(root):
             out["bench_config"] = {k: b["config"][k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
             out["steps"], out["warmup"] = b["steps"], b["warmup"]
             out["timed_launches"] = b["roofline"]["launches"]
+            out["library_digest"] = b["config"].get("library_digest")  # bench.py refuses the file for any other build
             out["bench_value_under_profiler"] = b["value"]
             print("== bench under the kernel-trace pass: %.1f %s, %d timed k_trace<ExtendIO> launches of %.3f ms (HIP events)" % (
                 b["value"], b["unit"], b["roofline"]["launches"], b["roofline"]["avg_launch_ms"]))

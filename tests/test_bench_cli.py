@@ -54,4 +54,38 @@ def test_mismatched_world_size_is_refused(monkeypatch, capsys):
 def test_pmc_file_is_refused_for_another_workload():
     b = _load_bench()
     cfg = {"workload": "something else", "triangles": 1, "resolution": "8x8", "spp_per_step": 1}
-    assert b.pmc_for_run(cfg, 10) is None
+    pmc, why = b.pmc_for_run(cfg, 10, "0123456789abcdef")
+    assert pmc is None and "no PMC file" in why
+
+
+def test_pmc_file_is_refused_for_another_build(tmp_path, monkeypatch):
+    """The roofline's counters must come from the library that is loaded: a PMC file stamped with another source digest
+    is refused (fields null, `pmc` says why), one with the right digest is used -- for all three render kernels."""
+    import json
+
+    b = _load_bench()
+    cfg = {"workload": "w", "triangles": 3, "resolution": "8x8", "spp_per_step": 2, "steps": 1, "warmup": 0}
+    rec = {"bench_config": {k: cfg[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}, "steps": 1, "warmup": 0,
+           "timed_launches": 2, "library_digest": "aaaaaaaaaaaaaaaa", "source": "test",
+           "kernels": {"k_trace_extend": {"counters": {"SQ_INSTS_VALU": [5.0, 1.0, 2.0], "SQ_THREAD_CYCLES_VALU": [0.0, 64.0, 64.0]}},
+                       "k_shade": {"counters": {"SQ_INSTS_VALU": [9.0, 9.0, 9.0]}}}}
+    (tmp_path / "pmc_bench_t.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(b, "PMC_GLOB", str(tmp_path / "pmc_bench_*.json"))
+    pmc, why = b.pmc_for_run(cfg, 2, "bbbbbbbbbbbbbbbb")
+    assert pmc is None and "stale build" in why
+    pmc, src = b.pmc_for_run(cfg, 2, "aaaaaaaaaaaaaaaa")
+    assert pmc["k_trace_extend"]["SQ_INSTS_VALU"] == 3.0 and pmc["k_shade"]["SQ_INSTS_VALU"] == 18.0  # the LAST two dispatches
+    assert "aaaaaaaaaaaaaaaa" in src and "scaled" not in src
+    r = b.kernel_rates(pmc["k_trace_extend"], 1.0, 2, 0.0)
+    assert r["lanes_per_instr"] == pytest.approx(128.0 / 3.0 / 64.0) and r["effective"] == pytest.approx(r["issue_frac"] * r["lanes_per_instr"])
+    pmc, src = b.pmc_for_run(cfg, 4, "aaaaaaaaaaaaaaaa")  # another launch count: per-launch averages, said so
+    assert pmc["k_trace_extend"]["SQ_INSTS_VALU"] == 6.0 and "scaled" in src
+
+
+def test_gpus_defaults_to_world_size(monkeypatch, capsys):
+    """`torchrun --nproc-per-node N bench.py` without --gpus runs with N ranks: no mismatch exit."""
+    b = _load_bench()
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    args = b.parse()
+    assert args.gpus is None
