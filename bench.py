@@ -144,6 +144,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--dump", default="", help="write the gathered frame as .npy (rank 0)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with one rank and no launcher: still create the process group and run the gather through it "
+                         "(RCCL initialisation + torch / HIP-runtime coexistence smoke run on a one-GPU box)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo = host tensors, for dry runs)")
     return ap.parse_args()
@@ -234,7 +237,17 @@ def main():
         sys.exit(2)
     dist = None
     torch = None
-    if world > 1:
+    if world == 1 and args.force_dist:  # a one-rank group, rendezvous on this host
+        import socket
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        sk.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
 
@@ -289,7 +302,7 @@ def main():
     if dist is not None:
         local_t = torch.zeros((npix_local, 4), dtype=torch.float32, device=tdev)
         # untimed rehearsal of the job's one collective: RCCL sets its point-to-point channels up on first use
-        multigpu.gather_frame(local_t, W, H, rank, world, dist)
+        multigpu.gather_frame(local_t, W, H, rank, world, dist, force=args.force_dist)
 
     barrier()
     t_begin = time.perf_counter()
@@ -303,14 +316,14 @@ def main():
             ctx.copy_accum_to_device(local_t.data_ptr(), npix_local * 16)
         else:
             local_t.copy_(torch.from_numpy(ctx.download_compact()))
-        frame = multigpu.gather_frame(local_t, W, H, rank, world, dist)
+        frame = multigpu.gather_frame(local_t, W, H, rank, world, dist, force=args.force_dist)
     barrier()
     elapsed = time.perf_counter() - t_begin
 
     st = ctx.stats()
     local = np.array(
         [elapsed, st["extension_rays"], st["shadow_rays"], st["samples"], st["extend_kernel_ms"], st["extend_launches"],
-         st["shade_kernel_ms"], st["connect_kernel_ms"], st["shaded_vertices"]],
+         st["shade_kernel_ms"], st["connect_kernel_ms"], st["shaded_vertices"], st["memoised_rays"], st["memo_build_rays"]],
         np.float64,
     )
     if dist is not None:
@@ -331,18 +344,23 @@ def main():
 
     if rank == 0:
         ext_rays, sh_rays, samples = tot[1], tot[2], tot[3]
-        rays = ext_rays + sh_rays
+        memoised, memo_build = tot[9], tot[10]
+        # `value` counts the rays that were TRACED: the depth-0 segments answered from the primary-hit memo (the reference
+        # shoots the same camera ray for every sample of a pixel) are left out, the one trace of each camera ray is in
+        traced_ext = ext_rays - memoised + memo_build
+        rays = traced_ext + sh_rays
         # ---- roofline of the dominant kernel (rank 0's launches): this run's HIP-event time, the committed counters
         b_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray  # ray + hit + node / triangle records
         ext_ms = st["extend_kernel_ms"]
         launches = max(1, st["extend_launches"])
-        alg_bytes = st["extension_rays"] * b_ray
+        ext_traced0 = st["extension_rays"] - st["memoised_rays"]  # rays rank 0's extend launches traced in the timed region
+        alg_bytes = ext_traced0 * b_ray
         cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S,
                    "steps": args.steps, "warmup": args.warmup}
         digest = g.pt.build_info()["digest"]
         pmc, pmc_src = pmc_for_run(cfg_key, int(st["extend_launches"]), digest) if world == 1 else (None, "N > 1: counters are a single-GPU measurement")
         vertices = float(tot[8])
-        ext = kernel_rates((pmc or {}).get("k_trace_extend"), ext_ms, launches, 32.0 * st["extension_rays"])
+        ext = kernel_rates((pmc or {}).get("k_trace_extend"), ext_ms, launches, 32.0 * ext_traced0)
         # k_trace<ConnectIO> streams the 32-B shadow ray in and 64 B of its record at the commit; k_shade streams the hit
         # + the path record in (80 B per vertex)
         con = kernel_rates((pmc or {}).get("k_trace_connect"), st["connect_kernel_ms"], launches, 96.0 * st["shadow_rays"])
@@ -370,12 +388,12 @@ def main():
             "other_kernels": {"k_trace<ConnectIO>": con, "k_shade": shd},
             "pmc": pmc_src,
         }
-        if pmc and pmc.get("k_trace_extend") and st["extension_rays"] > 0:
+        if pmc and pmc.get("k_trace_extend") and ext_traced0 > 0:
             c = pmc["k_trace_extend"]
             if "SQ_INSTS_VALU" in c:
-                roof["valu_instr_per_ray"] = c["SQ_INSTS_VALU"] / st["extension_rays"]
+                roof["valu_instr_per_ray"] = c["SQ_INSTS_VALU"] / ext_traced0
             if "SQ_THREAD_CYCLES_VALU" in c:
-                roof["valu_lane_instr_per_ray"] = c["SQ_THREAD_CYCLES_VALU"] / st["extension_rays"]
+                roof["valu_lane_instr_per_ray"] = c["SQ_THREAD_CYCLES_VALU"] / ext_traced0
         out = {
             "metric": "Mrays/s (extension + shadow rays), ~1M-tri Mitsuba-style scene at 1080p",
             "value": rays / elapsed / 1e6,
@@ -399,8 +417,11 @@ def main():
                 "target_spp": 4096,
                 "max_depth": 50,
                 "parallelism": "tile%d" % world if world > 1 else "single",
-                "extension_rays": int(ext_rays),
+                "collective": ("%s, %d rank(s), one gather of HDR tiles" % (dist.get_backend(), world)) if dist is not None else None,
+                "extension_rays": int(traced_ext),
                 "shadow_rays": int(sh_rays),
+                "memoised_rays": int(memoised),  # camera-ray segments copied from the primary-hit memo: NOT in `value`
+                "path_segments": int(ext_rays + sh_rays),  # what the reference traces for the same samples
                 "bvh_build_ms": st["bvh_build_ms"],
                 "scene_upload_ms": upload_s * 1e3,
                 "library_digest": digest,

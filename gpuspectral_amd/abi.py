@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-GSP_ABI_VERSION = 3
+GSP_ABI_VERSION = 4
 
 BSDF_DIFFUSE = 0
 BSDF_SMOOTH_DIELECTRIC = 1
@@ -167,10 +167,15 @@ class Stats(C.Structure):
         ("num_bvh_nodes", C.c_uint64),
         ("device_bytes", C.c_uint64),
         ("algorithmic_bytes", C.c_uint64),
+        ("memoised_rays", C.c_uint64),
+        ("memo_build_rays", C.c_uint64),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        # rays that were actually traced: path segments answered from the primary-hit memo are not
+        d["traced_rays"] = d["extension_rays"] - d["memoised_rays"] + d["memo_build_rays"] + d["shadow_rays"]
+        return d
 
 
 class SceneArrays:

@@ -4,8 +4,13 @@
 // timestamp only, raygen.rgen:37; no pixel filter), so the frame is partitioned by interleaved 32x32 tiles, the scene
 // and its BVH are replicated on every GPU, every GPU renders all samples of its own tiles with the single-GPU
 // pipeline (pt_render.hip), and the ONLY exchange is one gather of the HDR tiles into GPU 0 at read-back: each
-// share's compact RGBA32F buffer is copied device-to-device into a staging buffer on GPU 0 (peer access over
-// xGMI), a scatter kernel there places the tiles in the frame, and one copy brings the frame to the host.
+// share's compact RGBA32F buffer travels into a staging buffer on GPU 0, a scatter kernel there places the tiles in
+// the frame, and one copy brings the frame to the host.  The gather is ONE RCCL group over xGMI (r03): every share
+// ncclSend()s its buffer, GPU 0 posts the matching ncclRecv()s, all inside one ncclGroupStart / ncclGroupEnd of the
+// single-process communicator (ncclCommInitAll) -- the north_star's "single RCCL gather of HDR tiles".  A device list
+// with repeats (several shares on one GPU: how the one-GPU test box runs partition + gather + scatter with 2 / 3 / 8
+// shares) cannot form a communicator -- RCCL wants one rank per device -- and takes the peer-copy route
+// (hipMemcpyPeerAsync, a plain copy on the same device); GSP_MULTI_GATHER=copy / rccl forces a route.
 //
 // A C++ caller (the reference's host is C++: S/main.cpp:15-30, S/renderer/Renderer.h:22-25,44) gets N GPUs through
 // this file without Python or torch; bench.py's one-process-per-GPU path (torch.distributed, RCCL gather) uses the
@@ -22,6 +27,8 @@
 #include <system_error>
 #include <thread>
 #include <vector>
+
+#include <rccl/rccl.h>
 
 #include "pt_internal.h"
 
@@ -54,6 +61,12 @@ struct gsp_multi {
   uint32_t* d_ids = nullptr; // all shares' pixel ids back to back
   size_t frame_pixels = 0;
   std::string err;
+  // RCCL: one communicator rank per share (device lists without repeats), ranks = share indices
+  std::vector<ncclComm_t> comms;
+  std::vector<hipStream_t> comm_streams;  // one per share, on its device
+  std::vector<char> peer_ok;              // per share: peer access towards devices[0] was obtained (copy route)
+  bool use_rccl = false;
+  uint64_t rccl_gathers = 0, copy_gathers = 0;  // gathers through each route so far (gsp_multi_gather_route)
 };
 
 namespace {
@@ -145,6 +158,14 @@ const char* gsp_multi_last_error(const gsp_multi* m) {
 
 void gsp_multi_destroy(gsp_multi* m) {
   if (!m) return;
+  for (size_t r = 0; r < m->comms.size(); ++r) {
+    (void)hipSetDevice(m->devices[r]);
+    if (m->comms[r]) (void)ncclCommDestroy(m->comms[r]);
+  }
+  for (size_t r = 0; r < m->comm_streams.size(); ++r) {
+    (void)hipSetDevice(m->devices[r]);
+    if (m->comm_streams[r]) (void)hipStreamDestroy(m->comm_streams[r]);
+  }
   for (gsp_context* c : m->ctx) gsp_ctx_destroy(c);
   free_frame(m);
   if (m->stream) {
@@ -173,15 +194,50 @@ int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
     }
     m->ctx.push_back(c);
   }
-  // peer access towards the gathering device (xGMI); a share on the gathering device itself needs none
+  // shares that sit on one device size their path pools concurrently: each takes its part of the 40 % a lone context may
+  bool repeats = false;
+  for (int r = 0; r < n; ++r) {
+    int same = 0;
+    for (int q = 0; q < n; ++q) same += devices[q] == devices[r] ? 1 : 0;
+    repeats = repeats || same > 1;
+    gsp_internal_set_memory_share(m->ctx[r], 0.4 / same);
+  }
+  // peer access towards the gathering device (xGMI) for the copy route; a share on the gathering device needs none
+  m->peer_ok.assign(n, 1);
   for (int r = 1; r < n; ++r) {
     if (devices[r] == devices[0]) continue;
     int can = 0;
+    m->peer_ok[r] = 0;
     if (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) == hipSuccess && can) {
       (void)hipSetDevice(devices[r]);
-      (void)hipDeviceEnablePeerAccess(devices[0], 0);  // "already enabled" is fine; without peer access the runtime
-      (void)hipGetLastError();                         // stages the device-to-device copy through the host
+      const hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
+      m->peer_ok[r] = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+      (void)hipGetLastError();  // (without peer access hipMemcpyPeerAsync stages through the host: slower, still correct)
     }
+  }
+  // RCCL communicator over the shares (ranks = share indices): needs one device per rank
+  const char* route = getenv("GSP_MULTI_GATHER");
+  const bool want_rccl = route ? std::string(route) == "rccl" : (n > 1 && !repeats);
+  if (want_rccl && !repeats) {
+    m->comms.assign(n, nullptr);
+    m->comm_streams.assign(n, nullptr);
+    const ncclResult_t nr = ncclCommInitAll(m->comms.data(), n, devices);
+    if (nr != ncclSuccess) {
+      set_multi_create_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(nr));
+      m->comms.clear();
+      gsp_multi_destroy(m);
+      return GSP_ERR_DEVICE;
+    }
+    for (int r = 0; r < n; ++r) {
+      hipError_t se = hipSetDevice(devices[r]);
+      if (se == hipSuccess) se = hipStreamCreateWithFlags(&m->comm_streams[r], hipStreamNonBlocking);
+      if (se != hipSuccess) {
+        set_multi_create_error(std::string("gsp_multi_create (RCCL stream): ") + hipGetErrorString(se));
+        gsp_multi_destroy(m);
+        return GSP_ERR_DEVICE;
+      }
+    }
+    m->use_rccl = true;
   }
   hipError_t e = hipSetDevice(devices[0]);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
@@ -197,12 +253,20 @@ int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
 int gsp_multi_num_shares(const gsp_multi* m) { return m ? (int)m->ctx.size() : 0; }
 
 int gsp_multi_upload_scene(gsp_multi* m, const gsp_scene_desc* scene) {
-  if (!m || !scene) return GSP_ERR_INVALID;
+  if (!m) return GSP_ERR_INVALID;
+  if (!scene) {
+    m->err = "gsp_multi_upload_scene: null scene";
+    return GSP_ERR_INVALID;
+  }
   return for_each_share(m, [&](size_t r) { return gsp_upload_scene(m->ctx[r], scene); });
 }
 
 int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height) {
-  if (!m || width == 0 || height == 0) return GSP_ERR_INVALID;
+  if (!m) return GSP_ERR_INVALID;
+  if (width == 0 || height == 0) {
+    m->err = "gsp_multi_frame_begin: empty frame";
+    return GSP_ERR_INVALID;
+  }
   const uint32_t world = (uint32_t)m->ctx.size();
   free_frame(m);
   m->width = width;
@@ -222,7 +286,7 @@ int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height) {
     m->err = "internal error: tile partition does not cover the frame";
     return GSP_ERR_INVALID;
   }
-  if (world > 1) {
+  if (world > 1 || m->use_rccl) {  // (one share + a forced RCCL route: the self send / recv of the RCCL smoke test)
     MULTI_TRY(m, hipSetDevice(m->devices[0]));
     MULTI_TRY(m, hipMalloc((void**)&m->staging, total * sizeof(q4)));
     MULTI_TRY(m, hipMalloc((void**)&m->frame, total * sizeof(q4)));
@@ -235,7 +299,7 @@ int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height) {
   int rc = for_each_share(m, [&](size_t r) {
     // a single share owns the whole frame: no subset, no gather
     static const uint32_t none = 0;  // a share without a tile (more shares than tiles) owns NO pixel: non-null list, length 0
-    return world == 1 ? gsp_frame_begin(m->ctx[r], width, height, nullptr, 0)
+    return world == 1 && !m->use_rccl ? gsp_frame_begin(m->ctx[r], width, height, nullptr, 0)
                       : gsp_frame_begin(m->ctx[r], width, height, m->ids[r].empty() ? &none : m->ids[r].data(), m->ids[r].size());
   });
   m->have_frame = rc == GSP_OK;
@@ -243,7 +307,11 @@ int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height) {
 }
 
 int gsp_multi_render(gsp_multi* m, const gsp_render_params* params) {
-  if (!m || !params) return GSP_ERR_INVALID;
+  if (!m) return GSP_ERR_INVALID;
+  if (!params) {
+    m->err = "gsp_multi_render: null parameters";
+    return GSP_ERR_INVALID;
+  }
   return for_each_share(m, [&](size_t r) { return gsp_render(m->ctx[r], params); });
 }
 
@@ -256,18 +324,60 @@ int gsp_multi_sync(gsp_multi* m) {
 // *device_frame (optional) receives the device pointer (width*height RGBA32F on devices[0], valid until the next
 // gsp_multi_frame_begin / destroy).
 int gsp_multi_gather(gsp_multi* m, void** device_frame) {
-  if (!m || !m->have_frame) return GSP_ERR_INVALID;
-  const uint32_t world = (uint32_t)m->ctx.size();
-  if (world == 1) {
-    if (device_frame) *device_frame = nullptr;  // (single share: the frame lives in the context's accumulate buffer)
-    return gsp_sync(m->ctx[0]);
+  if (!m) return GSP_ERR_INVALID;
+  if (!m->have_frame) {
+    m->err = "gsp_multi_gather needs gsp_multi_frame_begin first";
+    return GSP_ERR_INVALID;
   }
-  // the one exchange of the job: every share copies its compact buffer into the staging buffer on devices[0]
-  int rc = for_each_share(m, [&](size_t r) {
-    if (m->ids[r].empty()) return gsp_sync(m->ctx[r]);
-    return gsp_copy_accum_to_device(m->ctx[r], m->staging + m->offset[r], m->ids[r].size() * sizeof(q4));
-  });
+  const uint32_t world = (uint32_t)m->ctx.size();
+  if (world == 1 && !m->use_rccl) {
+    if (device_frame) *device_frame = nullptr;  // (single share: the frame lives in the context's accumulate buffer)
+    int rc = gsp_sync(m->ctx[0]);
+    if (rc != GSP_OK) m->err = gsp_last_error(m->ctx[0]);
+    return rc;
+  }
+  // every share finishes its samples; its compact accumulate buffer is the send buffer
+  std::vector<void*> src(world, nullptr);
+  std::vector<uint64_t> cnt(world, 0);
+  int rc = for_each_share(m, [&](size_t r) { return gsp_internal_accum(m->ctx[r], &src[r], &cnt[r], nullptr); });
   if (rc != GSP_OK) return rc;
+  for (uint32_t r = 0; r < world; ++r)
+    if (cnt[r] != m->ids[r].size()) {
+      m->err = "internal error: a share's pixel count differs from its tile list";
+      return GSP_ERR_DEVICE;
+    }
+  if (m->use_rccl) {
+    // the one exchange of the job, as ONE RCCL group: share r sends its tiles, GPU 0 receives them side by side
+    ncclResult_t nr = ncclGroupStart();
+    for (uint32_t r = 0; r < world && nr == ncclSuccess; ++r) {
+      if (cnt[r] == 0) continue;
+      nr = ncclSend(src[r], cnt[r] * 4, ncclFloat, 0, m->comms[r], m->comm_streams[r]);
+      if (nr == ncclSuccess) nr = ncclRecv(m->staging + m->offset[r], cnt[r] * 4, ncclFloat, (int)r, m->comms[0], m->comm_streams[0]);
+    }
+    const ncclResult_t ge = ncclGroupEnd();
+    if (nr == ncclSuccess) nr = ge;
+    if (nr != ncclSuccess) {
+      m->err = std::string("RCCL gather: ") + ncclGetErrorString(nr);
+      return GSP_ERR_DEVICE;
+    }
+    for (uint32_t r = 0; r < world; ++r) {
+      MULTI_TRY(m, hipSetDevice(m->devices[r]));
+      MULTI_TRY(m, hipStreamSynchronize(m->comm_streams[r]));
+    }
+    ++m->rccl_gathers;
+  } else {
+    // peer copies into the staging buffer (device lists with repeats; GSP_MULTI_GATHER=copy)
+    MULTI_TRY(m, hipSetDevice(m->devices[0]));
+    for (uint32_t r = 0; r < world; ++r) {
+      if (cnt[r] == 0) continue;
+      if (m->devices[r] == m->devices[0])
+        MULTI_TRY(m, hipMemcpyAsync(m->staging + m->offset[r], src[r], cnt[r] * sizeof(q4), hipMemcpyDeviceToDevice, m->stream));
+      else
+        MULTI_TRY(m, hipMemcpyPeerAsync(m->staging + m->offset[r], m->devices[0], src[r], m->devices[r], cnt[r] * sizeof(q4), m->stream));
+    }
+    MULTI_TRY(m, hipStreamSynchronize(m->stream));
+    ++m->copy_gathers;
+  }
   MULTI_TRY(m, hipSetDevice(m->devices[0]));
   const uint64_t total = m->frame_pixels;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 8);
@@ -278,9 +388,22 @@ int gsp_multi_gather(gsp_multi* m, void** device_frame) {
   return GSP_OK;
 }
 
+// Which route the gathers of this object take: 1 = RCCL (ncclSend / ncclRecv group), 0 = peer copies.
+// *rccl_gathers / *copy_gathers (optional): how many gathers each route has carried so far.
+int gsp_multi_gather_route(const gsp_multi* m, uint64_t* rccl_gathers, uint64_t* copy_gathers) {
+  if (!m) return -1;
+  if (rccl_gathers) *rccl_gathers = m->rccl_gathers;
+  if (copy_gathers) *copy_gathers = m->copy_gathers;
+  return m->use_rccl ? 1 : 0;
+}
+
 int gsp_multi_download(gsp_multi* m, float* out_rgba) {
-  if (!m || !out_rgba || !m->have_frame) return GSP_ERR_INVALID;
-  if (m->ctx.size() == 1) {
+  if (!m) return GSP_ERR_INVALID;
+  if (!out_rgba || !m->have_frame) {
+    m->err = !out_rgba ? "gsp_multi_download: null output buffer" : "gsp_multi_download needs gsp_multi_frame_begin first";
+    return GSP_ERR_INVALID;
+  }
+  if (m->ctx.size() == 1 && !m->use_rccl) {
     int rc = gsp_download(m->ctx[0], out_rgba);
     if (rc != GSP_OK) m->err = gsp_last_error(m->ctx[0]);
     return rc;
@@ -316,6 +439,8 @@ int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
       t.shadow_tris_tested += s.shadow_tris_tested;
       t.shadow_stat_rays += s.shadow_stat_rays;
       t.algorithmic_bytes += s.algorithmic_bytes;
+      t.memoised_rays += s.memoised_rays;
+      t.memo_build_rays += s.memo_build_rays;
       t.extend_launches += s.extend_launches;
       t.device_bytes += s.device_bytes;
       t.render_seconds = std::max(t.render_seconds, s.render_seconds);

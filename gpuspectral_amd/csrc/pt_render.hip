@@ -126,8 +126,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t num_pixels, uint32_t K,
                                                       uint32_t first_timestamp,
                                                       const uint32_t* __restrict__ pixel_ids, PathQueue q,
-                                                      uint32_t offset, uint32_t sid_base, q4* __restrict__ result,
-                                                      uint32_t lane, uint32_t lanes) {
+                                                      uint32_t offset, uint32_t sid_base, const q4* __restrict__ memo,
+                                                      q4* __restrict__ hits, uint32_t lane, uint32_t lanes) {
   // num_pixels = pixels of this pipeline lane: owned pixel lp * lanes + lane for lp in [0, num_pixels)
   const uint64_t total = (uint64_t)num_pixels * K;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
@@ -141,6 +141,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
     qst(&q.P1[j], mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid)));
     qst(&q.P2[j], mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight));
     qst(&q.P3[j], mkq(0.0f, 0.0f, 0.0f, ub(p.flags)));  // (the ring entry is written once, by the bounce that ends the path)
+    // primary-hit memo: the camera ray of a pixel is the same for every sample (no jitter, raygen.rgen:31-38), so its
+    // hit record is copied instead of traced again; the extend launch skips these leading entries of the queue
+    if (memo) qst(&hits[j], memo[i % num_pixels]);
   }
 }
 
@@ -159,6 +162,32 @@ struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
   // hit word: slot in bits 0..27, BSDF type of the hit triangle in bits 28..30; miss = all ones
   __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux) const {
     hits[i] = mkq(h.t, h.u, h.v, ub(h.slot < 0 ? 0xffffffffu : ((uint32_t)h.slot | ((aux & 7u) << 28))));
+  }
+};
+
+// Primary-hit memo (r03): the reference shoots the SAME camera ray for every sample of a pixel -- the sub-pixel jitter is
+// commented out, raygen.rgen:38, only the RNG seed depends on the timestamp -- so the depth-0 hit of each owned pixel is
+// traced once per frame (this source: ray i = camera ray of owned pixel i, hit record in ExtendIO's format) and copied
+// into the hit queue by k_generate for every later sample.  Bit-exact by construction: the closest-hit rule does not
+// depend on the traversal.  gsp_stats.memoised_rays counts the path segments answered from the memo: they are not
+// traced rays (bench.py's Mrays/s leaves them out).
+struct MemoIO {
+  static constexpr float kTmin = 0.0f, kTmax = 1e10f;
+  RenderConsts rc;
+  const uint32_t* pixel_ids;
+  uint32_t lane, lanes;
+  q4* memo;
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
+    const uint32_t lp = i * lanes + lane;
+    PathState p;
+    generate_path(rc, pixel_ids ? pixel_ids[lp] : lp, 0u, 0u, p);
+    o = p.o;
+    d = p.d;
+    tmin = 0.0f;
+    tmax = 1e10f;
+  }
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux) const {
+    memo[i] = mkq(h.t, h.u, h.v, ub(h.slot < 0 ? 0xffffffffu : ((uint32_t)h.slot | ((aux & 7u) << 28))));
   }
 };
 
@@ -651,6 +680,7 @@ struct gsp_context {
     uint32_t iteration = 0;
     uint32_t next_ts = 0, remaining = 0;
     uint32_t folded_end = 0;  // one past the last timestamp folded into the accumulate buffer
+    uint64_t front = 0;       // leading paths of the current queue whose hit records came from the primary-hit memo
   };
   // The owned pixels are dealt to kLanes independent pipelines (pixel lp belongs to lane lp % lanes), each
   // with its own pool, counters and stream.  While the host reads one lane's counters back and queues its
@@ -663,7 +693,9 @@ struct gsp_context {
     hipStream_t stream = nullptr;
     uint64_t num_pixels = 0;
     uint64_t pool_cap = 0, result_cap = 0;
-    DevBuf<q4> P0[2], P1[2], P2[2], P3[2], hits, result, S0, S1, S2, S3, S4;
+    DevBuf<q4> P0[2], P1[2], P2[2], P3[2], hits[2], result, S0, S1, S2, S3, S4;
+    DevBuf<q4> memo;          // primary-hit memo: one hit record per owned pixel of this lane
+    bool memo_valid = false;  // ... traced for the current scene / camera / frame
     DevBuf<uint32_t> counters;
     DevBuf<uint32_t> spill;
     uint32_t* h_counters = nullptr;  // pinned: one read-back buffer of C_READBACK words per iteration parity
@@ -675,6 +707,7 @@ struct gsp_context {
     struct Iter {
       bool traced = false, timing = false, finish = false;
       uint64_t injected = 0;  // paths generated into the queue that the following iteration traces
+      uint64_t front = 0;     // leading paths of this iteration's queue that were not traced (primary-hit memo)
     } it[2];
     uint32_t queued = 0;       // iterations in flight (0 .. kPipeDepth)
     uint32_t enq = 0, col = 0; // running index of the next iteration to queue / to collect (parity picks the tail set)
@@ -688,6 +721,8 @@ struct gsp_context {
   gsp_render_params pipe_params{};  // integrator constants the lanes are running with
   uint32_t folded_idle = 0;         // timestamps folded when no pipeline is running (gsp_peek)
   uint32_t finish_paths = 0;        // k_finish takes over below this many live paths (GSP_FINISH_PATHS, 0 = never)
+  bool primary_memo = true;         // GSP_PRIMARY_MEMO=0: every sample traces its camera ray
+  double memory_share = 0.4;        // of the free device memory, for the path pool + result ring (gsp_internal_set_memory_share)
   bool pipe_active = false;
 
   SceneView view() const {
@@ -823,6 +858,7 @@ int gsp_ctx_create(int device, gsp_context** out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   c->finish_paths = getenv("GSP_FINISH_PATHS") ? (uint32_t)strtoul(getenv("GSP_FINISH_PATHS"), nullptr, 10) : kFinishPaths;
+  if (const char* pm = getenv("GSP_PRIMARY_MEMO")) c->primary_memo = atoi(pm) != 0;
   if (const char* nl = getenv("GSP_LANES")) c->num_lanes = (uint32_t)std::min(std::max(atoi(nl), 1), (int)gsp_context::kMaxLanes);
   for (uint32_t l = 0; l < c->num_lanes && e == hipSuccess; ++l) {
     gsp_context::Lane& L = c->lanes[l];
@@ -869,6 +905,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     if (rc_ != GSP_OK) return rc_;
   }
   ctx->have_scene = false;
+  for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
   // ---- validate ----
   if ((sc->num_instances && !sc->instances) || (sc->num_vertices && (!sc->positions || !sc->normals)) ||
       (sc->num_lights && !sc->lights)) {
@@ -1034,6 +1071,7 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uin
     return GSP_ERR_INVALID;
   }
   ctx->have_frame = false;
+  for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
   ctx->subset = pixel_ids != nullptr;
   if (pixel_ids) {
     for (uint64_t i = 0; i < num_pixels; ++i) {
@@ -1082,7 +1120,8 @@ static int ensure_pool(gsp_context* ctx, gsp_context::Lane& L, uint64_t cap, uin
     CTX_TRY(ctx, L.P2[k].ensure(cap, &ctx->bytes));
     CTX_TRY(ctx, L.P3[k].ensure(cap, &ctx->bytes));
   }
-  CTX_TRY(ctx, L.hits.ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, L.hits[0].ensure(cap, &ctx->bytes));
+  CTX_TRY(ctx, L.hits[1].ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S0.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S1.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S2.ensure(cap, &ctx->bytes));
@@ -1152,6 +1191,21 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   I = gsp_context::Lane::Iter{};
 
   CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
+  const bool use_memo = ctx->primary_memo && !stats_mode;
+  if (use_memo && !L.memo_valid && P.remaining > 0) {  // once per scene / camera / frame: trace the camera rays
+    CTX_TRY(ctx, L.memo.ensure(npix, &ctx->bytes));
+    CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_WORK_EXT, 0, kWorkShards * kWorkStride * sizeof(uint32_t), st));
+    const MemoIO io{rcst, ctx->subset ? ctx->pixel_ids.p : nullptr, L.index, ctx->num_lanes, L.memo.p};
+    const uint32_t chunk = npix >= (1u << 20) ? kChunkLarge : kChunkSmall;
+    hipLaunchKernelGGL((k_trace<false, false, MemoIO>), dim3(ctx->trace_grid(npix, chunk)), dim3(kTraceBlock), 0, st, view.nodes,
+                       view.tri_isect, (const uint32_t*)nullptr, (uint32_t)npix, 0u, chunk, io, L.counters.p + C_WORK_EXT, L.spill.p,
+                       ctx->spill_stride, so_ext);
+    CTX_TRY(ctx, hipGetLastError());
+    ctx->stats.memo_build_rays += npix;
+    L.memo_valid = true;
+  }
+  const uint64_t front = use_memo ? P.front : 0;  // (a stats pass traces everything: its counters describe all rays)
+  I.front = front;
   if (drain && exact && P.remaining == 0 && n > 0 && n <= ctx->finish_paths && !stats_mode &&
       ctx->bvh.depth + 2 <= kFinishLevels) {
     // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
@@ -1182,7 +1236,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       if (slot == P.num_slots || n + inj + paths > P.cap) break;
       hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
                          ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur ^ 1], (uint32_t)inj, (uint32_t)(slot * batch_paths),
-                         L.result.p, L.index, ctx->num_lanes);
+                         use_memo ? L.memo.p : (const q4*)nullptr, L.hits[cur ^ 1].p, L.index, ctx->num_lanes);
       CTX_TRY(ctx, hipGetLastError());
       CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(live + slot), (int)paths, 1, st));
       L.h_live[slot] = (uint32_t)paths;
@@ -1201,15 +1255,15 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_WORK_EXT, 0, (C_COUNT - C_WORK_EXT) * sizeof(uint32_t), st));
       if (timing) CTX_TRY(ctx, hipEventRecord(ev[0], st));
       {
-        const ExtendIO io{Q[cur], L.hits.p};
+        const ExtendIO io{Q[cur], L.hits[cur].p};
         uint32_t* work = L.counters.p + C_WORK_EXT;
         if (stats_mode)
           hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                             (const uint32_t*)(tails_in + T_NEXT), 0u, 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
+                             (const uint32_t*)(tails_in + T_NEXT), 0u, (uint32_t)front, chunk, io, work, L.spill.p, ctx->spill_stride,
                              so_ext);
         else
           hipLaunchKernelGGL((k_trace<false, false, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
-                             (const uint32_t*)(tails_in + T_NEXT), 0u, 0u, chunk, io, work, L.spill.p, ctx->spill_stride,
+                             (const uint32_t*)(tails_in + T_NEXT), 0u, (uint32_t)front, chunk, io, work, L.spill.p, ctx->spill_stride,
                              so_ext);
         CTX_TRY(ctx, hipGetLastError());
       }
@@ -1219,10 +1273,10 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
                                 (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (GSP_SHADE_MINWAVES * 256 / kShadeBlock)));  // the resident blocks
       if (ctx->textured)
         hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
-                           L.hits.p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+                           L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
       else
         hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
-                           L.hits.p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+                           L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
       CTX_TRY(ctx, hipGetLastError());
       if (timing) CTX_TRY(ctx, hipEventRecord(ev[2], st));
       {
@@ -1249,6 +1303,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   ++L.queued;
   ++L.enq;
   P.cur ^= 1;
+  P.front = use_memo && !I.finish ? I.injected : 0;
   P.n = (I.finish ? 0 : n) + I.injected;  // survivors <= n: an upper bound of the next iteration's input until the read-back says more
   P.n_est = (I.finish ? 0.0 : (exact ? (double)n : std::min((double)n, P.n_est)) * P.survive) + (double)I.injected;
   return GSP_OK;
@@ -1271,7 +1326,8 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
       ctx->stats.extension_rays += (uint64_t)tails[T_FIN_EXT] | ((uint64_t)tails[T_FIN_EXT + 1] << 32);
       ctx->stats.shadow_rays += (uint64_t)tails[T_FIN_SH] | ((uint64_t)tails[T_FIN_SH + 1] << 32);
     } else if (I.traced) {
-      ctx->stats.extension_rays += n_traced;
+      ctx->stats.extension_rays += n_traced;  // path segments; I.front of them were answered from the memo
+      ctx->stats.memoised_rays += I.front;
       ctx->stats.shadow_rays += tails[T_SHADOW];
     }
     const uint32_t bounce = P.iteration++;
@@ -1436,15 +1492,15 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
       {
         // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline
-        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  224 B of queues per
-        // path of capacity (2 x 64-B path records, 16-B hit, 80-B shadow record), capacity = 2 x the pool target.
+        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  240 B of queues per
+        // path of capacity (2 x 64-B path records, 2 x 16-B hit, 80-B shadow record), capacity = 2 x the pool target.
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          const uint64_t have = L.pool_cap * 224ull + L.result_cap * sizeof(q4);
-          const uint64_t budget = (uint64_t)((double)free_b * 0.4) + have;
-          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 224ull;
+          const uint64_t have = L.pool_cap * 240ull + L.result_cap * sizeof(q4);
+          const uint64_t budget = (uint64_t)((double)free_b * ctx->memory_share) + have;
+          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 240ull;
           if (queues > budget / 2) {
-            const uint64_t fit = budget / 2 / 224ull;  // paths of capacity that fit
+            const uint64_t fit = budget / 2 / 240ull;  // paths of capacity that fit
             P.pool_target = std::max<uint64_t>(2 * P.batch_paths, fit > P.batch_paths ? (fit - P.batch_paths) / 2 : 0);
           }
           ring_bytes = std::min<uint64_t>(ring_bytes, std::max<uint64_t>(budget / 2, 4 * P.batch_paths * sizeof(q4)));
@@ -1553,6 +1609,25 @@ int gsp_copy_accum_to_device(gsp_context* ctx, void* dst, uint64_t bytes) {
   return GSP_OK;
 }
 
+}  // extern "C"
+
+int gsp::gsp_internal_accum(gsp_context* ctx, void** accum, uint64_t* num_pixels, hipStream_t* stream) {
+  if (!ctx || !ctx->have_frame) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = pipeline_drain(ctx);
+  if (rc != GSP_OK) return rc;
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (accum) *accum = ctx->accum.p;
+  if (num_pixels) *num_pixels = ctx->num_pixels;
+  if (stream) *stream = ctx->stream;
+  return GSP_OK;
+}
+void gsp::gsp_internal_set_memory_share(gsp_context* ctx, double fraction) {
+  if (ctx) ctx->memory_share = std::min(0.4, std::max(0.01, fraction));
+}
+
+extern "C" {
+
 int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels) {
   if (!ctx || !rgba || !ctx->have_frame || num_pixels != ctx->num_pixels) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
@@ -1588,8 +1663,8 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
   ctx->stats.num_triangles = ctx->bvh.num_tris;
   ctx->stats.num_bvh_nodes = ctx->bvh.num_nodes;
   ctx->stats.device_bytes = ctx->bytes;
-  ctx->stats.algorithmic_bytes = 48ull * ctx->stats.stat_rays + 64ull * ctx->stats.nodes_visited + 48ull * ctx->stats.tris_tested +
-                                 96ull * ctx->stats.shadow_stat_rays + 64ull * ctx->stats.shadow_nodes_visited +
+  ctx->stats.algorithmic_bytes = 48ull * ctx->stats.stat_rays + (uint64_t)kNodeBytes * ctx->stats.nodes_visited + 48ull * ctx->stats.tris_tested +
+                                 96ull * ctx->stats.shadow_stat_rays + (uint64_t)kNodeBytes * ctx->stats.shadow_nodes_visited +
                                  48ull * ctx->stats.shadow_tris_tested;
   *out = ctx->stats;
   return GSP_OK;

@@ -35,16 +35,21 @@ def partition(width, height, rank, world, tile=TILE):
     return tile_pixel_ids(width, height, rank, world, tile)
 
 
-def gather_frame(local_rgba, width, height, rank, world, dist, tile=TILE):
+def gather_frame(local_rgba, width, height, rank, world, dist, tile=TILE, force=False):
     """Gather the ranks' compact [n_r, 4] float32 tensors to rank 0 and assemble the
     full [height*width, 4] frame there (returns None on the other ranks).
 
     `local_rgba` is a torch tensor (cuda for nccl, cpu for gloo) holding this rank's
-    pixels in partition() order."""
+    pixels in partition() order.  force: a one-rank group still runs the collective (the RCCL
+    smoke run of a one-GPU box, bench.py --force-dist)."""
     import torch
 
-    if world <= 1:
+    if world <= 1 and not force:
         return local_rgba
+    if world <= 1:
+        gl = [torch.empty_like(local_rgba)]
+        dist.gather(local_rgba, gl, dst=0)
+        return gl[0]
     counts = [len(tile_pixel_ids(width, height, r, world, tile)) for r in range(world)]
     maxn = max(counts)
     buf = torch.zeros((maxn, 4), dtype=torch.float32, device=local_rgba.device)

@@ -43,6 +43,7 @@ EXPORTS = (
     "gsp_multi_render",
     "gsp_multi_sync",
     "gsp_multi_gather",
+    "gsp_multi_gather_route",
     "gsp_multi_download",
     "gsp_multi_get_stats",
     "gsp_multi_reset_stats",
@@ -108,9 +109,14 @@ def load():
     L.gsp_multi_download.argtypes = [vp, vp]
     L.gsp_multi_get_stats.argtypes = [vp, C.POINTER(abi.Stats), C.POINTER(abi.Stats)]
     L.gsp_multi_reset_stats.argtypes = [vp]
+    if hasattr(L, "gsp_multi_gather_route"):  # (absent from an ABI-3 build variant)
+        L.gsp_multi_gather_route.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.gsp_multi_last_error.argtypes = [vp]
     L.gsp_multi_last_error.restype = C.c_char_p
-    if L.gsp_abi_version() != abi.GSP_ABI_VERSION:
+    v = L.gsp_abi_version()
+    # (a GSP_LIB_PATH build variant of an earlier round -- the same-box baseline of an A/B -- may be one version behind:
+    # version 4 only appended fields to gsp_stats, which such a library leaves zero in the caller's struct)
+    if v != abi.GSP_ABI_VERSION and not (os.environ.get("GSP_LIB_PATH") and v == abi.GSP_ABI_VERSION - 1):
         raise GspError("ABI version mismatch between abi.py and %s" % path)
     _LIB = L
     return L
@@ -332,6 +338,12 @@ class MultiContext:
         each = (abi.Stats * self.num_shares)()
         self._check(self._L.gsp_multi_get_stats(self._h, C.byref(tot), each), "gsp_multi_get_stats")
         return (tot.as_dict(), [e.as_dict() for e in each]) if per_share else tot.as_dict()
+
+    def gather_route(self):
+        """("rccl" | "copy", gathers carried by RCCL so far, gathers carried by peer copies so far)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        r = self._L.gsp_multi_gather_route(self._h, C.byref(a), C.byref(b))
+        return ("rccl" if r == 1 else "copy"), a.value, b.value
 
     def reset_stats(self):
         self._check(self._L.gsp_multi_reset_stats(self._h), "gsp_multi_reset_stats")

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 3 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes */
+#define GSP_ABI_VERSION 4 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -258,6 +258,13 @@ typedef struct gsp_stats {
                                  + 16 (hit) + 64 per node + 48 per triangle record read, per shadow ray 64 + 32 + the
                                  same node / triangle terms.  What the traversal ASKS of the memory hierarchy; the
                                  bytes that reach HBM are a quarter of it (rocprofv3 FETCH_SIZE) */
+  /* (ABI 4) primary-hit memo: every sample of a pixel shoots the same camera ray (raygen.rgen:31-38, no jitter), so the
+     camera rays of a frame are traced once (memo_build_rays) and later samples copy the hit.  extension_rays keeps
+     counting PATH SEGMENTS (what the reference traces: it equals the oracle's count); memoised_rays of them were
+     answered from the memo.  Rays actually traced = extension_rays - memoised_rays + memo_build_rays + shadow_rays.
+     GSP_PRIMARY_MEMO=0 turns the memo off. */
+  uint64_t memoised_rays;
+  uint64_t memo_build_rays;
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;
@@ -362,10 +369,17 @@ int gsp_multi_upload_scene(gsp_multi* m, const gsp_scene_desc* scene);
 int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height);
 int gsp_multi_render(gsp_multi* m, const gsp_render_params* params);
 int gsp_multi_sync(gsp_multi* m);
-/* The one exchange of a render: completes the queued samples, copies every share's HDR tiles device-to-device into
- * devices[0] and assembles the frame there.  *device_frame (optional) = the RGBA32F frame on devices[0] (NULL for a
- * single share, whose frame is its context's accumulate buffer). */
+/* The one exchange of a render: completes the queued samples, brings every share's HDR tiles into devices[0] and
+ * assembles the frame there.  With one share per device the gather is ONE RCCL group over xGMI (every share
+ * ncclSend()s its tiles, devices[0] ncclRecv()s them); a device list with repeats (several shares on one GPU, for
+ * tests) uses peer copies instead -- RCCL wants one rank per device.  GSP_MULTI_GATHER=rccl | copy forces a route
+ * (rccl with ONE share performs a self send / recv: the RCCL smoke test of a one-GPU box).
+ * *device_frame (optional) = the RGBA32F frame on devices[0] (NULL for a single share without RCCL, whose frame is its
+ * context's accumulate buffer). */
 int gsp_multi_gather(gsp_multi* m, void** device_frame);
+/* 1: the gathers of `m` go through RCCL, 0: through peer copies (-1: m is NULL).  The optional outputs receive the
+ * number of gathers each route has carried so far. */
+int gsp_multi_gather_route(const gsp_multi* m, uint64_t* rccl_gathers, uint64_t* copy_gathers);
 /* gsp_multi_gather + one copy to the host: width*height*4 floats, identical to a single-GPU gsp_download. */
 int gsp_multi_download(gsp_multi* m, float* out_rgba);
 /* total (optional): counters summed over the shares, times of the slowest share (they run concurrently);

@@ -9,6 +9,6 @@ with g.Context(0) as ctx:
     for rep in range(int(os.environ.get("REPS", "2"))):
         ctx.reset_stats(); t = time.time(); ctx.render(spp=48, first_timestamp=ts, collect_kernel_times=1); ctx.sync(); dt = time.time() - t; ts += 48
         st = ctx.stats()
-        r = ((st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, st["extend_kernel_ms"], st["shade_kernel_ms"], st["connect_kernel_ms"])
+        r = (st["traced_rays"] / dt / 1e6, st["extend_kernel_ms"], st["shade_kernel_ms"], st["connect_kernel_ms"])
         best = r if best is None or r[0] > best[0] else best
     print("%.1f Mrays/s | extend %.1f shade %.1f connect %.1f ms" % best, flush=True)

@@ -21,7 +21,7 @@ def probe(name, sc, W, H, spp, K=0):
         ctx.sync()
         dt = time.time() - t
         st = ctx.stats()
-        rays = st["extension_rays"] + st["shadow_rays"]
+        rays = st["traced_rays"]
         print("%s: %d tris, upload+build %.1f ms (build %.1f), %dx%d x %d spp: %.3f s, %.1f Mrays/s, %.2f Msamples/s | "
               "extend %.1f ms (%d launches) shade %.1f ms connect %.1f ms | ext %d sh %d | mem %.2f GB"
               % (name, st["num_triangles"], up * 1e3, st["bvh_build_ms"], W, H, spp, dt, rays / dt / 1e6,

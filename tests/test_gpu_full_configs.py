@@ -102,5 +102,5 @@ def test_config_at_full_size(name, golden):
         got = [s2[k] for k in ("extension_rays", "shadow_rays", "shaded_vertices", "samples")]
         assert got == [int(v) for v in golden[name + "/counts_full"]], (got, golden[name + "/counts_full"])
         print("%s: %d tris %dx%d x %d spp on %d px: %.0f Mrays/s, %.0f Msamples/s" % (
-            name, st["num_triangles"], W, H, spp, npix, (st["extension_rays"] + st["shadow_rays"]) / st["render_seconds"] / 1e6,
+            name, st["num_triangles"], W, H, spp, npix, st["traced_rays"] / st["render_seconds"] / 1e6,
             st["samples"] / st["render_seconds"] / 1e6))

@@ -94,6 +94,72 @@ def test_config4_partition_at_full_resolution():
     assert tot["extension_rays"] == st1["extension_rays"] and tot["shadow_rays"] == st1["shadow_rays"]
 
 
+def test_rccl_gather_route_with_one_device(monkeypatch, materials_scene):
+    """The RCCL route of gsp_multi_gather on the one GPU of the test box: GSP_MULTI_GATHER=rccl makes a single share
+    build a communicator (ncclCommInitAll over one device) and send / receive its tiles to itself inside one
+    ncclGroupStart / ncclGroupEnd, then scatter them: the frame must equal the single-context frame.  (With one
+    share per device this is the default route; a device list with repeats cannot form a communicator.)"""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import pt
+
+    W, H, spp = 320, 200, 6
+    with g.Context(0) as ctx:
+        ctx.upload_scene(materials_scene)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        ref = ctx.download()
+    monkeypatch.setenv("GSP_MULTI_GATHER", "rccl")
+    with pt.MultiContext([0]) as m:
+        assert m.gather_route()[0] == "rccl"
+        m.upload_scene(materials_scene)
+        m.frame_begin(W, H)
+        m.render(spp=spp)
+        img = m.download()
+        route, n_rccl, n_copy = m.gather_route()
+        assert route == "rccl" and n_rccl >= 1 and n_copy == 0
+        m.render(spp=2, first_timestamp=spp)  # a second gather through the same communicator
+        img2 = m.download()
+        assert m.gather_route()[1] >= 2
+    assert np.array_equal(img, ref)
+    assert np.isfinite(img2).all()
+    monkeypatch.setenv("GSP_MULTI_GATHER", "copy")
+    with pt.MultiContext([0, 0]) as m:  # repeats: always the copy route
+        assert m.gather_route()[0] == "copy"
+    monkeypatch.delenv("GSP_MULTI_GATHER")
+    with pt.MultiContext([0, 0]) as m:
+        assert m.gather_route()[0] == "copy"
+
+
+def test_library_links_rccl():
+    """The C++ product itself carries the RCCL gather (ldd shows librccl), not only the torch path of bench.py."""
+    lib = os.path.join(ROOT, "gpuspectral_amd", "lib", "libgpuspectral_pt.so")
+    out = subprocess.run(["ldd", lib], capture_output=True, text=True).stdout
+    assert "librccl" in out, out
+
+
+def test_bench_one_rank_through_nccl(tmp_path):
+    """bench.py with ONE rank but through torch.distributed's "nccl" backend (= RCCL): process-group creation, the
+    torch-bundled HIP runtime next to the hipcc-built library, the device-to-device hand-over of the accumulate
+    buffer into a torch CUDA tensor and a (one-rank) dist.gather, on every driver run -- so that the first
+    execution of this path is not the 8-GPU scaling run.  Frame and ray counts equal the plain single-rank run's."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "1", "--warmup", "1", "--spp-per-step", "4", "--tris", "60000", "--width", "416", "--height", "240",
+              "--no-cpu-baseline"]
+    f1, f2 = str(tmp_path / "plain.npy"), str(tmp_path / "nccl.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump", f1] + common, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl", "--dump", f2] + common,
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["config"]["collective"] is None and j2["config"]["collective"].startswith("nccl, 1 rank")
+    assert j1["config"]["extension_rays"] == j2["config"]["extension_rays"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]
+    a, b = np.load(f1), np.load(f2)
+    assert a.shape == (240, 416, 4) and np.array_equal(a.reshape(-1, 4), b.reshape(-1, 4))
+
+
 def _read_pfm(path):
     with open(path, "rb") as f:
         assert f.readline() == b"PF\n"
@@ -136,7 +202,9 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2
-    assert j1["config"]["extension_rays"] == j2["config"]["extension_rays"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]
+    # path segments are a property of the samples; how many of the camera-ray segments were copied from the primary-hit
+    # memo instead of traced is not (a rank whose few remaining paths go to k_finish traces them from the camera)
+    assert j1["config"]["path_segments"] == j2["config"]["path_segments"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]
     a, b = np.load(f1), np.load(f2)
     assert a.shape == b.shape == (240, 416, 4) and np.array_equal(a, b)
 

@@ -27,8 +27,8 @@ def run(name, sc, W, H, spp, ids=None, check_px=96, **kw):
         t = time.time(); ref, _ = O.Oracle(sc).render(W, H, spp=spp, pixel_ids=own[pick], params=p); cpu_dt = time.time() - t
         ndiff = int((img[pick] != ref).any(1).sum())
         rec = dict(config=name, triangles=st["num_triangles"], resolution="%dx%d" % (W, H), pixels=int(len(own)), spp=spp, seconds=dt,
-                   mrays_per_s=(st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, msamples_per_s=st["samples"] / dt / 1e6,
-                   rays_per_sample=(st["extension_rays"] + st["shadow_rays"]) / st["samples"], upload_build_ms=up * 1e3,
+                   mrays_per_s=st["traced_rays"] / dt / 1e6, msamples_per_s=st["samples"] / dt / 1e6,
+                   rays_per_sample=st["traced_rays"] / st["samples"], upload_build_ms=up * 1e3,
                    device_gb=st["device_bytes"] / 1e9, oracle_pixels_checked_at_full_spp=check_px, oracle_pixels_differing=ndiff,
                    oracle_seconds=cpu_dt, nan_pixels=int(np.isnan(img).any(1).sum()), frame_crc32="%08x" % zlib.crc32(img.tobytes()),
                    mean_rgb=[float(v) for v in img[:, :3].mean(0)], **{k: v for k, v in kw.items()})

@@ -30,8 +30,8 @@ with g.Context(0) as ctx:
         img = ctx.download()
         full_sub = img.reshape(-1, 4)[ids]
         rec = dict(scene=name, triangles=st["num_triangles"], lights=len(sc.lights), resolution="%dx%d" % (W, H), spp=SPP,
-                   seconds=dt, mrays_per_s=(st["extension_rays"] + st["shadow_rays"]) / dt / 1e6,
-                   msamples_per_s=st["samples"] / dt / 1e6, rays_per_sample=(st["extension_rays"] + st["shadow_rays"]) / st["samples"],
+                   seconds=dt, mrays_per_s=st["traced_rays"] / dt / 1e6,
+                   msamples_per_s=st["samples"] / dt / 1e6, rays_per_sample=st["traced_rays"] / st["samples"],
                    upload_build_ms=up * 1e3, parity_pixels=len(ids), parity_pixels_differing=ndiff,
                    parity_rays_equal=bool(st_g["extension_rays"] == st_o["extension_rays"] and st_g["shadow_rays"] == st_o["shadow_rays"]),
                    nan_pixels=int(np.isnan(img).any(2).sum()), mean_rgb=[float(v) for v in img[..., :3].mean((0, 1))])

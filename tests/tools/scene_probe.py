@@ -35,7 +35,7 @@ with g.Context(0) as ctx:
         spp = int(max(64, min(16384, 32 * SECONDS / max(dt, 1e-3))))
         ctx.reset_stats(); t = time.time(); ctx.render(spp=spp, first_timestamp=ts, collect_kernel_times=1); ctx.sync(); dt = time.time() - t
         st = ctx.stats()
-        rays = st["extension_rays"] + st["shadow_rays"]
+        rays = st["traced_rays"]
         print(json.dumps(dict(scene=name, triangles=st["num_triangles"], bvh_nodes=st["num_bvh_nodes"], resolution="%dx%d" % (W, H), spp=spp,
                               seconds=round(dt, 3), mrays_per_s=round(rays / dt / 1e6, 1), msamples_per_s=round(st["samples"] / dt / 1e6, 1),
                               rays_per_sample=round(rays / st["samples"], 2), shadow_share=round(st["shadow_rays"] / rays, 3),

@@ -20,7 +20,7 @@ with g.Context(0) as ctx:
             ctx.reset_stats(); t = time.time(); ctx.render(spp=4 * spp, first_timestamp=spp * (1 + 4 * rep), collect_kernel_times=1); ctx.sync(); dt = time.time() - t
             st = ctx.stats()
             r = dict(share="1/%d" % world, pixels=ctx.num_pixels, spp=4 * spp, seconds=round(dt, 3),
-                     mrays_per_s=round((st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, 1),
+                     mrays_per_s=round(st["traced_rays"] / dt / 1e6, 1),
                      kernels_ms=round(st["extend_kernel_ms"] + st["shade_kernel_ms"] + st["connect_kernel_ms"], 1),
                      busy=round((st["extend_kernel_ms"] + st["shade_kernel_ms"] + st["connect_kernel_ms"]) / (dt * 1e3), 4),
                      launches=st["extend_launches"], rays_per_launch=round(st["extension_rays"] / max(1, st["extend_launches"]) / 1e6, 2))

@@ -22,7 +22,7 @@ def run(name, sc, W, H, spp, check_px=64, **kw):
             setattr(p, k, v)
         ref, _ = O.Oracle(sc).render(W, H, spp=spp, pixel_ids=pick, params=p)
         print(json.dumps(dict(case=name, triangles=st["num_triangles"], resolution="%dx%d" % (W, H), spp=spp, seconds=dt,
-                              mrays_per_s=(st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, upload_build_ms=up * 1e3,
+                              mrays_per_s=st["traced_rays"] / dt / 1e6, upload_build_ms=up * 1e3,
                               device_gb=st["device_bytes"] / 1e9, oracle_pixels_checked=check_px,
                               oracle_pixels_differing=int((img[pick] != ref).any(1).sum()), nan_pixels=int(np.isnan(img).any(1).sum()))), flush=True)
 

@@ -27,7 +27,7 @@ def run(sc, label):
             dt = time.time() - t
             ts += 48
             st = ctx.stats()
-            r = ((st["extension_rays"] + st["shadow_rays"]) / dt / 1e6, st["extend_kernel_ms"], st["shade_kernel_ms"], st["connect_kernel_ms"])
+            r = (st["traced_rays"] / dt / 1e6, st["extend_kernel_ms"], st["shade_kernel_ms"], st["connect_kernel_ms"])
             best = r if best is None or r[0] > best[0] else best
         print("%-34s %.1f Mrays/s | extend %.1f shade %.1f connect %.1f ms | device %.2f GB" % ((label,) + best + (st["device_bytes"] / 1e9,)), flush=True)
 
