@@ -349,13 +349,15 @@ int extendSign(uint32_t bits, int size) {  // T.81 F.2.2.1
 
 // 8x8 inverse DCT (T.81 A.3.3), separable, double precision; output level-shifted and clamped
 void inverseDct(const int coef[64], const uint16_t quant[64], uint8_t* out, int stride) {
-  static double basis[8][8];
-  static bool ready = false;
-  if (!ready) {
-    for (int x = 0; x < 8; ++x)
-      for (int u = 0; u < 8; ++u) basis[x][u] = (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0) * 0.5;
-    ready = true;
-  }
+  struct Basis {  // built once, by the first caller, under the language's own guard (scenes may load on several threads)
+    double b[8][8];
+    Basis() {
+      for (int x = 0; x < 8; ++x)
+        for (int u = 0; u < 8; ++u) b[x][u] = (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0) * 0.5;
+    }
+  };
+  static const Basis table;
+  const double (&basis)[8][8] = table.b;
   double f[64], tmp[64];
   for (int k = 0; k < 64; ++k) f[k] = (double)coef[k] * quant[k];
   for (int v = 0; v < 8; ++v)  // rows: over u
@@ -495,6 +497,9 @@ Image8 decodeJpeg(const uint8_t* data, size_t size) {
                 const int t = dc[c.td].decode(in);  // F.2.2.1
                 if (t > 11) fail("jpeg: bad DC size");
                 c.pred += extendSign(in.take(t), t);
+                // 8-bit samples: |DC| < 2^11 after quantisation (T.81 F.1.2.1); a forged stream must not walk the
+                // predictor towards INT_MAX one difference at a time
+                if (c.pred < -32768 || c.pred > 32767) fail("jpeg: DC out of range");
                 coef[0] = c.pred;
                 for (int k = 1; k < 64;) {  // F.2.2.2
                   const int rs = ac[c.ta].decode(in);

@@ -30,12 +30,32 @@ int main(int argc, char** argv) {
   const uint32_t width = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 500;  // S/main.cpp:17: 500x500 window
   const uint32_t height = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 500;
   const uint32_t spp = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 64;
+  // device list: decimal indices separated by single commas ("0", "0,1,2,3"; a repeated index = several shares on one
+  // GPU); anything else is a usage error, not "device 0"
   std::vector<int> devices;
-  for (const char* p = argc > 6 ? argv[6] : "0"; *p;) {
-    char* e;
-    devices.push_back((int)std::strtol(p, &e, 10));
-    p = (*e == ',') ? e + 1 : e;
-    if (e == p && *p) break;
+  {
+    const char* p = argc > 6 ? argv[6] : "0";
+    bool ok = *p != 0;
+    while (ok) {
+      if (*p < '0' || *p > '9') {
+        ok = false;
+        break;
+      }
+      char* e;
+      const long v = std::strtol(p, &e, 10);
+      if (e == p || v < 0 || v > 1023) {
+        ok = false;
+        break;
+      }
+      devices.push_back((int)v);
+      if (*e == 0) break;
+      if (*e != ',') ok = false;
+      p = e + 1;
+    }
+    if (!ok || devices.empty()) {
+      std::fprintf(stderr, "gsp_render: bad device list '%s' (expected e.g. 0 or 0,1,2,3)\n", argc > 6 ? argv[6] : "");
+      return 2;
+    }
   }
   try {
     Scene scene = loadScene(argv[1], "", options);

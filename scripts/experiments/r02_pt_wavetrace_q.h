@@ -1,3 +1,5 @@
+// (r02 experiment, rejected: DESIGN 4 "wave-level leaf queue".  Written against the r02 traversal (4-wide nodes with a
+// sort network); kept as a record, not built.)
 // pt_wavetrace_q.h -- EXPERIMENT, not part of the product build: the persistent traversal kernel of pt_wavetrace.h with a
 // wave-level leaf queue.  Built only as a variant (scripts/build_variant.sh q5 "-include pt_wavetrace_q.h -DGSP_LEAF_QUEUE
 // -DGSP_LDS_LEVELS=22 -DGSP_BLOCKS_PER_CU=5 -DGSP_TRACE_WAVES=5"): force-included ahead of pt_render.hip, it renames the

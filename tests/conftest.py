@@ -75,6 +75,17 @@ def staircase2_xml(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def coffee_xml(tmp_path_factory):
+    """The reference's 'Coffee Maker' scene (scene.xml + its OBJ meshes, CC-BY), unpacked from the committed archive."""
+    import tarfile
+
+    d = tmp_path_factory.mktemp("ref_coffee")
+    with tarfile.open(os.path.join(GOLDEN, "ref_scenes", "coffee.tar.xz")) as t:
+        t.extractall(str(d))
+    return os.path.join(str(d), "coffee", "scene.xml")
+
+
+@pytest.fixture(scope="session")
 def materials_scene():
     from gpuspectral_amd import scenes
 

@@ -395,3 +395,18 @@ def test_usable_cpus_respects_cgroup_quota(oracle_mod, monkeypatch, tmp_path):
 
     monkeypatch.setattr(builtins, "open", fake_open)
     assert oracle_mod.usable_cpus() == min(2, len(os.sched_getaffinity(0)))
+
+
+def test_cli_rejects_a_malformed_device_list(tmp_path):
+    """gsp_render's device list: digits separated by single commas.  Garbage used to render silently on device 0
+    (ADVICE r02); it is a usage error now, reported before anything touches a GPU."""
+    import subprocess
+
+    lib = os.path.join(ROOT, "gpuspectral_amd", "lib")
+    exe = os.path.join(lib, "gsp_render")
+    if not os.path.exists(exe):
+        pytest.skip("host CLI not built")
+    env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for bad in ("abc", "0,,1", "-1", "0,1x", "", ",0", "0,"):
+        r = subprocess.run([exe, CORNELL_XML, str(tmp_path / "x.pfm"), "8", "8", "1", bad], env=env, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "bad device list" in r.stderr, (bad, r.returncode, r.stderr)

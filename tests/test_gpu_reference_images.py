@@ -142,7 +142,7 @@ def test_staircase2_with_dormant_features_against_tungsten(staircase2_xml):
     assert np.abs(chroma - 1.0).max() < 0.12, np.abs(chroma - 1.0).max()
 
 
-def test_coffee_against_tungsten():
+def test_coffee_against_tungsten(coffee_xml):
     """'Coffee Maker' (168 199 triangles; smooth/rough plastic, dielectric glass, rough conductor).  The camera is pitched
     and the reference flips the ray's *world-space* y (raygen.rgen:25: d = toWorld * d; d.y *= -1), which displaces
     the image vertically against Tungsten's (measured: ~14 of 125 block rows), and the film is portrait while the
@@ -150,9 +150,14 @@ def test_coffee_against_tungsten():
     not by place: mean radiance of the orange plastic body (mask: r > 2 b + 0.05, 0.15 < r < 0.95) and of the grey
     backdrop beside it.  Measured (1024 spp): body (0.640, 0.137, 0.031) vs Tungsten (0.620, 0.150, 0.039); backdrop
     0.045 / 0.034 vs 0.056 / 0.041 (left / right edge, mid height)."""
-    from gpuspectral_amd import abi
+    from gpuspectral_amd import abi, host
 
-    sc = abi.SceneArrays.load(os.path.join(REF, "coffee.npz"))
+    # SURVEY 8(f).1 on the GPU box: the reference's own scene.xml + OBJ files through the product's C++ loader (r03; the
+    # flattened copy committed in r01 must be what it produces)
+    sc = host.Scene(coffee_xml).arrays()
+    cached = abi.SceneArrays.load(os.path.join(REF, "coffee.npz"))
+    assert sc.num_triangles == 168199 and np.array_equal(sc.positions, cached.positions) and np.array_equal(sc.instances, cached.instances)
+    assert all(np.array_equal(a, b) for a, b in zip(sc.bsdfs, cached.bsdfs)) and np.array_equal(sc.lights, cached.lights)
     ours = _render(sc, 800, 1000)
     t = np.load(os.path.join(REF, "tungsten_coffee.npz"))["lin"].astype(np.float64)
 
