@@ -39,6 +39,7 @@ namespace gsp {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kFirstSlot = 4;  // first triangle slot in use (>= the largest ni of a 4-wide node)
 
 // leaf of the BINARY tree (the build's intermediate form): ~((first slot << 2) | (count - 1)), count always 1
 __host__ __device__ __forceinline__ int32_t make_leaf(uint32_t first_slot, uint32_t count) {
@@ -125,9 +126,17 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     // accept.  It scales with the triangle's own extent as well as with its coordinates, so an
     // axis-aligned (flat) box at coordinate 0 is still padded.
     const float diag = fmaxf(h[0] - l[0], fmaxf(h[1] - l[1], h[2] - l[2]));
+    // Slivers (r03): the float32 triangle test loses accuracy in its t in proportion to (longest edge)^2 / area -- a
+    // 6.3 m x 2 mm bevel of the reference's living-room scene reports t 5e-4 short of where the ray meets it, 8 x the
+    // plain pad, so whether its box was still entered after a nearer hit, and with it which of two triangles won,
+    // depended on the visiting order (1 ray in 918 k).  The pad grows with that aspect ratio (1 up to aspect 32).
+    const f3 e3 = p2 - p1;
+    const float l2 = fmaxf(fmaxf(dot(e1, e1), dot(e2, e2)), dot(e3, e3));
+    const f3 cr = cross(e1, e2);
+    const float sliver = fminf(fmaxf(l2 / fmaxf(gsqrt(dot(cr, cr)), 1e-30f) * (1.0f / 32.0f), 1.0f), 1024.0f);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float pad = 1e-5f * fmaxf(fmaxf(fabsf(l[k]), fabsf(h[k])), fmaxf(diag, 1e-3f));
+      const float pad = 1e-5f * fmaxf(fmaxf(fabsf(l[k]), fabsf(h[k])), fmaxf(diag, 1e-3f)) * sliver;
       lo[k] = l[k] - pad;
       hi[k] = h[k] + pad;
     }
@@ -563,9 +572,11 @@ void free_bvh(DeviceBvh& b) {
 int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::string& err) {
   free_bvh(out);
   const uint32_t n = in.num_tris;
-  const uint32_t slots = n + 1;  // slot n is a degenerate all-zero triangle (det == 0: never hit): what the single
-                                  // node of an empty scene points at
+  // triangle slots are handed out from kFirstSlot on: a node's tri_base - ni (pt_trace.h) is then never negative and
+  // fits the 28 bits the traversal packs it into; the leading slots stay all-zero triangles (det == 0: never hit)
+  const uint32_t slots = n + kFirstSlot;
   out.num_tris = n;
+  out.first_slot = kFirstSlot;
   out.num_nodes = 0;
   size_t b_is = (size_t)slots * 48, b_sh = (size_t)slots * 64, b_map = (size_t)slots * 4;
   GSP_HIP_TRY(hipMalloc((void**)&out.tri_isect, b_is));
@@ -580,9 +591,9 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   if (n == 0) {  // one node without children: every ray misses
     q4 node[kNodeQuads];
 #if GSP_WIDE == 8
-    encode_node_w8(node, nullptr, 0u, 0u, 0u, 0u);
+    encode_node_w8(node, nullptr, 0u, 0u, 0u, kFirstSlot);
 #else
-    encode_node_w4(node, nullptr, 0, 0, 0u, 0u);
+    encode_node_w4(node, nullptr, 0, 0, 0u, kFirstSlot);
 #endif
     GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeBytes));
     GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
@@ -651,15 +662,15 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     c[0].lo = box[0];
     c[0].hi = box[1];
 #if GSP_WIDE == 8
-    encode_node_w8(node, c, 0u, 1u, 0u, 0u);
+    encode_node_w8(node, c, 0u, 1u, 0u, kFirstSlot);
 #else
-    encode_node_w4(node, c, 0, 1, 0u, 0u);
+    encode_node_w4(node, c, 0, 1, 0u, kFirstSlot);
 #endif
     GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeBytes));
     GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
-    GSP_HIP_TRY(hipMemcpyAsync(out.tri_isect, isect_m, 48, hipMemcpyDeviceToDevice, stream));
-    GSP_HIP_TRY(hipMemcpyAsync(out.tri_shade, shade_m, 64, hipMemcpyDeviceToDevice, stream));
-    GSP_HIP_TRY(hipMemcpyAsync(out.slot_to_global, s2g_m, 4, hipMemcpyDeviceToDevice, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(out.tri_isect + 3ull * kFirstSlot, isect_m, 48, hipMemcpyDeviceToDevice, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(out.tri_shade + 4ull * kFirstSlot, shade_m, 64, hipMemcpyDeviceToDevice, stream));
+    GSP_HIP_TRY(hipMemcpyAsync(out.slot_to_global + kFirstSlot, s2g_m, 4, hipMemcpyDeviceToDevice, stream));
     out.bytes += kNodeBytes;
     out.num_nodes = 1;
     GSP_HIP_TRY(hipStreamSynchronize(stream));
@@ -722,7 +733,8 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   q4* wide = nullptr;
   GSP_HIP_TRY(S.alloc(&wide, (size_t)kNodeQuads * n_int));
   int32_t *items_a = child_l, *items_b = child_r;  // (free again after the hierarchy pass)
-  uint32_t *n_inner = flag, *n_leaf = idx4, *inner_off, *leaf_off, *tri_src = vals_in;
+  uint32_t *n_inner = flag, *n_leaf = idx4, *inner_off, *leaf_off, *tri_src;
+  GSP_HIP_TRY(S.alloc(&tri_src, (size_t)n + kFirstSlot));
   GSP_HIP_TRY(S.alloc(&inner_off, n + 1ull));
   GSP_HIP_TRY(S.alloc(&leaf_off, n + 1ull));
   size_t scan_bytes = 0;
@@ -730,7 +742,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   void* scan_tmp = nullptr;
   GSP_HIP_TRY(S.alloc((char**)&scan_tmp, scan_bytes));
   GSP_HIP_TRY(hipMemcpyAsync(items_a, &root2, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  uint32_t count = 1, node_first = 0, tri_done = 0, levels = 0;
+  uint32_t count = 1, node_first = 0, tri_done = kFirstSlot, levels = 0;
   // 4-wide default: the parity collapse (children = grandchildren).  On PLOC trees it beats the greedy surface-area
   // collapse -- bench scene 14.7 vs 15.1 nodes per extension ray, 7.5 vs 9.2 per shadow ray (profiles/r03_collapse.txt;
   // the CPU probe agrees: 10.2 vs 10.4, 7.7 vs 8.3) -- while on top-down SAH trees it is the other way round.
@@ -758,7 +770,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       return GSP_ERR_DEVICE;
     }
   }
-  if (tri_done != n) {
+  if (tri_done != n + kFirstSlot) {
     err = "wide collapse lost triangles (internal error)";
     return GSP_ERR_DEVICE;
   }
@@ -772,8 +784,8 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
   out.bytes += b_nodes;
   GSP_HIP_TRY(hipMemcpyAsync(out.nodes, wide, b_nodes, hipMemcpyDeviceToDevice, stream));
-  hipLaunchKernelGGL(k_permute_tris, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, tri_src, isect_m, shade_m, s2g_m,
-                     out.tri_isect, out.tri_shade, out.slot_to_global);
+  hipLaunchKernelGGL(k_permute_tris, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, tri_src + kFirstSlot, isect_m, shade_m, s2g_m,
+                     out.tri_isect + 3ull * kFirstSlot, out.tri_shade + 4ull * kFirstSlot, out.slot_to_global + kFirstSlot);
   GSP_HIP_TRY(hipGetLastError());
   GSP_HIP_TRY(hipStreamSynchronize(stream));
   out.depth = levels;  // levels of the wide tree: a traversal stacks at most one node group per level

@@ -26,7 +26,8 @@ struct DeviceBvh {
   q4* tri_shade = nullptr;  // 4 quads per slot
   uint32_t* slot_to_global = nullptr;
   int32_t root = 0;
-  uint32_t num_tris = 0;   // real triangles (0 allowed; one dummy slot is still allocated)
+  uint32_t num_tris = 0;   // real triangles (0 allowed)
+  uint32_t first_slot = 0; // triangle slots in use: [first_slot, first_slot + num_tris); the leading ones are all-zero triangles
   uint32_t num_nodes = 0;
   uint32_t depth = 0;      // levels of the wide tree (bounds the traversal stack: <= 1 node group per level)
   size_t bytes = 0;

@@ -564,12 +564,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_
 
 // ---- per-slot texture coordinates (dormant-feature extension) -----------------------------------------------------
 // slot -> global triangle (BVH order) -> instance (tri_first is ascending) -> the instance's vertices in the uv array
-__global__ __launch_bounds__(kBlock) void k_gather_uv(uint32_t num_tris, const uint32_t* __restrict__ slot_to_global,
+__global__ __launch_bounds__(kBlock) void k_gather_uv(uint32_t num_tris, uint32_t first_slot, const uint32_t* __restrict__ slot_to_global,
                                                       const uint32_t* __restrict__ tri_first, uint32_t num_instances,
                                                       const gsp_instance* __restrict__ instances, const float* __restrict__ uvs,
                                                       float* __restrict__ tri_uv) {
-  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t s = blockIdx.x * kBlock + threadIdx.x;
   if (s >= num_tris) return;
+  s += first_slot;
   const uint32_t g = slot_to_global[s];
   uint32_t lo = 0, hi = num_instances;  // last instance with tri_first <= g
   while (hi - lo > 1) {
@@ -926,7 +927,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     }
     total_tris += in.vertex_count / 3;
   }
-  if (total_tris >= (1ull << 28)) {
+  if (total_tris >= (1ull << 28) - 16) {
     ctx->err = "too many triangles (limit 2^28)";
     return GSP_ERR_SCENE;
   }
@@ -1036,11 +1037,11 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     CTX_TRY(ctx, ctx->texel_decode.upload(decode, 256, st, &ctx->bytes));
     CTX_TRY(ctx, ctx->textures.upload(sc->textures, sc->num_textures, st, &ctx->bytes));
     CTX_TRY(ctx, ctx->texels.upload(sc->texels, sc->num_texels, st, &ctx->bytes));
-    CTX_TRY(ctx, ctx->tri_uv.ensure(8ull * std::max<uint64_t>(total_tris, 1), &ctx->bytes));
+    CTX_TRY(ctx, ctx->tri_uv.ensure(8ull * (total_tris + ctx->bvh.first_slot + 1), &ctx->bytes));
     if (total_tris) {
       CTX_TRY(ctx, d_uv.upload(sc->uvs, 2ull * sc->num_vertices, st, nullptr));
       hipLaunchKernelGGL(k_gather_uv, dim3((uint32_t)((total_tris + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (uint32_t)total_tris,
-                         ctx->bvh.slot_to_global, d_first.p, sc->num_instances, d_inst.p, d_uv.p, ctx->tri_uv.p);
+                         ctx->bvh.first_slot, ctx->bvh.slot_to_global, d_first.p, sc->num_instances, d_inst.p, d_uv.p, ctx->tri_uv.p);
       CTX_TRY(ctx, hipGetLastError());
     }
     CTX_TRY(ctx, hipStreamSynchronize(st));  // `decode` is a stack array

@@ -72,6 +72,10 @@ def lib():
         ]
         L.oracle_trace.restype = C.c_int
         L.oracle_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+        L.oracle_ray_log.argtypes = [C.c_int]
+        L.oracle_ray_log.restype = None
+        L.oracle_ray_log_read.argtypes = [C.c_void_p, C.c_uint64]
+        L.oracle_ray_log_read.restype = C.c_uint64
         L.oracle_primary_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.oracle_tea.restype = C.c_uint32
         L.oracle_tea.argtypes = [C.c_uint32, C.c_uint32]
@@ -141,6 +145,18 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle_render failed: %d" % rc)
         return accum, st.as_dict()
+
+    def extension_rays_of(self, width, height, spp=1, first_timestamp=0, pixel_ids=None, params=None):
+        """Debug aid: the extension rays {o, tmin, d, tmax} the oracle traces for this render, in trace order (one thread)."""
+        lib().oracle_ray_log(1)
+        try:
+            self.render(width, height, spp=spp, first_timestamp=first_timestamp, pixel_ids=pixel_ids, threads=1, params=params)
+            n = lib().oracle_ray_log_read(None, 0)
+            rays = np.zeros((n, 8), np.float32)
+            lib().oracle_ray_log_read(rays.ctypes.data, n)
+        finally:
+            lib().oracle_ray_log(0)
+        return rays
 
     def trace(self, rays, any_hit=False):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

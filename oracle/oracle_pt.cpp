@@ -129,8 +129,14 @@ static void buildAccel(const gsp_scene_desc& sc, Accel& A) {
     // accept; it scales with the triangle's extent as well as with its coordinates (flat boxes at
     // coordinate 0 are padded too)
     const float diag = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    // slivers: the float32 triangle test's t error grows like (longest edge)^2 / area, and the box must still hold what
+    // the test reports or the winner of two nearly coincident hits depends on the traversal order; the pad grows with
+    // that aspect ratio (the product pads the same way, gpuspectral_amd/csrc/pt_bvh.hip k_bake)
+    const vec3 e1 = b - a, e2 = c - a, e3 = c - b, cr = cross(e1, e2);
+    const float l2 = std::max(std::max(dot(e1, e1), dot(e2, e2)), dot(e3, e3));
+    const float sliver = std::min(std::max(l2 / std::max(std::sqrt(dot(cr, cr)), 1e-30f) * (1.0f / 32.0f), 1.0f), 1024.0f);
     for (int k = 0; k < 3; ++k) {
-      float pad = 1e-5f * std::max(std::max(std::fabs(lo[k]), std::fabs(hi[k])), std::max(diag, 1e-3f));
+      float pad = 1e-5f * std::max(std::max(std::fabs(lo[k]), std::fabs(hi[k])), std::max(diag, 1e-3f)) * sliver;
       cmin[3ull * i + k] = lo[k] - pad;
       cmax[3ull * i + k] = hi[k] + pad;
       cen[3ull * i + k] = 0.5f * (lo[k] + hi[k]);
@@ -529,6 +535,10 @@ static inline vec3 rayDirFn(float w, float h, float px, float py, float z) {
   return normalize(V(-x, y, z));
 }
 
+// Debug aid of the test infrastructure (oracle_ray_log): the extension rays of a render, in trace order, so that a GPU /
+// oracle disagreement on a path can be pinned to the ray that caused it (single-threaded renders only).
+static std::vector<float>* g_ray_log = nullptr;
+
 // raygen.rgen:29-82: one sample of one pixel; returns `result`
 static vec3 samplePixel(const SceneCtx& S, const RenderCfg& cfg, uint32_t px, uint32_t py, uint32_t timestamp,
                         float zplane, Counters& C, bool collect) {
@@ -552,6 +562,10 @@ static vec3 samplePixel(const SceneCtx& S, const RenderCfg& cfg, uint32_t px, ui
   while (true) {                                                           // :51
     prd.emitted = V(0.0f);
     C.extension_rays++;
+    if (g_ray_log) {
+      const float r[8] = {prd.origin.x, prd.origin.y, prd.origin.z, 0.0f, prd.direction.x, prd.direction.y, prd.direction.z, 1e10f};
+      g_ray_log->insert(g_ray_log->end(), r, r + 8);
+    }
     Hit h = closestHit(S.accel, prd.origin, prd.direction, 0.0f, 1e10f, collect ? &C.trav : nullptr);  // :53-58
     if (h.prim >= 0) {
       C.shaded_vertices++;
@@ -757,6 +771,19 @@ int oracle_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixe
     out->num_bvh_nodes = o->S.accel.nodes.size();
   }
   return 0;
+}
+
+// enable != 0: start logging the extension rays of single-threaded oracle_render calls; 0: stop and drop the log.
+// oracle_ray_log_read copies up to cap rays (8 floats each) and returns how many were logged.
+void oracle_ray_log(int enable) {
+  delete g_ray_log;
+  g_ray_log = enable ? new std::vector<float>() : nullptr;
+}
+uint64_t oracle_ray_log_read(float* out, uint64_t cap) {
+  if (!g_ray_log) return 0;
+  const uint64_t n = g_ray_log->size() / 8;
+  if (out) memcpy(out, g_ray_log->data(), sizeof(float) * 8 * std::min(n, cap));
+  return n;
 }
 
 // rays = n * {ox,oy,oz,tmin, dx,dy,dz,tmax}; hits = n * {t,u,v,prim}

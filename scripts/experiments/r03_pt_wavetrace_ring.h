@@ -1,0 +1,457 @@
+// (r03 experiment, rejected: profiles/r03_ab_triangle_ring.txt.  The wave kernel with a per-lane LDS ring of postponed triangle
+// groups; kept as a record, not built.)
+// pt_wavetrace.h -- persistent wave64 BVH traversal kernel (device only).
+//
+// The extend (closest hit), connect (any hit) and test-hook kernels are all this
+// one loop with a different ray source / result sink (`IO`).
+//
+// Why it looks like this (rocprofv3 PMC, profiles/r01_a_pmc_summary.txt and r01_b_*): the
+// first version (one ray per lane per grid-stride iteration) kept the VALU pipes ~85 % busy
+// with only ~17 % of the lanes enabled -- rays of very different length share a wave, and
+// lanes in a leaf wait for lanes in inner nodes.  The kernel is VALU-issue bound, so the
+// lever is lanes doing useful work per issued instruction.  Hence a flat, wave-uniform
+// state machine (every decision is a ballot + scalar branch, no divergent loops):
+//   * each lane owns a ray state {node group, the triangle group it is testing, a small ring of postponed triangle
+//     groups in LDS, stack}; per loop iteration the wave runs a few node steps for all lanes that have a child node to
+//     visit, and a leaf step (ONE triangle test per lane; longer groups stay pending) only when kLeafBatch lanes have
+//     triangles pending or nothing else can run -- triangle tests execute with many lanes enabled
+//     (leaf postponing after Aila & Laine 2009, re-tuned for 64 lanes; r03: a lane postpones up to
+//     1 + kTriQueue groups instead of two leaves, so it rarely stalls on its triangles and a leaf step finds more
+//     lanes with work);
+//   * lanes whose ray finished commit their result and are refilled from a wave-local pool
+//     as soon as kRefillLanes of them are idle; the pool takes 256-ray chunks from 8
+//     hand-out counters (one per blockIdx % 8 label = per XCD under round-robin placement;
+//     speed only), i.e. one atomic per 256 rays on a line no other XCD touches;
+//   * per-lane stack of node groups in LDS ([level][lane]: conflict-free) with an HBM spill region behind
+//     it; a node step pushes at most ONE entry (the rest of the group it descends from: r03, pt_trace.h), so the
+//     stack is as deep as the tree, not three times that; a sentinel at the bottom removes the empty-stack test.
+#pragma once
+#include "pt_trace.h"
+
+namespace gsp {
+
+constexpr int kTraceBlock = 256;
+#ifndef GSP_TRI_QUEUE
+#define GSP_TRI_QUEUE 4  // triangle groups a lane can hold back (beside the one it is testing) before it must wait for a leaf step
+#endif
+#ifndef GSP_LDS_LEVELS
+#define GSP_LDS_LEVELS (GSP_WIDE == 8 ? 10 - GSP_TRI_QUEUE : 20 - GSP_TRI_QUEUE)
+#endif
+#ifndef GSP_TRACE_WAVES
+#define GSP_TRACE_WAVES 7  // waves per SIMD the register allocator must allow (<= 72 VGPRs; 8 would spill)
+#endif
+constexpr int kStackWords = GSP_WIDE == 8 ? 2 : 1;   // 32-bit words per stack entry (one node group)
+constexpr int kLdsStackDepth = GSP_LDS_LEVELS;       // LDS levels (entries) per lane
+constexpr int kTriQueue = GSP_TRI_QUEUE;             // per-lane ring of postponed triangle groups in LDS (a power of two)
+static_assert(kTriQueue >= 1 && (kTriQueue & (kTriQueue - 1)) == 0 && kTriQueue <= 16, "GSP_TRI_QUEUE: 1, 2, 4, 8 or 16");
+#ifndef GSP_REFILL_LANES
+#define GSP_REFILL_LANES 16
+#endif
+#ifndef GSP_LEAF_BATCH
+#define GSP_LEAF_BATCH 20
+#endif
+#ifndef GSP_STALL_BATCH
+#define GSP_STALL_BATCH 8
+#endif
+#ifndef GSP_LEAF_BATCH_CLOSEST
+#define GSP_LEAF_BATCH_CLOSEST 32
+#endif
+#ifndef GSP_BATCH_COMMIT
+#define GSP_BATCH_COMMIT (ANY ? 32 : 24)
+#endif
+// 0: a lane waits for the leaf step as soon as it has triangles to test; 1: it keeps taking node steps and queues the
+// triangle groups they produce (up to kTriQueue of them) -- leaf steps then run with more lanes and node steps stall less
+#ifndef GSP_POSTPONE_ANY
+#define GSP_POSTPONE_ANY 1
+#endif
+#ifndef GSP_POSTPONE_CLOSEST
+#define GSP_POSTPONE_CLOSEST 1
+#endif
+constexpr int kRefillLanes = GSP_REFILL_LANES;  // idle lanes that trigger a refill
+constexpr int kLeafBatch = GSP_LEAF_BATCH;      // pending leaves that trigger a leaf step
+#ifndef GSP_CHUNK_LARGE
+#define GSP_CHUNK_LARGE 256
+#endif
+constexpr uint32_t kChunkLarge = GSP_CHUNK_LARGE;  // rays per hand-out (big queues)
+constexpr uint32_t kChunkSmall = 64;        // ... when the queue is small: one ray per lane, all waves busy
+constexpr int kWorkShards = 8;
+constexpr int kWorkStride = 32;             // counters sit on separate 128-B lines
+
+// Explicit address spaces: a generic pointer that may be LDS or HBM compiles to flat_load /
+// flat_store on every push and pop; with typed pointers the LDS levels are ds_read/ds_write.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+
+// the step table (pt_trace.h) in LDS
+struct LdsStepTable {
+  const __attribute__((address_space(3))) char* base;
+  __device__ __forceinline__ uint32_t operator()(uint32_t byte_off) const {
+#if GSP_WIDE == 8
+    return *(const lds_u8*)(base + byte_off);
+#else
+    return *(const lds_u16*)(base + byte_off);
+#endif
+  }
+};
+__device__ __forceinline__ void stage_step_table(uint32_t* lds_words, uint32_t tid, uint32_t threads) {
+  const uint32_t* src = (const uint32_t*)&kStepTable;
+  for (uint32_t i = tid; i < kStepTableBytes / 4; i += threads) lds_words[i] = src[i];
+}
+
+struct WaveStack {
+  lds_u32* lds;    // &lds_stack[threadIdx.x]; word L of this lane lives at lds + L * kTraceBlock
+  glb_u32* spill;  // &spill[global thread], stride spill_stride
+  uint32_t spill_stride;
+  // BYTE offset of the next free word from `lds` (word * kWordBytes): a push or pop is one add and a
+  // ds access with an immediate offset -- no per-access shifts (v_lshl_or_b32 issues at half the rate
+  // of v_add_u32 on this chip, profiles/r01_h_microbench/valu_rate.txt)
+  uint32_t sp;
+  static constexpr uint32_t kWordBytes = 4u * kTraceBlock;
+  static constexpr uint32_t kEntryBytes = kWordBytes * kStackWords;
+  static constexpr uint32_t kLdsBytes = (uint32_t)kLdsStackDepth * kEntryBytes;
+  __device__ __forceinline__ lds_u32* at(uint32_t off) const {
+    return (lds_u32*)((__attribute__((address_space(3))) char*)lds + off);
+  }
+  // Slow, per-lane form: LDS word or HBM spill word.
+  __device__ __forceinline__ void store_at(uint32_t off, uint32_t v) {
+    if (off < kLdsBytes) *at(off) = v;
+    else spill[(size_t)((off - kLdsBytes) / kWordBytes) * spill_stride] = v;
+  }
+  __device__ __forceinline__ uint32_t load_at(uint32_t off) {
+    uint32_t v;
+    if (off < kLdsBytes) v = *at(off);
+    else v = spill[(size_t)((off - kLdsBytes) / kWordBytes) * spill_stride];
+    return v;
+  }
+  // Hot path: the LDS-or-spill decision is taken once per wave (a ballot and a scalar branch);
+  // almost always every lane is inside the LDS levels and the access is a bare ds_read / ds_write.
+  __device__ __forceinline__ void push_group(uint32_t gb, uint32_t gs) {
+    if (__builtin_expect(__ballot(sp + kEntryBytes > kLdsBytes) == 0, 1)) {
+#if GSP_WIDE == 8
+      at(sp)[0] = gb;
+      at(sp)[kTraceBlock] = gs;
+#else
+      at(sp)[0] = (gb << 9) | gs;
+#endif
+    } else {
+#if GSP_WIDE == 8
+      store_at(sp, gb);
+      store_at(sp + kWordBytes, gs);
+#else
+      store_at(sp, (gb << 9) | gs);
+#endif
+    }
+    sp += kEntryBytes;
+  }
+  __device__ __forceinline__ void pop_group(uint32_t& gb, uint32_t& gs) {
+    sp -= kEntryBytes;
+#if GSP_WIDE == 8
+    if (__builtin_expect(__ballot(sp + kEntryBytes > kLdsBytes) == 0, 1)) {
+      gb = at(sp)[0];
+      gs = at(sp)[kTraceBlock];
+    } else {
+      gb = load_at(sp);
+      gs = load_at(sp + kWordBytes);
+    }
+#else
+    uint32_t e;
+    if (__builtin_expect(__ballot(sp >= kLdsBytes) == 0, 1)) e = at(sp)[0];
+    else e = load_at(sp);
+    gb = e >> 9;
+    gs = e & 511u;
+#endif
+  }
+};
+
+#ifdef GSP_WAVE_PROFILE
+// [0] node steps (per wave) [1] lanes enabled in them [2] leaf steps [3] lanes enabled [4] loop passes
+// [5] refill passes [6] lanes refilled [7] lanes idle (no ray) summed over node steps [8] lanes stalled (triangles pending, no node step possible) over node steps
+// [9] node steps after the hand-out ran dry [10] lanes enabled in them
+__device__ unsigned long long g_wave_profile[16];
+#endif
+struct TraceStatsOut {
+  unsigned long long* nodes;
+  unsigned long long* tris;
+  unsigned long long* rays;
+};
+
+// lanes set in a ballot, as a 32-bit scalar: comparing the 64-bit result of __popcll with a constant is compiled
+// to a VALU v_cmp_*_u64 on broadcast values (five of them per loop pass)
+__device__ __forceinline__ int wave_count(uint64_t m) {
+  return __builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// IO contract:
+//   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const;
+//   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux) const;   // h.slot < 0: miss / unoccluded;
+//                                                  aux = BSDF type of the accepted triangle
+//   static constexpr float kTmin, kTmax: >= 0 = every ray of this source has that bound (load() returns the same
+//                                                  value): the kernel keeps it out of the registers
+// Rays [first, n) of the queue are traced (first > 0: the leading entries carry memoised results, pt_render.hip).
+template <bool ANY, bool STATS, class IO>
+__global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
+                                                        const uint32_t* __restrict__ n_ptr,
+                                                        uint32_t n_imm, uint32_t first, uint32_t chunk, IO io,
+                                                        uint32_t* __restrict__ work,
+                                                        uint32_t* __restrict__ spill, uint32_t spill_stride,
+                                                        TraceStatsOut so) {
+  __shared__ uint32_t lds_stack[kLdsStackDepth * kStackWords * kTraceBlock];
+  __shared__ uint32_t lds_triq[kTriQueue * kStackWords * kTraceBlock];  // [entry][word][thread]: conflict-free like the stack
+  __shared__ uint32_t lds_table[kStepTableBytes / 4];
+  stage_step_table(lds_table, threadIdx.x, kTraceBlock);
+  __syncthreads();
+  const LdsStepTable tab{(const __attribute__((address_space(3))) char*)lds_table};
+  const uint32_t n = n_ptr ? *n_ptr : n_imm;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t shard = blockIdx.x % kWorkShards;
+  uint32_t* my_work = work + shard * kWorkStride;
+
+  WaveStack stk;
+  stk.lds = (lds_u32*)lds_stack + threadIdx.x;
+  stk.spill = (glb_u32*)spill + (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
+  stk.spill_stride = spill_stride;
+  stk.sp = 0;
+
+  // wave-uniform hand-out state
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+
+  // per-lane ray state: the node group being worked on {gb, gs}, the triangle group under test {tb, tm} and the ring of
+  // groups queued behind it: tq_w / tq_r count the groups written / read (entry = counter % kTriQueue); the lane takes no
+  // node step while the ring is full
+  uint32_t gb = 0, gs = no_group<ANY>(), tb = 0, tm = 0, tq_w = 0, tq_r = 0;
+  lds_u32* const triq = (lds_u32*)lds_triq + threadIdx.x;
+#if GSP_WIDE == 8
+#define GSP_TQ_PUT(slot, b, m) (triq[(slot) * 2 * kTraceBlock] = (b), triq[((slot) * 2 + 1) * kTraceBlock] = (m))
+#define GSP_TQ_GET(slot, b, m) ((b) = triq[(slot) * 2 * kTraceBlock], (m) = triq[((slot) * 2 + 1) * kTraceBlock])
+#else  // one word: tri_base - ni (< 2^28, never negative: the builder hands out triangle slots from 4 on) and 4 mask bits
+#define GSP_TQ_PUT(slot, b, m) (triq[(slot) * kTraceBlock] = ((b) << 4) | (m))
+#define GSP_TQ_GET(slot, b, m) ((m) = triq[(slot) * kTraceBlock], (b) = (m) >> 4, (m) &= 15u)
+#endif
+  uint32_t ri = 0xffffffffu, best_id = 0xffffffffu;  // best_id: p0.w of the closest hit so far (id << 3 | BSDF type)
+  RayBox rb = make_raybox(mk3(0, 0, 0), mk3(1, 1, 1));
+  RayShear rs;
+  rs.kx = rs.ky = rs.kz = 0;
+  rs.Sx = rs.Sy = rs.Sz = 0.0f;
+  float tmin_v = 0.0f, tmax_v = 0.0f;
+#define tmin (IO::kTmin >= 0.0f ? IO::kTmin : tmin_v)
+#define tmax (IO::kTmax >= 0.0f ? IO::kTmax : tmax_v)
+  HitRec h;
+  h.t = 0.0f;
+  h.u = h.v = 0.0f;
+  h.slot = -1;
+  uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
+
+#ifdef GSP_WAVE_PROFILE
+  unsigned long long wp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  for (;;) {
+#ifdef GSP_WAVE_PROFILE
+    ++wp[4];
+#endif
+    // ---- commit finished rays ------------------------------------------------------------
+    // batched like the refill: the commit path (for shadow rays: three loads, the firefly test, two stores) is
+    // issued for the whole wave, so it waits until enough lanes are out of work (A/B: any-hit kernel -13 % at 32,
+    // closest-hit -1.6 % at 24; 40+ starves the wave)
+    {
+      const bool pending = ri != 0xffffffffu && group_empty<ANY>(gs) && tris_empty(tm);
+      const uint64_t pend_m = __ballot(pending);
+      if (pend_m) {
+        const uint64_t out_m = pend_m | __ballot(ri == 0xffffffffu);
+        if (wave_count(out_m) >= GSP_BATCH_COMMIT || out_m == ~0ull) {
+          if (pending) {
+            io.store(ri, h, best_id & 7u);
+            ri = 0xffffffffu;
+          }
+        }
+      }
+    }
+    // ---- refill idle lanes from the wave-local pool -----------------------------------------
+    uint64_t idle_m = __ballot(ri == 0xffffffffu);
+    if (!exhausted && wave_count(idle_m) >= kRefillLanes) {
+#ifdef GSP_WAVE_PROFILE
+      ++wp[5];
+      wp[6] += __popcll(idle_m);
+#endif
+      while (idle_m) {  // wave-uniform
+        if (pool_next >= pool_end) {
+          uint32_t k = 0;
+          if (lane == 0) k = atomicAdd(my_work, 1u);
+          k = __shfl(k, 0);
+          const uint64_t start = ((uint64_t)k * kWorkShards + shard) * chunk + first;
+          if (start >= n) {
+            exhausted = true;
+            break;
+          }
+          pool_next = (uint32_t)start;
+          pool_end = (uint32_t)(start + chunk < n ? start + chunk : n);
+        }
+        // set bits of idle_m below this lane (v_mbcnt: no per-lane mask register)
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+        const uint32_t avail = pool_end - pool_next;
+        if (((idle_m >> lane) & 1ull) && rank < avail) {
+          ri = pool_next + rank;
+          f3 d;
+          f3 o;
+          io.load(ri, o, d, tmin_v, tmax_v);
+          rb = make_raybox(o, d);
+          rs = make_shear(d);
+          rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
+          h.t = tmax;
+          h.u = h.v = 0.0f;
+          h.slot = -1;
+          best_id = 0xffffffffu;
+          stk.sp = 0;
+          stk.push_group(0u, no_group<ANY>());  // sentinel: popping it leaves the lane without node work
+          gb = 0u;
+          gs = root_group<ANY>();
+          tm = 0u;
+          tq_r = tq_w;
+          if (STATS) ++c_rays;
+        }
+        const uint32_t want = (uint32_t)__popcll(idle_m);
+        pool_next += want < avail ? want : avail;
+        idle_m = __ballot(ri == 0xffffffffu);
+      }
+    }
+    // ---- what can run? -------------------------------------------------------------------------
+    // a lane takes a node step when it has a child node to visit and room for the triangle group the step may produce
+    constexpr bool kPostpone = (ANY ? GSP_POSTPONE_ANY : GSP_POSTPONE_CLOSEST) != 0;
+    const bool on_node = !group_empty<ANY>(gs) && (kPostpone ? tq_w - tq_r < (uint32_t)kTriQueue : tris_empty(tm));
+    const uint64_t node_m = __ballot(on_node);
+    const uint64_t leaf_m = __ballot(!tris_empty(tm));
+    if ((node_m | leaf_m) == 0) {
+      if (exhausted || idle_m == 0) break;  // nothing in flight and nothing left to hand out
+      continue;                             // (all lanes idle: the refill above runs next)
+    }
+    // ---- one node step for every lane that can take one ------------------------------------------
+    // closest hit: lanes that cannot advance without a leaf step (triangles pending, no node step possible)
+    // trigger it early; lanes that still descend can wait for a fuller batch
+    const uint64_t stall_m = leaf_m & ~node_m;
+    const bool leaf_step = (!ANY && wave_count(stall_m) >= GSP_STALL_BATCH) ||
+                           wave_count(leaf_m) >= (ANY ? kLeafBatch : GSP_LEAF_BATCH_CLOSEST) || node_m == 0;
+    if (node_m != 0 && !leaf_step) {
+      // measured on the 1M-triangle bench scene (scripts/ab_variants.sh): closest-hit 3 steps while >= 32 lanes
+      // are on inner nodes, any-hit 4 steps while >= 24 are (+3.6 % Mrays/s over 2 steps / 40 lanes)
+#ifndef GSP_NODE_REPS
+#define GSP_NODE_REPS (ANY ? 4 : 3)
+#endif
+#ifndef GSP_REP_LANES
+#define GSP_REP_LANES (ANY ? 24 : 32)
+#endif
+      // up to GSP_NODE_REPS node steps per pass through the bookkeeping above, as long as most
+      // lanes can still take one
+      for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
+        const bool on = !group_empty<ANY>(gs) && (kPostpone ? tq_w - tq_r < (uint32_t)kTriQueue : tris_empty(tm));
+        if (rep > 0 && wave_count(__ballot(on)) < GSP_REP_LANES) break;
+#ifdef GSP_WAVE_PROFILE
+        ++wp[0];
+        wp[1] += __popcll(__ballot(on));
+        wp[7] += __popcll(__ballot(ri == 0xffffffffu));
+        wp[8] += __popcll(__ballot(ri != 0xffffffffu && !on));
+        if (exhausted) {  // end game: the hand-out is empty, idle lanes stay idle
+          ++wp[9];
+          wp[10] += __popcll(__ballot(on));
+        }
+#endif
+        if (on) {
+          // the nearest child of the current group (32-bit offset + uniform base, no 64-bit address arithmetic)
+          const q4* nd = (const q4*)((const char*)nodes + group_next<ANY>(gb, gs, rb, tab));
+          q4 nq[kNodeQuads];
+#pragma unroll
+          for (uint32_t k = 0; k < kNodeQuads; ++k) nq[k] = nd[k];
+          if (STATS) ++c_nodes;
+          uint32_t ngb, ngs, ntb, ntm;
+          node_step<ANY>(nq, rb, tmin, h.t, tab, ngb, ngs, ntb, ntm);
+          if (!group_empty<ANY>(ngs)) {  // descend: the rest of the current group waits on the stack
+            if (!group_empty<ANY>(gs)) stk.push_group(gb, gs);
+            gb = ngb;
+            gs = ngs;
+          } else if (group_empty<ANY>(gs)) {
+            stk.pop_group(gb, gs);
+          }
+          if (!tris_empty(ntm)) {  // hit leaf children: postponed to a leaf step
+            if (tris_empty(tm)) {
+              tb = ntb;
+              tm = ntm;
+            } else {  // behind the group under test
+              const uint32_t e = tq_w & (uint32_t)(kTriQueue - 1);
+              GSP_TQ_PUT(e, ntb, ntm);
+              ++tq_w;
+            }
+          }
+        }
+      }
+      continue;
+    }
+    // ---- leaf step: one triangle test for every lane with a pending triangle group ---------------------
+#ifdef GSP_WAVE_PROFILE
+    ++wp[2];
+    wp[3] += __popcll(__ballot(!tris_empty(tm)));
+#endif
+    // one triangle per lane per step: a group with more triangles stays pending, so short groups do not idle
+    // while long ones finish and groups that arrive in between join the next step
+    if (!tris_empty(tm)) {
+      const uint32_t slot = tris_next(tb, tm);
+      bool stop = false;
+      {
+        const q4* p = tris + 3ll * slot;
+        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
+        if (STATS) ++c_tris;
+        float t, u, v;
+        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u,
+                          v)) {
+          if (ANY) {
+            h.t = t;
+            h.slot = (int32_t)slot;
+            stop = true;
+          } else {
+            const uint32_t id = __float_as_uint(p0.w);
+            if (t < h.t || (t == h.t && id < best_id)) {
+              h.t = t;
+              h.u = u;
+              h.v = v;
+              h.slot = (int32_t)slot;
+              best_id = id;
+            }
+          }
+        }
+      }
+      if (ANY && stop) {  // the ray is done
+        gs = no_group<ANY>();
+        tm = 0u;
+        tq_r = tq_w;
+      } else if (tris_empty(tm) && tq_r != tq_w) {  // the next queued group moves up
+        const uint32_t e = tq_r & (uint32_t)(kTriQueue - 1);
+        GSP_TQ_GET(e, tb, tm);
+        ++tq_r;
+      }
+    }
+  }
+#undef tmin
+#undef tmax
+#undef GSP_TQ_PUT
+#undef GSP_TQ_GET
+#ifdef GSP_WAVE_PROFILE
+  if (lane == 0 && !ANY)
+    for (int k = 0; k < 12; ++k) atomicAdd(&g_wave_profile[k], wp[k]);
+#endif
+  if (STATS) {
+    const unsigned long long a = wave_sum_u64(c_nodes), b = wave_sum_u64(c_tris), c = wave_sum_u64(c_rays);
+    if (lane == 0) {
+      atomicAdd(so.nodes, a);
+      atomicAdd(so.tris, b);
+      atomicAdd(so.rays, c);
+    }
+  }
+}
+
+}  // namespace gsp

@@ -288,6 +288,23 @@ def test_living_room_reference_scene(ctx, oracle_mod):
     ref, ost = o.render(W, H, spp=2)
     assert np.array_equal(img, ref) and not img[:, :3].any()  # no emitter the loader can load: black, as the reference's
     assert st["extension_rays"] == ost["extension_rays"] > 2 * W * H and st["shadow_rays"] == ost["shadow_rays"] == 0
+    # The path rays themselves (the image is black, so only the ray counts above would notice a wrong hit): every
+    # extension ray the oracle traced for this frame, in its order and in a shuffled one.  Until r03 ONE of these
+    # 918 614 rays had an order-dependent answer -- it meets a 6.3 m x 2 mm bevel whose float32 t comes out 5e-4 short,
+    # outside the triangle's padded box, so the bevel won or lost against the wall behind it depending on which was
+    # tested first (r02's kernel and the oracle disagreed); the boxes of slivers are padded by their aspect ratio now
+    # (pt_bvh.hip k_bake, oracle buildAccel) and the smaller float t wins in every order.
+    rays = o.extension_rays_of(W, H, spp=2)
+    assert len(rays) == ost["extension_rays"]
+    want = o.trace(rays)
+    got = ctx.trace(rays)
+    assert (got["prim"] == want["prim"]).all() and (got["t"] == want["t"])[want["prim"] >= 0].all()
+    perm = np.random.RandomState(5).permutation(len(rays))
+    again = ctx.trace(rays[perm])
+    assert (again["prim"] == got["prim"][perm]).all() and (again["t"] == got["t"][perm]).all()
+    sliver = np.array([[-0.8807780146598816, 0.00010001489135902375, -0.18816836178302765, 0.0,
+                        -0.6416327953338623, 0.45284968614578247, 0.6190593838691711, 1e10]], np.float32)
+    assert ctx.trace(sliver)["prim"][0] == o.trace(sliver)["prim"][0] == 295778
 
 
 @pytest.mark.parametrize("size", [(1, 1), (3, 2), (17, 5), (40, 23), (65, 31)])
