@@ -319,10 +319,11 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
     const bool leaf_step = (!ANY && wave_count(stall_m) >= GSP_STALL_BATCH) ||
                            wave_count(leaf_m) >= (ANY ? kLeafBatch : GSP_LEAF_BATCH_CLOSEST) || node_m == 0;
     if (node_m != 0 && !leaf_step) {
-      // measured on the 1M-triangle bench scene (scripts/ab_variants.sh): closest-hit 3 steps while >= 32 lanes
-      // are on inner nodes, any-hit 4 steps while >= 24 are (+3.6 % Mrays/s over 2 steps / 40 lanes)
+      // measured on the 1M-triangle bench scene: closest-hit 5 steps while >= 32 lanes can take one (r03: the node step
+      // lost its sort network, so the bookkeeping around it weighs more: 5 steps -2 % against 3,
+      // profiles/r03_ab_trace_thresholds.txt), any-hit 4 steps while >= 24 can
 #ifndef GSP_NODE_REPS
-#define GSP_NODE_REPS (ANY ? 4 : 3)
+#define GSP_NODE_REPS (ANY ? 4 : 5)
 #endif
 #ifndef GSP_REP_LANES
 #define GSP_REP_LANES (ANY ? 24 : 32)

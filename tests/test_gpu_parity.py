@@ -307,6 +307,29 @@ def test_living_room_reference_scene(ctx, oracle_mod):
     assert ctx.trace(sliver)["prim"][0] == o.trace(sliver)["prim"][0] == 295778
 
 
+@pytest.mark.parametrize("name", ["coffee", "staircase2", "interior", "caustics"])
+def test_path_rays_hit_the_same_triangle_in_any_order(ctx, oracle_mod, name):
+    """The rays paths actually shoot (the oracle's extension rays of a small frame: they start ON surfaces and graze
+    their neighbours, unlike random rays in a box), traced by the GPU in the oracle's order and in a shuffled one:
+    triangle and t must agree bit for bit, i.e. the closest hit is a function of the ray, not of the traversal."""
+    from conftest import GOLDEN
+    from gpuspectral_amd import abi, scenes
+
+    if name in ("coffee", "staircase2"):
+        sc = abi.SceneArrays.load(os.path.join(GOLDEN, "ref_scenes", name + ".npz"))
+    else:
+        sc = scenes.interior(150_000, seed=7) if name == "interior" else scenes.caustics(150_000, seed=11)
+    ctx.upload_scene(sc)
+    o = oracle_mod.Oracle(sc)
+    rays = o.extension_rays_of(200, 120, spp=2)
+    assert len(rays) > 2 * 200 * 120
+    want, got = o.trace(rays), ctx.trace(rays)
+    assert (got["prim"] == want["prim"]).all() and (got["t"] == want["t"])[want["prim"] >= 0].all()
+    perm = np.random.RandomState(9).permutation(len(rays))
+    again = ctx.trace(rays[perm])
+    assert (again["prim"] == got["prim"][perm]).all() and (again["t"] == got["t"][perm]).all()
+
+
 @pytest.mark.parametrize("size", [(1, 1), (3, 2), (17, 5), (40, 23), (65, 31)])
 def test_tiny_frames_and_small_queues(ctx, oracle_mod, materials_scene, size):
     """Queues of a handful to a few thousand rays: every hand-out shard of the persistent traversal
