@@ -361,12 +361,12 @@ def main():
         pmc, pmc_src = pmc_for_run(cfg_key, int(st["extend_launches"]), digest) if world == 1 else (None, "N > 1: counters are a single-GPU measurement")
         vertices = float(tot[8])
         ext = kernel_rates((pmc or {}).get("k_trace_extend"), ext_ms, launches, 32.0 * ext_traced0)
-        # k_trace<ConnectIO> streams the 32-B shadow ray in and 64 B of its record at the commit; k_shade streams the hit
+        # k_trace<ConnectIO> streams the 32-B shadow ray in and 16-20 B of its record at the commit; k_shade streams the hit
         # + the path record in (80 B per vertex)
-        con = kernel_rates((pmc or {}).get("k_trace_connect"), st["connect_kernel_ms"], launches, 96.0 * st["shadow_rays"])
+        con = kernel_rates((pmc or {}).get("k_trace_connect"), st["connect_kernel_ms"], launches, 50.0 * st["shadow_rays"])
         shd = kernel_rates((pmc or {}).get("k_shade"), st["shade_kernel_ms"], launches, 80.0 * vertices)
         # k_shade's compulsory queue traffic: hit + path record in, the survivor's record and the shadow record out
-        shade_bytes = 80.0 * vertices + 64.0 * max(0.0, st["extension_rays"] - samples) + 80.0 * st["shadow_rays"]
+        shade_bytes = 80.0 * vertices + 64.0 * max(0.0, st["extension_rays"] - samples) + 64.0 * st["shadow_rays"]
         shd["queue_bytes_per_vertex"] = shade_bytes / max(1.0, vertices)
         shd["queue_gbs"] = shade_bytes / (st["shade_kernel_ms"] * 1e-3) / 1e9 if st["shade_kernel_ms"] > 0 else None
         shd["queue_frac_of_hbm_peak"] = shd["queue_gbs"] / HBM_PEAK_GBS if shd["queue_gbs"] else None

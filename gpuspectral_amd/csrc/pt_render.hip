@@ -22,14 +22,16 @@
 //   P0 = {o.x, o.y, o.z, d.x}   P1 = {d.y, d.z, bits(seed), bits(sid)}
 //   P2 = {w.r, w.g, w.b, directWeight}   P3 = {sum.r, sum.g, sum.b, bits(flags)}
 //   HIT = {t, u, v, bits(slot)}
-//   S0 = {o.xyz, tmax}  S1 = {d.xyz, bits(sid)}  S2 = {nee.rgb, dw_nee}  S3 = {emis.rgb, bits(next)}
-//   S4 = {sum.rgb, bits(flags of the continuing path)}
+//   S0 = {o.xyz, tmax}  S1 = {d.xyz, bits(next)}  S2 = {sum if unoccluded .rgb, dw_nee}
+//   S3 = {sum if occluded .rgb, bits(flags of the continuing path | sample id of a path that ended)}
 // `sum` = the radiance the sample has collected so far (raygen.rgen:60-63 `result`).  It TRAVELS WITH THE PATH (r03): a
 // bounce adds to the copy it read with its path record and hands the new value to the continuing path's record, and
 // only the bounce that ends the path stores it in the sample-result ring.  Until r02 every bounce read-modify-wrote the
 // ring entry of its sample instead -- a scattered 16-B load on the dependent chain of k_trace<ConnectIO>'s commit
 // (three loads -> load -> add -> store), 26 % of that kernel's time (profiles/r03_ab_connect_ablation.txt).  The
-// additions per sample and their order are the same, so the images are.
+// additions per sample and their order are the same, so the images are.  The shadow record carries BOTH outcomes of
+// its bounce, formed by k_shade with connect_vertex itself: the commit of a shadow ray is one 16-B load of the outcome
+// that happened (+ 4 B) and its stores, no arithmetic.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -60,7 +62,6 @@ struct ShadowQueue {
   q4* S1;
   q4* S2;
   q4* S3;
-  q4* S4;
 };
 
 // Device counter words of a pipeline lane.  Two TAIL SETS of 32 words (one 128-B line each), used alternately by
@@ -152,7 +153,7 @@ struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
   static constexpr float kTmin = 0.0f, kTmax = 1e10f;
   PathQueue q;
   q4* hits;
-  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax, uint32_t& pay) const {
     const q4 p0 = q.P0[i], p1 = q.P1[i];
     o = mk3(p0.x, p0.y, p0.z);
     d = mk3(p0.w, p1.x, p1.y);
@@ -160,7 +161,7 @@ struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
     tmax = 1e10f;
   }
   // hit word: slot in bits 0..27, BSDF type of the hit triangle in bits 28..30; miss = all ones
-  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux) const {
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux, uint32_t) const {
     hits[i] = mkq(h.t, h.u, h.v, ub(h.slot < 0 ? 0xffffffffu : ((uint32_t)h.slot | ((aux & 7u) << 28))));
   }
 };
@@ -177,7 +178,7 @@ struct MemoIO {
   const uint32_t* pixel_ids;
   uint32_t lane, lanes;
   q4* memo;
-  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax, uint32_t& pay) const {
     const uint32_t lp = i * lanes + lane;
     PathState p;
     generate_path(rc, pixel_ids ? pixel_ids[lp] : lp, 0u, 0u, p);
@@ -186,7 +187,7 @@ struct MemoIO {
     tmin = 0.0f;
     tmax = 1e10f;
   }
-  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux) const {
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux, uint32_t) const {
     memo[i] = mkq(h.t, h.u, h.v, ub(h.slot < 0 ? 0xffffffffu : ((uint32_t)h.slot | ((aux & 7u) << 28))));
   }
 };
@@ -198,31 +199,30 @@ struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any h
   q4* next_P3;
   q4* result;
   float clampv;
-  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax, uint32_t& pay) const {
     const q4 s0 = sq.S0[i], s1 = sq.S1[i];
     o = mk3(s0.x, s0.y, s0.z);
     d = mk3(s1.x, s1.y, s1.z);
     tmin = 0.01f;
     tmax = s0.w;
+    pay = fb(s1.w);  // index of the continuing path in the next queue, or none: the commit needs it
   }
-  // The bounce's emitted radiance joins the sample's sum (`(0 + nee) + emis` behind the firefly test) and the sum moves
-  // on: into the continuing path's record, or -- the path ended at this vertex -- into the sample-result ring.  Four
-  // independent loads of the ray's own record and two or three stores; nothing is read back from where it is written.
-  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t) const {
-    const q4 s1 = sq.S1[i], s2 = sq.S2[i], s3 = sq.S3[i], s4 = sq.S4[i];
-    ShadowRay r;
-    r.nee = mk3(s2.x, s2.y, s2.z);
-    r.emis = mk3(s3.x, s3.y, s3.z);
-    q4 res = s4;
-    bool nee_done;
-    connect_vertex(clampv, r, h.slot >= 0, res, nee_done);
-    const uint32_t nx = fb(s3.w);
+  // The verdict picks which of the two sums k_shade prepared (`(0 + nee) + emis` or `0 + emis` added behind the firefly
+  // test, rayhit.rchit:750-754 + raygen.rgen:60-63) moves on: into the continuing path's record, or -- the path ended
+  // at this vertex -- into the sample-result ring.  One 16-B load of the ray's own record (+ 4 B when unoccluded) and
+  // one or two stores; nothing is read back from where it is written.
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t, uint32_t nx) const {
+    const bool occluded = h.slot >= 0;
+    q4 res = occluded ? sq.S3[i] : sq.S2[i];
+    const float dw = res.w;                                   // (unoccluded: directWeight of the continuing path)
+    if (!occluded) res.w = sq.S3[i].w;                        // flags of the continuing path | sample id
     if (nx != 0xffffffffu) {
-      next_P3[nx] = res;                          // (.w = the continuing path's flags, put there by k_shade)
-      if (nee_done) next_P2[nx].w = s2.w;         // rayhit.rchit:785-787
+      next_P3[nx] = res;
+      if (!occluded) next_P2[nx].w = dw;                      // rayhit.rchit:785-787
     } else {
+      const uint32_t sid = fb(res.w);
       res.w = 0.0f;
-      result[fb(s1.w)] = res;
+      result[sid] = res;
     }
   }
 };
@@ -234,14 +234,14 @@ struct TestIO {  // gsp_trace
   const uint32_t* slot_to_global;
   int any_hit;
   uint32_t num_tris;
-  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const {
+  __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax, uint32_t& pay) const {
     const float* r = rays + 8ull * i;
     o = mk3(r[0], r[1], r[2]);
     d = mk3(r[4], r[5], r[6]);
     tmin = r[3];
     tmax = r[7];
   }
-  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t) const {
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t, uint32_t) const {
     const bool hit = h.slot >= 0 && num_tris != 0;
     if (any_hit) hits[i] = mkq(0.0f, 0.0f, 0.0f, ub(hit ? 0u : 0xffffffffu));
     else hits[i] = hit ? mkq(h.t, h.u, h.v, ub(slot_to_global[h.slot])) : mkq(0.0f, 0.0f, 0.0f, ub(0xffffffffu));
@@ -453,11 +453,15 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     if (has_shadow) {
       const uint32_t s = s_base[1][wave] + (uint32_t)__popcll(sm & lt_mask);
       const ShadowRay& r = out.shadow;
+      // both outcomes of the bounce, by the function k_finish and the host harness apply once the verdict is known
+      q4 clear = sum, occ = sum;
+      bool nee_done;
+      connect_vertex(rc.clamp, r, false, clear, nee_done);
+      connect_vertex(rc.clamp, r, true, occ, nee_done);
       qst(&sq.S0[s], mkq(r.o.x, r.o.y, r.o.z, r.tmax));
-      qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(r.sid)));
-      qst(&sq.S2[s], mkq(r.nee.x, r.nee.y, r.nee.z, r.dw_nee));
-      qst(&sq.S3[s], mkq(r.emis.x, r.emis.y, r.emis.z, ub(alive ? j : 0xffffffffu)));
-      qst(&sq.S4[s], mkq(sum.x, sum.y, sum.z, ub(out.next.flags)));
+      qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(alive ? j : 0xffffffffu)));
+      qst(&sq.S2[s], mkq(clear.x, clear.y, clear.z, r.dw_nee));
+      qst(&sq.S3[s], mkq(occ.x, occ.y, occ.z, ub(alive ? out.next.flags : r.sid)));
     }
   }
   __syncthreads();
@@ -694,7 +698,7 @@ struct gsp_context {
     hipStream_t stream = nullptr;
     uint64_t num_pixels = 0;
     uint64_t pool_cap = 0, result_cap = 0;
-    DevBuf<q4> P0[2], P1[2], P2[2], P3[2], hits[2], result, S0, S1, S2, S3, S4;
+    DevBuf<q4> P0[2], P1[2], P2[2], P3[2], hits[2], result, S0, S1, S2, S3;
     DevBuf<q4> memo;          // primary-hit memo: one hit record per owned pixel of this lane
     bool memo_valid = false;  // ... traced for the current scene / camera / frame
     DevBuf<uint32_t> counters;
@@ -1127,7 +1131,6 @@ static int ensure_pool(gsp_context* ctx, gsp_context::Lane& L, uint64_t cap, uin
   CTX_TRY(ctx, L.S1.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S2.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S3.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, L.S4.ensure(cap, &ctx->bytes));
   L.pool_cap = cap;
   return GSP_OK;
 }
@@ -1183,7 +1186,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   hipEvent_t* ev = timing ? &L.ev[4 * t] : nullptr;
   PathQueue Q[2];
   for (int k = 0; k < 2; ++k) Q[k] = PathQueue{L.P0[k].p, L.P1[k].p, L.P2[k].p, L.P3[k].p};
-  ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p, L.S4.p};
+  ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p};
   const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
   const uint64_t n = P.n;  // exact, or an upper bound of what this iteration traces
@@ -1493,15 +1496,15 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
       {
         // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline
-        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  240 B of queues per
-        // path of capacity (2 x 64-B path records, 2 x 16-B hit, 80-B shadow record), capacity = 2 x the pool target.
+        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  224 B of queues per
+        // path of capacity (2 x 64-B path records, 2 x 16-B hit, 64-B shadow record), capacity = 2 x the pool target.
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          const uint64_t have = L.pool_cap * 240ull + L.result_cap * sizeof(q4);
+          const uint64_t have = L.pool_cap * 224ull + L.result_cap * sizeof(q4);
           const uint64_t budget = (uint64_t)((double)free_b * ctx->memory_share) + have;
-          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 240ull;
+          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 224ull;
           if (queues > budget / 2) {
-            const uint64_t fit = budget / 2 / 240ull;  // paths of capacity that fit
+            const uint64_t fit = budget / 2 / 224ull;  // paths of capacity that fit
             P.pool_target = std::max<uint64_t>(2 * P.batch_paths, fit > P.batch_paths ? (fit - P.batch_paths) / 2 : 0);
           }
           ring_bytes = std::min<uint64_t>(ring_bytes, std::max<uint64_t>(budget / 2, 4 * P.batch_paths * sizeof(q4)));

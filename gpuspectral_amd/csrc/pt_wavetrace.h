@@ -181,9 +181,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 // IO contract:
-//   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax) const;
-//   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux) const;   // h.slot < 0: miss / unoccluded;
-//                                                  aux = BSDF type of the accepted triangle
+//   __device__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax, uint32_t& pay) const;
+//   __device__ void store(uint32_t i, const HitRec& h, uint32_t aux, uint32_t pay) const;   // h.slot < 0: miss / unoccluded;
+//                                                  aux = BSDF type of the accepted triangle; pay = a word of the ray's
+//                                                  record that load() hands to store() through the traversal
 //   static constexpr float kTmin, kTmax: >= 0 = every ray of this source has that bound (load() returns the same
 //                                                  value): the kernel keeps it out of the registers
 // Rays [first, n) of the queue are traced (first > 0: the leading entries carry memoised results, pt_render.hip).
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
   // {tb, tm} (+ {tb2, tm2}: the lane stalls when both are taken)
   uint32_t gb = 0, gs = no_group<ANY>(), tb = 0, tm = 0, tb2 = 0, tm2 = 0;
   uint32_t ri = 0xffffffffu, best_id = 0xffffffffu;  // best_id: p0.w of the closest hit so far (id << 3 | BSDF type)
+  uint32_t pay = 0;                                   // (sources that do not use it leave no register behind)
   RayBox rb = make_raybox(mk3(0, 0, 0), mk3(1, 1, 1));
   RayShear rs;
   rs.kx = rs.ky = rs.kz = 0;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
         const uint64_t out_m = pend_m | __ballot(ri == 0xffffffffu);
         if (wave_count(out_m) >= GSP_BATCH_COMMIT || out_m == ~0ull) {
           if (pending) {
-            io.store(ri, h, best_id & 7u);
+            io.store(ri, h, best_id & 7u, pay);
             ri = 0xffffffffu;
           }
         }
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
           ri = pool_next + rank;
           f3 d;
           f3 o;
-          io.load(ri, o, d, tmin_v, tmax_v);
+          io.load(ri, o, d, tmin_v, tmax_v, pay);
           rb = make_raybox(o, d);
           rs = make_shear(d);
           rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
@@ -330,6 +332,9 @@ __global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4
 #endif
       // up to GSP_NODE_REPS node steps per pass through the bookkeeping above, as long as most
       // lanes can still take one
+#ifdef GSP_REPS_NOUNROLL
+#pragma nounroll
+#endif
       for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
         const bool on = !group_empty<ANY>(gs) && tris_empty(kPostpone ? tm2 : tm);
         if (rep > 0 && wave_count(__ballot(on)) < GSP_REP_LANES) break;
