@@ -26,6 +26,8 @@ def short(name):
         stats = "_stats" if re.search(r"k_trace<(false|true|\d), true", name) else ""
         return "k_trace_" + io + stats
     m = re.search(r"(k_[a-z_0-9]+)(<[a-z]+>)?", name)
+    if m and m.group(1) == "k_shade":  # <false> = the reference's path (what bench.py runs), <true> = textured scenes
+        return "k_shade" if (m.group(2) or "<false>") == "<false>" else "k_shade_tex"
     return (m.group(1) + (m.group(2) or "")) if m else name[:40]
 
 
