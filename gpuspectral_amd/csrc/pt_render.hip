@@ -765,7 +765,12 @@ struct gsp_context {
 #ifndef GSP_BLOCKS_PER_CU
 #define GSP_BLOCKS_PER_CU 7  // 7 x 22 KB LDS (stack + step table), 7 waves per SIMD (A/B: 5 -> -4 %, 6 -> -1 %, 8 spills)
 #endif
-  uint32_t max_blocks() const { return (uint32_t)num_cus * GSP_BLOCKS_PER_CU; }  // resident 256-thread blocks per CU
+#ifndef GSP_BLOCKS_PER_CU_ANY
+#define GSP_BLOCKS_PER_CU_ANY GSP_BLOCKS_PER_CU  // ... of the any-hit launches
+#endif
+  uint32_t max_blocks(bool any = false) const {  // resident 256-thread blocks of a k_trace launch
+    return (uint32_t)num_cus * (any ? GSP_BLOCKS_PER_CU_ANY : GSP_BLOCKS_PER_CU);
+  }
   uint32_t grid_for(uint64_t n) const {
     uint64_t b = (n + kBlock - 1) / kBlock;
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(b, max_blocks()));
@@ -773,17 +778,17 @@ struct gsp_context {
   // Rays are handed out in `chunk`-sized pieces from kWorkShards counters; chunk c belongs to shard
   // c % kWorkShards and only blocks with blockIdx % kWorkShards == shard serve it, so the grid must
   // hold a block for every shard that owns a chunk.
-  uint32_t trace_grid(uint64_t n, uint32_t chunk) const {
+  uint32_t trace_grid(uint64_t n, uint32_t chunk, bool any = false) const {
     const uint64_t chunks = (n + chunk - 1) / chunk;
     const uint64_t by_threads = (n + kTraceBlock - 1) / kTraceBlock;
     const uint64_t g = std::max<uint64_t>(by_threads, std::min<uint64_t>(chunks, kWorkShards));
-    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, max_blocks()));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(g, max_blocks(any)));
   }
   int ensure_spill() {
     // a descent pushes at most one node group per level of the wide tree (+ sentinel, slack)
     const uint32_t bound = bvh.depth + 2;
     const uint32_t need = (bound > (uint32_t)kLdsStackDepth ? bound - kLdsStackDepth : 1) * kStackWords;
-    spill_stride = max_blocks() * kBlock;
+    spill_stride = std::max(max_blocks(false), max_blocks(true)) * kBlock;
     for (uint32_t l = 0; l < num_lanes; ++l) GSP_HIP_TRY(lanes[l].spill.ensure((size_t)need * spill_stride, &bytes));
     return GSP_OK;
   }
@@ -1286,12 +1291,13 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       {
         const ConnectIO io{SQ, Q[cur ^ 1].P2, Q[cur ^ 1].P3, L.result.p, rcst.clamp};
         uint32_t* work = L.counters.p + C_WORK_SH;
+        const uint32_t grid_any = ctx->trace_grid(std::max<uint64_t>(n, 1), chunk, true);
         if (stats_mode)
-          hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+          hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid_any), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
                              (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, io, work, L.spill.p,
                              ctx->spill_stride, so_sh);
         else
-          hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
+          hipLaunchKernelGGL((k_trace<true, false, ConnectIO>), dim3(grid_any), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
                              (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, io, work, L.spill.p,
                              ctx->spill_stride, so_sh);
         CTX_TRY(ctx, hipGetLastError());
@@ -1709,7 +1715,7 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   const TestIO io{d_rays.p, d_hits.p, ctx->bvh.slot_to_global, any_hit, ctx->bvh.num_tris};
   const TraceStatsOut none{nullptr, nullptr, nullptr};
   if (any_hit)
-    hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
+    hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall, true)), dim3(kTraceBlock), 0, ctx->stream,
                        view.nodes, view.tri_isect, (const uint32_t*)nullptr, (uint32_t)n, 0u, kChunkSmall, io, d_work.p,
                        ctx->lanes[0].spill.p, ctx->spill_stride, none);
   else

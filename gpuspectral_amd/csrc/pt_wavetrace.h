@@ -33,6 +33,9 @@ constexpr int kTraceBlock = 256;
 #ifndef GSP_TRACE_WAVES
 #define GSP_TRACE_WAVES 7  // waves per SIMD the register allocator must allow (<= 72 VGPRs; 8 would spill)
 #endif
+#ifndef GSP_TRACE_WAVES_ANY
+#define GSP_TRACE_WAVES_ANY GSP_TRACE_WAVES  // ... of the any-hit instantiations (they keep no u, v, tie-break id)
+#endif
 constexpr int kStackWords = GSP_WIDE == 8 ? 2 : 1;   // 32-bit words per stack entry (one node group)
 constexpr int kLdsStackDepth = GSP_LDS_LEVELS;       // LDS levels (entries) per lane
 #ifndef GSP_REFILL_LANES
@@ -189,13 +192,15 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 //                                                  value): the kernel keeps it out of the registers
 // Rays [first, n) of the queue are traced (first > 0: the leading entries carry memoised results, pt_render.hip).
 template <bool ANY, bool STATS, class IO>
-__global__ __launch_bounds__(kTraceBlock, GSP_TRACE_WAVES) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
+__global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_WAVES) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
                                                         const uint32_t* __restrict__ n_ptr,
                                                         uint32_t n_imm, uint32_t first, uint32_t chunk, IO io,
                                                         uint32_t* __restrict__ work,
                                                         uint32_t* __restrict__ spill, uint32_t spill_stride,
                                                         TraceStatsOut so) {
   __shared__ uint32_t lds_stack[kLdsStackDepth * kStackWords * kTraceBlock];
+  static_assert((kLdsStackDepth * kStackWords * kTraceBlock * 4 + kStepTableBytes) * (ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_WAVES) <= 160 * 1024,
+                "LDS per block x resident blocks per CU exceeds 160 KB");
   __shared__ uint32_t lds_table[kStepTableBytes / 4];
   stage_step_table(lds_table, threadIdx.x, kTraceBlock);
   __syncthreads();
