@@ -169,6 +169,7 @@ class Stats(C.Structure):
         ("algorithmic_bytes", C.c_uint64),
         ("memoised_rays", C.c_uint64),
         ("memo_build_rays", C.c_uint64),
+        ("bvh_depth", C.c_uint64),
     ]
 
     def as_dict(self):

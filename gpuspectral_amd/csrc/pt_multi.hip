@@ -441,6 +441,7 @@ int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
       t.algorithmic_bytes += s.algorithmic_bytes;
       t.memoised_rays += s.memoised_rays;
       t.memo_build_rays += s.memo_build_rays;
+      t.bvh_depth = std::max(t.bvh_depth, s.bvh_depth);
       t.extend_launches += s.extend_launches;
       t.device_bytes += s.device_bytes;
       t.render_seconds = std::max(t.render_seconds, s.render_seconds);

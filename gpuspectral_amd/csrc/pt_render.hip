@@ -1672,6 +1672,7 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
   ctx->stats.num_triangles = ctx->bvh.num_tris;
   ctx->stats.num_bvh_nodes = ctx->bvh.num_nodes;
+  ctx->stats.bvh_depth = ctx->bvh.depth;
   ctx->stats.device_bytes = ctx->bytes;
   ctx->stats.algorithmic_bytes = 48ull * ctx->stats.stat_rays + (uint64_t)kNodeBytes * ctx->stats.nodes_visited + 48ull * ctx->stats.tris_tested +
                                  96ull * ctx->stats.shadow_stat_rays + (uint64_t)kNodeBytes * ctx->stats.shadow_nodes_visited +

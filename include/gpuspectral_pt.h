@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 4 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays */
+#define GSP_ABI_VERSION 4 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -265,6 +265,9 @@ typedef struct gsp_stats {
      GSP_PRIMARY_MEMO=0 turns the memo off. */
   uint64_t memoised_rays;
   uint64_t memo_build_rays;
+  uint64_t bvh_depth;        /* (ABI 4) levels of the wide BVH: a traversal stacks at most one entry per level; beyond the 20
+                                levels a lane keeps in LDS the stack continues in HBM, beyond 34 the tail of a drain is left
+                                to the wavefront kernels */
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;

@@ -513,6 +513,52 @@ def test_triangle_soup_hits_do_not_depend_on_bvh(ctx, oracle_mod):
     assert (g2["prim"] == r2["prim"]).all()
 
 
+def _nested_scene(n=520):
+    """Concentric, geometrically growing quads + boxes around one point: equal Morton codes and nested boxes make the
+    agglomerative build chain them up, so the BVH is far deeper than the 20 stack levels a lane keeps in LDS."""
+    from gpuspectral_amd import scenes
+
+    b = scenes.SceneBuilder()
+    rect, box = b.add_mesh(*scenes.rect_mesh()), b.add_mesh(*scenes.box_mesh())
+    white, mirror, glass = b.diffuse((0.7, 0.7, 0.7)), b.mirror(0.0), b.dielectric(1.5)
+    for k in range(n):
+        s = 0.004 * 1.01 ** k  # 4 mm ... 0.7 m
+        m = (white, mirror, glass)[k % 3]
+        b.add_object(rect if k % 2 else box, scenes.trs((0, 1, 0), s, 17.0 * k), m, twofaced=True)
+    b.add_object(box, scenes.trs((0.5, 2.6, 0.8), 0.2, 0.0), b.diffuse((0, 0, 0)), twofaced=False, emission=(15, 14, 12))
+    b.add_object(box, scenes.trs((0, 1, 0), (150, 150, 150)), white, twofaced=True)  # the room around it all
+    b.camera_lookat((0.3, 1.2, 4.0), (0, 1, 0), fov_deg=50)
+    return b.build()
+
+
+def test_deep_tree_runs_on_the_stack_spill_path(ctx, oracle_mod):
+    """A tree deeper than the LDS stack levels of k_trace (20) and than k_finish's stack (36): the per-lane stack continues
+    in HBM (slow path of WaveStack) and the drain is left to the wavefront kernels; rays, image and ray counts must still
+    equal the oracle's."""
+    sc = _nested_scene()
+    ctx.upload_scene(sc)
+    o = oracle_mod.Oracle(sc)
+    rng = np.random.RandomState(41)
+    rays = random_rays(150000, 41, lo=(-3, -2, -3), hi=(3, 4, 3))
+    aim = np.array([0, 1, 0], np.float32) - rays[:, 0:3] + rng.normal(scale=0.15, size=(len(rays), 3)).astype(np.float32)
+    rays[:, 4:7] = aim / np.linalg.norm(aim, axis=1, keepdims=True)  # through the nest, where the tree is deep
+    got, want = ctx.trace(rays), o.trace(rays)
+    assert (got["prim"] == want["prim"]).all() and (got["t"] == want["t"])[want["prim"] >= 0].all()
+    sh = rays.copy()
+    sh[:, 3], sh[:, 7] = 0.01, 3.0
+    assert ((ctx.trace(sh, any_hit=True)["prim"] >= 0) == (o.trace(sh, any_hit=True)["prim"] >= 0)).all()
+    W, H = 96, 64
+    ctx.frame_begin(W, H)
+    ctx.reset_stats()
+    ctx.render(spp=3)
+    img = ctx.download().reshape(-1, 4)
+    st = ctx.stats()
+    assert st["bvh_depth"] > 36, st["bvh_depth"]  # (else this test does not reach the paths it is about)
+    ref, ost = o.render(W, H, spp=3)
+    assert np.array_equal(img, ref)
+    assert st["extension_rays"] == ost["extension_rays"] and st["shadow_rays"] == ost["shadow_rays"]
+
+
 def test_two_pipeline_lanes_give_the_same_image(oracle_mod, materials_scene, monkeypatch):
     """GSP_LANES=2 deals the owned pixels to two independent pipelines on two streams; the per-pixel arithmetic
     is unchanged, so the frame, the ray counts and a pixel-subset context are bit-identical to one lane."""
