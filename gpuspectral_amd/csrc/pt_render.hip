@@ -1480,8 +1480,9 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     // order, once its live count has dropped to zero.
     // paths in flight over all lanes: per-launch fixed costs (drained wave tails, launch gaps) amortise over the pool
     // size -- r01 bench scan: 8 M 5.35, 12 M 5.76, 24 M 6.11, 48 M 6.16, 96 M 6.25 Grays/s; r02 (final kernels): 32 M 7.48,
-    // 48 M 7.63, 64 M 7.64 (profiles/r02_ab_pool_size.txt).  48 M paths: 22 GB of queues (capacity 2 x the target)
-    uint64_t total_target = 48ull << 20;
+    // 48 M 7.63, 64 M 7.64 (profiles/r02_ab_pool_size.txt); r03 (faster kernels, so the fixed cost per launch weighs more): 32 M 7.84,
+    // 48 M 7.98, 64 M 8.09, 96 M 8.24, 128 M 8.21 (profiles/r03_ab_pool_size.txt).  96 M paths: 43 GB of queues (capacity 2 x the target)
+    uint64_t total_target = 96ull << 20;
     if (const char* e = getenv("GSP_POOL_PATHS")) total_target = std::max<uint64_t>(1ull << 16, strtoull(e, nullptr, 10));
     for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
       gsp_context::Lane& L = ctx->lanes[l];
