@@ -60,6 +60,8 @@ def pmc_for_run(config, timed_launches, digest):
     import glob
 
     want = {k: config[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
+    if "primary_memo" in config:  # (the launches of a run without the primary-hit memo trace other ray sets)
+        want["primary_memo"] = config["primary_memo"]
     cands, stale = [], 0
     for path in sorted(glob.glob(PMC_GLOB)):
         try:
@@ -356,7 +358,7 @@ def main():
         ext_traced0 = st["extension_rays"] - st["memoised_rays"]  # rays rank 0's extend launches traced in the timed region
         alg_bytes = ext_traced0 * b_ray
         cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S,
-                   "steps": args.steps, "warmup": args.warmup}
+                   "steps": args.steps, "warmup": args.warmup, "primary_memo": bool(st["memoised_rays"] > 0)}
         digest = g.pt.build_info()["digest"]
         pmc, pmc_src = pmc_for_run(cfg_key, int(st["extend_launches"]), digest) if world == 1 else (None, "N > 1: counters are a single-GPU measurement")
         vertices = float(tot[8])
@@ -420,6 +422,7 @@ def main():
                 "collective": ("%s, %d rank(s), one gather of HDR tiles" % (dist.get_backend(), world)) if dist is not None else None,
                 "extension_rays": int(traced_ext),
                 "shadow_rays": int(sh_rays),
+                "primary_memo": bool(memoised > 0),
                 "memoised_rays": int(memoised),  # camera-ray segments copied from the primary-hit memo: NOT in `value`
                 "path_segments": int(ext_rays + sh_rays),  # what the reference traces for the same samples
                 "bvh_build_ms": st["bvh_build_ms"],

@@ -121,7 +121,7 @@ def main(root):
             continue
         if lines:
             b = json.loads(lines[-1])
-            out["bench_config"] = {k: b["config"][k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
+            out["bench_config"] = {k: b["config"][k] for k in ("workload", "triangles", "resolution", "spp_per_step", "primary_memo") if k in b["config"]}
             out["steps"], out["warmup"] = b["steps"], b["warmup"]
             out["timed_launches"] = b["roofline"]["launches"]
             out["library_digest"] = b["config"].get("library_digest")  # bench.py refuses the file for any other build
