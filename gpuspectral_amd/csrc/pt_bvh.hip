@@ -129,11 +129,15 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     // Slivers (r03): the float32 triangle test loses accuracy in its t in proportion to (longest edge)^2 / area -- a
     // 6.3 m x 2 mm bevel of the reference's living-room scene reports t 5e-4 short of where the ray meets it, 8 x the
     // plain pad, so whether its box was still entered after a nearer hit, and with it which of two triangles won,
-    // depended on the visiting order (1 ray in 918 k).  The pad grows with that aspect ratio (1 up to aspect 32).
+    // depended on the visiting order (1 ray in 918 k).  The pad grows with that aspect ratio (x 1 up to aspect 32, x 1024
+    // at most).
     const f3 e3 = p2 - p1;
     const float l2 = fmaxf(fmaxf(dot(e1, e1), dot(e2, e2)), dot(e3, e3));
     const f3 cr = cross(e1, e2);
-    const float sliver = fminf(fmaxf(l2 / fmaxf(gsqrt(dot(cr, cr)), 1e-30f) * (1.0f / 32.0f), 1.0f), 1024.0f);
+    // (a triangle thinner than 1e-6 of its length is a line at the precision of its own coordinates: nothing to protect,
+    // and 5 % of the reference's staircase2 scene is such triangles -- padding them cost it 9 % of its speed)
+    const float aspect = l2 / fmaxf(gsqrt(dot(cr, cr)), 1e-30f);
+    const float sliver = aspect < 1.0e6f ? fminf(fmaxf(aspect * (1.0f / 32.0f), 1.0f), 1024.0f) : 1.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const float pad = 1e-5f * fmaxf(fmaxf(fabsf(l[k]), fabsf(h[k])), fmaxf(diag, 1e-3f)) * sliver;

@@ -95,7 +95,8 @@ struct Emu {
         const float diag = std::max(h3[0] - l3[0], std::max(h3[1] - l3[1], h3[2] - l3[2]));
         const f3 e3 = p2 - p1, cr = cross(e1, e2);  // sliver factor, as k_bake (pt_bvh.hip)
         const float l2 = std::max(std::max(dot(e1, e1), dot(e2, e2)), dot(e3, e3));
-        const float sliver = std::min(std::max(l2 / std::max(gsqrt(dot(cr, cr)), 1e-30f) * (1.0f / 32.0f), 1.0f), 1024.0f);
+        const float aspect = l2 / std::max(gsqrt(dot(cr, cr)), 1e-30f);
+        const float sliver = aspect < 1.0e6f ? std::min(std::max(aspect * (1.0f / 32.0f), 1.0f), 1024.0f) : 1.0f;
         for (int c = 0; c < 3; ++c) {
           float pad = 1e-5f * std::max(std::max(std::fabs(l3[c]), std::fabs(h3[c])), std::max(diag, 1e-3f)) * sliver;
           glo.push_back(l3[c] - pad);
