@@ -553,7 +553,10 @@ def test_deep_tree_runs_on_the_stack_spill_path(ctx, oracle_mod):
     ctx.render(spp=3)
     img = ctx.download().reshape(-1, 4)
     st = ctx.stats()
-    assert st["bvh_depth"] > 36, st["bvh_depth"]  # (else this test does not reach the paths it is about)
+    from gpuspectral_amd import pt
+
+    wide8 = "GSP_WIDE=8" in pt.build_info()["flags"]  # (the A/B variant: 10 LDS levels, a shallower tree)
+    assert st["bvh_depth"] > (20 if wide8 else 36), st["bvh_depth"]  # (else this test does not reach the paths it is about)
     ref, ost = o.render(W, H, spp=3)
     assert np.array_equal(img, ref)
     assert st["extension_rays"] == ost["extension_rays"] and st["shadow_rays"] == ost["shadow_rays"]
