@@ -599,7 +599,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
 #else
     encode_node_w4(node, nullptr, 0, 0, 0u, kFirstSlot);
 #endif
-    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeBytes));
+    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeAllocMin));
     GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
     out.bytes += kNodeBytes;
     out.num_nodes = 1;
@@ -670,7 +670,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
 #else
     encode_node_w4(node, c, 0, 1, 0u, kFirstSlot);
 #endif
-    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeBytes));
+    GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeAllocMin));
     GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
     GSP_HIP_TRY(hipMemcpyAsync(out.tri_isect + 3ull * kFirstSlot, isect_m, 48, hipMemcpyDeviceToDevice, stream));
     GSP_HIP_TRY(hipMemcpyAsync(out.tri_shade + 4ull * kFirstSlot, shade_m, 64, hipMemcpyDeviceToDevice, stream));
@@ -785,7 +785,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   }
   out.num_nodes = num_nodes;
   const size_t b_nodes = (size_t)num_nodes * kNodeBytes;
-  GSP_HIP_TRY(hipMalloc((void**)&out.nodes, b_nodes));
+  GSP_HIP_TRY(hipMalloc((void**)&out.nodes, std::max<size_t>(b_nodes, kNodeAllocMin)));  // k_trace stages the first kTopNodes records
   out.bytes += b_nodes;
   GSP_HIP_TRY(hipMemcpyAsync(out.nodes, wide, b_nodes, hipMemcpyDeviceToDevice, stream));
   hipLaunchKernelGGL(k_permute_tris, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, tri_src + kFirstSlot, isect_m, shade_m, s2g_m,

@@ -71,6 +71,13 @@ struct HitRec {
 constexpr int kWide = GSP_WIDE;
 constexpr uint32_t kNodeQuads = kWide == 8 ? 5u : 4u;  // 16-B quads per node
 constexpr uint32_t kNodeBytes = 16u * kNodeQuads;
+// The first kTopNodes records of the node array (the tree is emitted level by level: the root and the levels under it)
+// are staged into LDS by every block of k_trace; the node buffer is allocated at least that long.
+#ifndef GSP_TOP_NODES
+#define GSP_TOP_NODES (GSP_WIDE == 8 ? 0 : 64)  // (the 8-wide A/B variant spends its LDS on two-word stack entries)
+#endif
+constexpr uint32_t kTopNodes = GSP_TOP_NODES;
+constexpr size_t kNodeAllocMin = (size_t)(kTopNodes > 0 ? kTopNodes : 1) * kNodeBytes;
 // child_base travels through the packed 32-bit stack entries of the 4-wide traversal in 23 bits
 constexpr uint32_t kMaxNodes = kWide == 8 ? (1u << 25) : (1u << 23);
 
@@ -129,6 +136,72 @@ GSP_HD bool intersect_tri(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t
   u = V * rcp;
   v = W * rcp;
   return t > tmin && t < tmax;
+}
+
+// The same test for the wave kernel's leaf step, restated for its instruction stream (same operations in the same
+// order on every accepted triangle, so the same t, u, v bit for bit):
+//  * no early exits: a wave runs the division whenever one of its lanes gets that far, so the branches buy nothing
+//    there, and every value a divergent block defines costs register copies at the joins (a rejected triangle may
+//    compute inf / NaN, which no comparison accepts);
+//  * the ray's axis permutation as two lane masks and full-rate bit selects (v_bitop3_b32) instead of 24 half-rate
+//    compares / conditional moves per triangle;
+//  * without make_shear's exchange of kx and ky for dz < 0: it negates U, V, W, det and T exactly (IEEE rounding is
+//    symmetric in sign) and leaves t = T / det, u = V / det, v = W / det and every sign test as they were -- it exists
+//    for back-face culling, which traceRayEXT runs without here (VulkanRays.cpp:91-118, cull disabled).
+struct RayShearRot {
+  uint32_t m0, m1;  // all ones where kz == 0 / kz == 1
+  float Sx, Sy, Sz;
+};
+GSP_HD float bit_select(uint32_t m, float a, float b) {  // m ? a : b, bitwise
+  uint32_t ua, ub;
+  __builtin_memcpy(&ua, &a, 4);
+  __builtin_memcpy(&ub, &b, 4);
+  const uint32_t r = (ua & m) | (ub & ~m);
+  float f;
+  __builtin_memcpy(&f, &r, 4);
+  return f;
+}
+// (x, y, z) -> (component kx, ky, kz) with kx = kz + 1, ky = kz + 2 (mod 3)
+GSP_HD f3 rotate_axes(const RayShearRot& rs, f3 p) {
+  return mk3(bit_select(rs.m0, p.y, bit_select(rs.m1, p.z, p.x)), bit_select(rs.m0, p.z, bit_select(rs.m1, p.x, p.y)),
+             bit_select(rs.m0, p.x, bit_select(rs.m1, p.y, p.z)));
+}
+// inv_dz = 1 / d[kz], correctly rounded (the traversal's RayBox holds it)
+GSP_HD RayShearRot make_shear_rot(f3 d) {
+  RayShearRot r;
+  const float ax = gabs(d.x), ay = gabs(d.y), az = gabs(d.z);
+  const int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);  // as make_shear
+  r.m0 = kz == 0 ? 0xffffffffu : 0u;
+  r.m1 = kz == 1 ? 0xffffffffu : 0u;
+  const f3 q = rotate_axes(r, d);
+  r.Sx = q.x / q.z;
+  r.Sy = q.y / q.z;
+  r.Sz = 1.0f / q.z;
+  return r;
+}
+GSP_HD bool intersect_tri_rot(f3 v0, f3 v1, f3 v2, f3 o, const RayShearRot& rs, float tmin, float tmax, float& t, float& u,
+                              float& v) {
+  const f3 A = rotate_axes(rs, v0 - o), B = rotate_axes(rs, v1 - o), C = rotate_axes(rs, v2 - o);
+  const float Ax = A.x - rs.Sx * A.z, Ay = A.y - rs.Sy * A.z;
+  const float Bx = B.x - rs.Sx * B.z, By = B.y - rs.Sy * B.z;
+  const float Cx = C.x - rs.Sx * C.z, Cy = C.y - rs.Sy * C.z;
+  float U = Cx * By - Cy * Bx;
+  float V = Ax * Cy - Ay * Cx;
+  float W = Bx * Ay - By * Ax;
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+  const bool neg = (U < 0.0f) | (V < 0.0f) | (W < 0.0f), pos = (U > 0.0f) | (V > 0.0f) | (W > 0.0f);
+  const float det = (U + V) + W;
+  const float Az = rs.Sz * A.z, Bz = rs.Sz * B.z, Cz = rs.Sz * C.z;
+  const float T = (U * Az + V * Bz) + W * Cz;
+  const float rcp = 1.0f / det;
+  t = T * rcp;
+  u = V * rcp;
+  v = W * rcp;
+  return !(neg & pos) & (det != 0.0f) & (t > tmin) & (t < tmax);
 }
 
 // min/max here are the NaN-dropping IEEE forms, so a NaN from 0*inf (origin on a slab plane, zero direction

@@ -28,7 +28,7 @@ namespace gsp {
 
 constexpr int kTraceBlock = 256;
 #ifndef GSP_LDS_LEVELS
-#define GSP_LDS_LEVELS (GSP_WIDE == 8 ? 10 : 20)
+#define GSP_LDS_LEVELS (GSP_WIDE == 8 ? 10 : (GSP_TOP_NODES > 0 ? 16 : 20))
 #endif
 #ifndef GSP_TRACE_WAVES
 #define GSP_TRACE_WAVES 7  // waves per SIMD the register allocator must allow (<= 72 VGPRs; 8 would spill)
@@ -77,6 +77,8 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(1))) uint32_t glb_u32;
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f_t lds_v4f;
 
 // the step table (pt_trace.h) in LDS
 struct LdsStepTable {
@@ -199,10 +201,15 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
                                                         uint32_t* __restrict__ spill, uint32_t spill_stride,
                                                         TraceStatsOut so) {
   __shared__ uint32_t lds_stack[kLdsStackDepth * kStackWords * kTraceBlock];
-  static_assert((kLdsStackDepth * kStackWords * kTraceBlock * 4 + kStepTableBytes) * (ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_WAVES) <= 160 * 1024,
+  static_assert((kLdsStackDepth * kStackWords * kTraceBlock * 4 + kStepTableBytes + kTopNodes * kNodeBytes) * (ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_WAVES) <= 160 * 1024,
                 "LDS per block x resident blocks per CU exceeds 160 KB");
   __shared__ uint32_t lds_table[kStepTableBytes / 4];
   stage_step_table(lds_table, threadIdx.x, kTraceBlock);
+  // the top of the tree: every ray starts there, and a fetch from LDS is not one of the divergent 16-B requests of which
+  // the vector-memory path takes one per cycle and CU (scripts/microbench/lane_fetch.hip) -- the rate both traversal
+  // kernels run at
+  __shared__ q4 lds_top[kTopNodes > 0 ? kTopNodes * kNodeQuads : 1];
+  for (uint32_t i = threadIdx.x; i < kTopNodes * kNodeQuads; i += kTraceBlock) lds_top[i] = nodes[i];
   __syncthreads();
   const LdsStepTable tab{(const __attribute__((address_space(3))) char*)lds_table};
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
@@ -226,8 +233,8 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   uint32_t ri = 0xffffffffu, best_id = 0xffffffffu;  // best_id: p0.w of the closest hit so far (id << 3 | BSDF type)
   uint32_t pay = 0;                                   // (sources that do not use it leave no register behind)
   RayBox rb = make_raybox(mk3(0, 0, 0), mk3(1, 1, 1));
-  RayShear rs;
-  rs.kx = rs.ky = rs.kz = 0;
+  RayShearRot rs;
+  rs.m0 = rs.m1 = 0u;
   rs.Sx = rs.Sy = rs.Sz = 0.0f;
   float tmin_v = 0.0f, tmax_v = 0.0f;
 #define tmin (IO::kTmin >= 0.0f ? IO::kTmin : tmin_v)
@@ -291,8 +298,8 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           f3 o;
           io.load(ri, o, d, tmin_v, tmax_v, pay);
           rb = make_raybox(o, d);
-          rs = make_shear(d);
-          rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
+          rs = make_shear_rot(d);
+          rs.Sz = rotate_axes(rs, rb.inv).z;  // = 1 / d[kz], the same correctly rounded quotient make_shear_rot computes
           h.t = tmax;
           h.u = h.v = 0.0f;
           h.slot = -1;
@@ -355,10 +362,20 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 #endif
         if (on) {
           // the nearest child of the current group (32-bit offset + uniform base, no 64-bit address arithmetic)
-          const q4* nd = (const q4*)((const char*)nodes + group_next<ANY>(gb, gs, rb, tab));
+          const uint32_t noff = group_next<ANY>(gb, gs, rb, tab);
           q4 nq[kNodeQuads];
+          if (kTopNodes > 0 && noff < kTopNodes * kNodeBytes) {
+            const lds_v4f* nd = (const lds_v4f*)((const __attribute__((address_space(3))) char*)lds_top + noff);
 #pragma unroll
-          for (uint32_t k = 0; k < kNodeQuads; ++k) nq[k] = nd[k];
+            for (uint32_t k = 0; k < kNodeQuads; ++k) {
+              const v4f_t q = nd[k];  // ds_read_b128
+              nq[k] = make_q4(q.x, q.y, q.z, q.w);
+            }
+          } else {
+            const q4* nd = (const q4*)((const char*)nodes + noff);
+#pragma unroll
+            for (uint32_t k = 0; k < kNodeQuads; ++k) nq[k] = nd[k];
+          }
           if (STATS) ++c_nodes;
           uint32_t ngb, ngs, ntb, ntm;
           node_step<ANY>(nq, rb, tmin, h.t, tab, ngb, ngs, ntb, ntm);
@@ -389,40 +406,46 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 #endif
     // one triangle per lane per step: a group with more triangles stays pending, so short groups do not idle
     // while long ones finish and groups that arrive in between join the next step
-    if (!tris_empty(tm)) {
-      const uint32_t slot = tris_next(tb, tm);
-      bool stop = false;
-      {
+    // Written without conditional blocks around the state: every update is a select on the variable's own register.
+    // (A divergent block that assigns loop-carried variables leaves the compiler with two copies of each -- the
+    // value before and after -- and the loop then moves them back and forth: 67 v_mov per leaf step, a third of
+    // its instructions.)  Only the loads sit under the lane's condition; their results are dead in the other lanes.
+    {
+      const bool act = !tris_empty(tm);
+      uint32_t tm_n = tm;
+      const uint32_t slot = tris_next(tb, tm_n);  // (tm == 0: some slot number, unused)
+      tm = act ? tm_n : tm;
+      float ax, ay, az, aw, bx, by, bz, cx, cy, cz;
+      asm("" : "=v"(ax), "=v"(ay), "=v"(az), "=v"(aw), "=v"(bx), "=v"(by), "=v"(bz), "=v"(cx), "=v"(cy), "=v"(cz));  // any value
+      if (act) {
         const q4* p = tris + 3ll * slot;
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
-        if (STATS) ++c_tris;
-        float t, u, v;
-        if (intersect_tri(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u,
-                          v)) {
-          if (ANY) {
-            h.t = t;
-            h.slot = (int32_t)slot;
-            stop = true;
-          } else {
-            const uint32_t id = __float_as_uint(p0.w);
-            if (t < h.t || (t == h.t && id < best_id)) {
-              h.t = t;
-              h.u = u;
-              h.v = v;
-              h.slot = (int32_t)slot;
-              best_id = id;
-            }
-          }
-        }
+        ax = p0.x, ay = p0.y, az = p0.z, aw = p0.w;
+        bx = p1.x, by = p1.y, bz = p1.z;
+        cx = p2.x, cy = p2.y, cz = p2.z;
       }
-      if (ANY && stop) {  // the ray is done
-        gs = no_group<ANY>();
-        tm = tm2 = 0u;
-      } else if (tris_empty(tm)) {  // the second group, if any, moves up
-        tb = tb2;
-        tm = tm2;
-        tm2 = 0u;
+      if (STATS) c_tris += act ? 1u : 0u;
+      float t, u, v;
+      const bool hit = act & intersect_tri_rot(mk3(ax, ay, az), mk3(bx, by, bz), mk3(cx, cy, cz), rb.o, rs, tmin, tmax, t, u, v);
+      if (ANY) {  // the first accepted triangle ends the ray
+        h.t = hit ? t : h.t;
+        h.slot = hit ? (int32_t)slot : h.slot;
+        gs = hit ? no_group<ANY>() : gs;
+        tm = hit ? 0u : tm;
+        tm2 = hit ? 0u : tm2;
+      } else {
+        const uint32_t id = __float_as_uint(aw);
+        const bool better = hit & ((t < h.t) | ((t == h.t) & (id < best_id)));
+        h.t = better ? t : h.t;
+        h.u = better ? u : h.u;
+        h.v = better ? v : h.v;
+        h.slot = better ? (int32_t)slot : h.slot;
+        best_id = better ? id : best_id;
       }
+      const bool up = act & tris_empty(tm);  // the second group, if any, moves up
+      tb = up ? tb2 : tb;
+      tm = up ? tm2 : tm;
+      tm2 = up ? 0u : tm2;
     }
   }
 #undef tmin

@@ -4,8 +4,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmcq_$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export GSP_LIB_PATH=$ROOT/$2
-timeout 150 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d $OUT/a -- python3 $ROOT/scripts/ab_probe.py > $OUT/a.log 2>&1 || echo pass a failed
-timeout 150 rocprofv3 --pmc SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/b -- python3 $ROOT/scripts/ab_probe.py > $OUT/b.log 2>&1 || echo pass b failed
+timeout 75 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d $OUT/a -- python3 $ROOT/scripts/ab_probe.py > $OUT/a.log 2>&1 || echo pass a failed
+timeout 75 rocprofv3 --pmc SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/b -- python3 $ROOT/scripts/ab_probe.py > $OUT/b.log 2>&1 || echo pass b failed
 python3 - <<PY
 import csv,glob,collections
 for ps in ("a","b"):
