@@ -650,6 +650,72 @@ int main(int argc, char** argv) {
     g_tbox[i].grow(g_tris[i].b);
     g_tbox[i].grow(g_tris[i].c);
   }
+  // SPLIT_GRID=G (r03): triangles larger than a cell of a G^3 grid over the scene's longest extent are entered once per
+  // cell they reach, each copy with the box of its clipped part (early split clipping): what does the tree gain?
+  const std::vector<Tri> orig_tris = g_tris;  // rays start on the triangles, not on their references
+  if (const char* sg = getenv("SPLIT_GRID")) {
+    const int G = atoi(sg);
+    Box sb;
+    for (size_t i = 0; i < n; ++i) sb.grow(g_tbox[i]);
+    const float ext = std::max(sb.hi.x - sb.lo.x, std::max(sb.hi.y - sb.lo.y, sb.hi.z - sb.lo.z));
+    const float cell = ext / G;
+    std::vector<Tri> nt;
+    std::vector<Box> nb;
+    size_t big = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const Box& b = g_tbox[i];
+      const float e = std::max(b.hi.x - b.lo.x, std::max(b.hi.y - b.lo.y, b.hi.z - b.lo.z));
+      if (G <= 0 || e <= cell) {
+        nt.push_back(g_tris[i]);
+        nb.push_back(b);
+        continue;
+      }
+      ++big;
+      int c0[3], c1[3];
+      for (int k = 0; k < 3; ++k) {
+        c0[k] = std::max(0, std::min(G - 1, (int)std::floor((comp(b.lo, k) - comp(sb.lo, k)) / cell)));
+        c1[k] = std::max(0, std::min(G - 1, (int)std::floor((comp(b.hi, k) - comp(sb.lo, k)) / cell)));
+      }
+      for (int cz = c0[2]; cz <= c1[2]; ++cz)
+        for (int cy = c0[1]; cy <= c1[1]; ++cy)
+          for (int cx = c0[0]; cx <= c1[0]; ++cx) {
+            const int cc[3] = {cx, cy, cz};
+            double poly[16][3], tmp[16][3];
+            int m = 3;
+            const V3 vv[3] = {g_tris[i].a, g_tris[i].b, g_tris[i].c};
+            for (int q = 0; q < 3; ++q) poly[q][0] = vv[q].x, poly[q][1] = vv[q].y, poly[q][2] = vv[q].z;
+            for (int k = 0; k < 3 && m > 0; ++k)
+              for (int side = 0; side < 2 && m > 0; ++side) {
+                const double plane = comp(sb.lo, k) + (double)cell * (cc[k] + side);
+                const double sgn = side ? -1.0 : 1.0;  // keep sgn * (x - plane) >= 0
+                int o = 0;
+                for (int q = 0; q < m; ++q) {
+                  const double* A = poly[q];
+                  const double* Bq = poly[(q + 1) % m];
+                  const double da = sgn * (A[k] - plane), db = sgn * (Bq[k] - plane);
+                  if (da >= 0) { tmp[o][0] = A[0]; tmp[o][1] = A[1]; tmp[o][2] = A[2]; ++o; }
+                  if ((da >= 0) != (db >= 0)) {
+                    const double t = da / (da - db);
+                    for (int c = 0; c < 3; ++c) tmp[o][c] = A[c] + t * (Bq[c] - A[c]);
+                    tmp[o][k] = plane;
+                    ++o;
+                  }
+                }
+                m = o;
+                for (int q = 0; q < m; ++q) for (int c = 0; c < 3; ++c) poly[q][c] = tmp[q][c];
+              }
+            if (m < 3) continue;
+            Box cb;
+            for (int q = 0; q < m; ++q) cb.grow(V3{(float)poly[q][0], (float)poly[q][1], (float)poly[q][2]});
+            nt.push_back(g_tris[i]);
+            nb.push_back(cb);
+          }
+    }
+    printf("SPLIT_GRID %d: %zu of %zu triangles larger than a cell -> %zu references\n", G, big, n, nt.size());
+    g_tris.swap(nt);
+    g_tbox.swap(nb);
+    n = g_tris.size();
+  }
   std::vector<int> idx(n);
   for (size_t i = 0; i < n; ++i) idx[i] = (int)i;
   g_bin.reserve(2 * n);
@@ -663,17 +729,18 @@ int main(int argc, char** argv) {
   std::uniform_real_distribution<float> U(0.0f, 1.0f);
   std::vector<Ray> rays;
   // area-weighted triangle choice
-  std::vector<double> cdf(n);
+  const size_t on = orig_tris.size();
+  std::vector<double> cdf(on);
   double acc = 0;
-  for (size_t i = 0; i < n; ++i) {
-    V3 c = cross(g_tris[i].b - g_tris[i].a, g_tris[i].c - g_tris[i].a);
+  for (size_t i = 0; i < on; ++i) {
+    V3 c = cross(orig_tris[i].b - orig_tris[i].a, orig_tris[i].c - orig_tris[i].a);
     acc += 0.5 * std::sqrt((double)dot(c, c));
     cdf[i] = acc;
   }
   while ((int)rays.size() < nrays) {
     size_t ti = std::lower_bound(cdf.begin(), cdf.end(), U(rng) * acc) - cdf.begin();
-    if (ti >= n) ti = n - 1;
-    const Tri& t = g_tris[ti];
+    if (ti >= on) ti = on - 1;
+    const Tri& t = orig_tris[ti];
     float u = U(rng), v = U(rng);
     if (u + v > 1) u = 1 - u, v = 1 - v;
     V3 p = t.a + (t.b - t.a) * u + (t.c - t.a) * v;
