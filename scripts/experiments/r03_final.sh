@@ -16,6 +16,6 @@ find gpurun_out/pmc_r03_s4_w1/trace -name "*kernel_stats.csv" -exec cp {} $O/ker
 find gpurun_out/pmc_r03_s20_w5/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_s20_w5.csv \;
 # the 8-wide variant and r02's library on the same box, for the record (profiles/r03_ab_wide_bvh.txt section 7)
 V=$PWD/gpuspectral_amd/lib/variants
-( for i in 1 2 3; do for v in current r02 w8_6; do echo -n "$v: "; if [ $v = current ]; then timeout 300 python scripts/ab_probe.py 2>&1 | tail -1; else GSP_LIB_PATH=$V/$v.so timeout 300 python scripts/ab_probe.py 2>&1 | tail -1; fi; done; done ) > $O/ab_final.txt 2>&1
+( for i in 1 2 3; do for v in current base r02 w8_6; do echo -n "$v: "; if [ $v = current ]; then timeout 300 python scripts/ab_probe.py 2>&1 | tail -1; else GSP_LIB_PATH=$V/$v.so timeout 300 python scripts/ab_probe.py 2>&1 | tail -1; fi; done; done ) > $O/ab_final.txt 2>&1
 GSP_LIB_PATH=$V/w8_6.so timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "not cli and not cpp_host" 2>&1 | tail -2 > $O/parity_w8.txt
 cat $O/gputest.txt; tail -3 $O/smoke.txt; cut -c1-400 $O/bench_n1.json; cat $O/ab_final.txt $O/parity_w8.txt
