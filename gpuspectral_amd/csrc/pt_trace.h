@@ -143,13 +143,11 @@ GSP_HD bool intersect_tri(f3 v0, f3 v1, f3 v2, f3 o, const RayShear& rs, float t
 //  * no early exits: a wave runs the division whenever one of its lanes gets that far, so the branches buy nothing
 //    there, and every value a divergent block defines costs register copies at the joins (a rejected triangle may
 //    compute inf / NaN, which no comparison accepts);
-//  * the ray's axis permutation as two lane masks and full-rate bit selects (v_bitop3_b32) instead of 24 half-rate
-//    compares / conditional moves per triangle;
-//  * without make_shear's exchange of kx and ky for dz < 0: it negates U, V, W, det and T exactly (IEEE rounding is
-//    symmetric in sign) and leaves t = T / det, u = V / det, v = W / det and every sign test as they were -- it exists
-//    for back-face culling, which traceRayEXT runs without here (VulkanRays.cpp:91-118, cull disabled).
+//  * the ray's axis permutation -- make_shear's (kx, ky, kz), the exchange of kx and ky for dz < 0 included, so that even the
+//    sign of a zero u or v is the oracle's -- as three lane masks and full-rate bit selects (v_bitop3_b32) instead of 24
+//    half-rate compares / conditional moves per triangle.
 struct RayShearRot {
-  uint32_t m0, m1;  // all ones where kz == 0 / kz == 1
+  uint32_t m0, m1, ms;  // all ones where kz == 0 / kz == 1 / d[kz] < 0
   float Sx, Sy, Sz;
 };
 GSP_HD float bit_select(uint32_t m, float a, float b) {  // m ? a : b, bitwise
@@ -161,10 +159,10 @@ GSP_HD float bit_select(uint32_t m, float a, float b) {  // m ? a : b, bitwise
   __builtin_memcpy(&f, &r, 4);
   return f;
 }
-// (x, y, z) -> (component kx, ky, kz) with kx = kz + 1, ky = kz + 2 (mod 3)
-GSP_HD f3 rotate_axes(const RayShearRot& rs, f3 p) {
-  return mk3(bit_select(rs.m0, p.y, bit_select(rs.m1, p.z, p.x)), bit_select(rs.m0, p.z, bit_select(rs.m1, p.x, p.y)),
-             bit_select(rs.m0, p.x, bit_select(rs.m1, p.y, p.z)));
+// (x, y, z) -> (component kx, ky, kz): kz by the masks, kx = kz + 1, ky = kz + 2 (mod 3), exchanged where ms is set
+GSP_HD f3 permute_axes(const RayShearRot& rs, f3 p) {
+  const float a = bit_select(rs.m0, p.y, bit_select(rs.m1, p.z, p.x)), b = bit_select(rs.m0, p.z, bit_select(rs.m1, p.x, p.y));
+  return mk3(bit_select(rs.ms, b, a), bit_select(rs.ms, a, b), bit_select(rs.m0, p.x, bit_select(rs.m1, p.y, p.z)));
 }
 // inv_dz = 1 / d[kz], correctly rounded (the traversal's RayBox holds it)
 GSP_HD RayShearRot make_shear_rot(f3 d) {
@@ -173,7 +171,8 @@ GSP_HD RayShearRot make_shear_rot(f3 d) {
   const int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);  // as make_shear
   r.m0 = kz == 0 ? 0xffffffffu : 0u;
   r.m1 = kz == 1 ? 0xffffffffu : 0u;
-  const f3 q = rotate_axes(r, d);
+  r.ms = comp(d, kz) < 0.0f ? 0xffffffffu : 0u;
+  const f3 q = permute_axes(r, d);
   r.Sx = q.x / q.z;
   r.Sy = q.y / q.z;
   r.Sz = 1.0f / q.z;
@@ -181,7 +180,7 @@ GSP_HD RayShearRot make_shear_rot(f3 d) {
 }
 GSP_HD bool intersect_tri_rot(f3 v0, f3 v1, f3 v2, f3 o, const RayShearRot& rs, float tmin, float tmax, float& t, float& u,
                               float& v) {
-  const f3 A = rotate_axes(rs, v0 - o), B = rotate_axes(rs, v1 - o), C = rotate_axes(rs, v2 - o);
+  const f3 A = permute_axes(rs, v0 - o), B = permute_axes(rs, v1 - o), C = permute_axes(rs, v2 - o);
   const float Ax = A.x - rs.Sx * A.z, Ay = A.y - rs.Sy * A.z;
   const float Bx = B.x - rs.Sx * B.z, By = B.y - rs.Sy * B.z;
   const float Cx = C.x - rs.Sx * C.z, Cy = C.y - rs.Sy * C.z;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   uint32_t pay = 0;                                   // (sources that do not use it leave no register behind)
   RayBox rb = make_raybox(mk3(0, 0, 0), mk3(1, 1, 1));
   RayShearRot rs;
-  rs.m0 = rs.m1 = 0u;
+  rs.m0 = rs.m1 = rs.ms = 0u;
   rs.Sx = rs.Sy = rs.Sz = 0.0f;
   float tmin_v = 0.0f, tmax_v = 0.0f;
 #define tmin (IO::kTmin >= 0.0f ? IO::kTmin : tmin_v)
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           io.load(ri, o, d, tmin_v, tmax_v, pay);
           rb = make_raybox(o, d);
           rs = make_shear_rot(d);
-          rs.Sz = rotate_axes(rs, rb.inv).z;  // = 1 / d[kz], the same correctly rounded quotient make_shear_rot computes
+          rs.Sz = permute_axes(rs, rb.inv).z;  // = 1 / d[kz], the same correctly rounded quotient make_shear_rot computes
           h.t = tmax;
           h.u = h.v = 0.0f;
           h.slot = -1;

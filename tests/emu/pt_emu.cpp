@@ -435,6 +435,30 @@ void emu_det_math(const float* x, uint64_t n, float* s, float* c, float* lg, flo
     ex[i] = det_expf(x[i]);
   }
 }
+// The two statements of the watertight triangle test (pt_trace.h): intersect_tri as the oracle states it (per-ray axis
+// permutation with the kx / ky exchange, early exits) and intersect_tri_rot as k_trace's leaf step runs it (axes selected by two
+// lane masks, no exchange, straight-line).  rays: n x {o.xyz, d.xyz, tmin, tmax}, tris: n x 9; out: n x {hit, t, u, v} twice.
+void emu_tri_tests(const float* rays, const float* tris, uint64_t n, float* out_ref, float* out_rot) {
+  for (uint64_t i = 0; i < n; ++i) {
+    const float* r = rays + 8 * i;
+    const float* p = tris + 9 * i;
+    const f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+    const f3 v0 = mk3(p[0], p[1], p[2]), v1 = mk3(p[3], p[4], p[5]), v2 = mk3(p[6], p[7], p[8]);
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    const RayShear rs = make_shear(d);
+    const bool h0 = intersect_tri(v0, v1, v2, o, rs, r[6], r[7], t, u, v);
+    out_ref[4 * i + 0] = h0 ? 1.0f : 0.0f;
+    out_ref[4 * i + 1] = h0 ? t : 0.0f;
+    out_ref[4 * i + 2] = h0 ? u : 0.0f;
+    out_ref[4 * i + 3] = h0 ? v : 0.0f;
+    const RayShearRot rr = make_shear_rot(d);
+    const bool h1 = intersect_tri_rot(v0, v1, v2, o, rr, r[6], r[7], t, u, v);
+    out_rot[4 * i + 0] = h1 ? 1.0f : 0.0f;
+    out_rot[4 * i + 1] = h1 ? t : 0.0f;
+    out_rot[4 * i + 2] = h1 ? u : 0.0f;
+    out_rot[4 * i + 3] = h1 ? v : 0.0f;
+  }
+}
 void emu_transform_inv_t(const float* m, float* out) {
   float tr[16];
   transpose4(m, tr);

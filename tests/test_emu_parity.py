@@ -130,3 +130,43 @@ def test_emu_deterministic_math_and_inverse(emu, oracle_mod, cornell):
         emu.L.emu_transform_inv_t(m.ctypes.data, out.ctypes.data)
         assert np.array_equal(out, oracle_mod.transform_inv_t(m))
     assert emu.L.emu_seed(128, 5, 9, 3) == oracle_mod.pcg_hash(oracle_mod.tea(128 * 9 + 5, 3))
+
+
+def test_leaf_step_triangle_test_equals_the_oracle_statement(emu):
+    """k_trace's leaf step runs the watertight test as straight-line code with the ray's axis permutation applied through two
+    lane masks and without make_shear's kx / ky exchange (pt_trace.h intersect_tri_rot).  Same verdict and the same t, u, v bit
+    for bit as the oracle's statement (intersect_tri) -- for rays of every dominant axis and sign, rays through shared edges and
+    vertices (the double-precision fallback), axis-parallel rays, degenerate and far-away triangles."""
+    rng = np.random.RandomState(77)
+    n = 400000
+    tris = rng.uniform(-2, 2, (n, 9)).astype(np.float32)
+    tris[: n // 8] *= np.float32(1e-3)  # tiny
+    tris[n // 8: n // 4] += np.float32(1e4)  # far from the origin
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    k = rng.randint(0, 4, n)
+    bary = rng.dirichlet((1, 1, 1), n).astype(np.float32)
+    bary[k == 1] = np.eye(3, dtype=np.float32)[rng.randint(0, 3, (k == 1).sum())]  # through a vertex
+    e = k == 2
+    bary[e, 2] = 0
+    bary[e, 0] = rng.uniform(0, 1, e.sum()).astype(np.float32)
+    bary[e, 1] = np.float32(1) - bary[e, 0]  # through an edge
+    tgt = (tris.reshape(n, 3, 3) * bary[:, :, None]).sum(1)
+    tgt[k == 3] = rng.uniform(-3, 3, ((k == 3).sum(), 3)).astype(np.float32)  # anywhere: mostly misses
+    d = tgt - o
+    ax = rng.randint(0, 12, n)
+    for a in range(3):  # axis-parallel rays (two zero components), both signs
+        m = ax == a
+        z = np.zeros((m.sum(), 3), np.float32)
+        z[:, a] = np.where(rng.rand(m.sum()) < 0.5, -1, 1)
+        d[m] = z
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30).astype(np.float32)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6] = o, d
+    rays[:, 6] = np.where(rng.rand(n) < 0.5, 0.0, 0.01)
+    rays[:, 7] = np.where(rng.rand(n) < 0.5, 1e10, rng.uniform(0.1, 8, n))
+    tris[-1000:, 6:9] = tris[-1000:, 0:3]  # zero-area triangles
+    a, b = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+    rays, tris = np.ascontiguousarray(rays), np.ascontiguousarray(tris)
+    emu.L.emu_tri_tests(rays.ctypes.data, tris.ctypes.data, n, a.ctypes.data, b.ctypes.data)
+    assert a[:, 0].sum() > n // 5  # (the case set does hit)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
