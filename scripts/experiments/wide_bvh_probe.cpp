@@ -212,6 +212,98 @@ static double sah_cost(int r) {
   return c;
 }
 
+// ---- insertion-based optimisation (Bittner, Hapala, Havran 2013), REINSERT=passes --------------------------------------
+// For every node N (largest first): take N and its parent out (the sibling moves up), find by branch and bound the
+// node X for which inserting N as X's new sibling adds the least surface area (direct: area(N u X); induced: the growth
+// of X's ancestors), and put it there.  What would a tree-quality pass behind the PLOC build be worth?
+static std::vector<int> g_parent;
+static void refit_up(int n) {
+  while (n >= 0) {
+    BNode& b = g_bin[n];
+    Box nb = g_bin[b.left].box;
+    nb.grow(g_bin[b.right].box);
+    b.box = nb;
+    n = g_parent[n];
+  }
+}
+static void reinsertion_pass() {
+  const int nn = (int)g_bin.size();
+  g_parent.assign(nn, -1);
+  for (int i = 0; i < nn; ++i)
+    if (!g_bin[i].leaf()) g_parent[g_bin[i].left] = i, g_parent[g_bin[i].right] = i;
+  std::vector<int> order;
+  for (int i = 0; i < nn; ++i)
+    if (i != g_root && g_parent[i] >= 0 && g_parent[i] != g_root) order.push_back(i);
+  std::sort(order.begin(), order.end(), [](int a, int b) { return g_bin[a].box.area() > g_bin[b].box.area(); });
+  float min_area = 0.0f;  // REINSERT_SEARCH_TOP=K2: candidate positions only among the K2 largest nodes (a top tree cut out of the whole)
+  if (const char* st = getenv("REINSERT_SEARCH_TOP")) {
+    const size_t k2 = std::min<size_t>(order.size() - 1, (size_t)atol(st));
+    min_area = g_bin[order[k2]].box.area();
+  }
+  if (const char* tk = getenv("REINSERT_TOP")) order.resize(std::min<size_t>(order.size(), (size_t)atol(tk)));  // only the K largest nodes
+  if (getenv("REINSERT_LEAVES_ONLY")) {  // only the leaves among them (the room-sized triangles)
+    std::vector<int> lv;
+    for (int i : order) if (g_bin[i].leaf()) lv.push_back(i);
+    order.swap(lv);
+  }
+  size_t moved = 0;
+  struct Cand {
+    float induced;
+    int node;
+    bool operator<(const Cand& o) const { return induced > o.induced; }
+  };
+  std::vector<Cand> pq;
+  for (int N : order) {
+    const int P = g_parent[N];
+    if (P < 0 || P == g_root) continue;
+    const int G = g_parent[P];
+    const int S = g_bin[P].left == N ? g_bin[P].right : g_bin[P].left;
+    // is N an ancestor position we must not insert under? (N's own subtree is excluded from the search)
+    // remove: S takes P's place
+    if (g_bin[G].left == P) g_bin[G].left = S; else g_bin[G].right = S;
+    g_parent[S] = G;
+    refit_up(G);
+    const Box nb = g_bin[N].box;
+    const float na = nb.area();
+    float best = 3e38f;
+    int bx = -1;
+    pq.clear();
+    pq.push_back({0.0f, g_root});
+    while (!pq.empty()) {
+      std::pop_heap(pq.begin(), pq.end());
+      const Cand c = pq.back();
+      pq.pop_back();
+      if (c.induced + na >= best) break;  // nothing below can beat the best (direct cost >= area(N))
+      const BNode& x = g_bin[c.node];
+      Box u = x.box;
+      u.grow(nb);
+      const float direct = u.area();
+      const float total = c.induced + direct;
+      if (total < best) best = total, bx = c.node;
+      const float ind = total - x.box.area();  // induced cost for the children of x
+      if (!x.leaf() && ind + na < best && x.box.area() >= min_area) {
+        pq.push_back({ind, x.left});
+        std::push_heap(pq.begin(), pq.end());
+        pq.push_back({ind, x.right});
+        std::push_heap(pq.begin(), pq.end());
+      }
+    }
+    // insert N as the sibling of bx under the recycled parent P
+    const int X = bx, XP = g_parent[X];
+    if (X != S || XP != G) ++moved;
+    g_bin[P].left = X;
+    g_bin[P].right = N;
+    g_parent[X] = P;
+    g_parent[N] = P;
+    g_parent[P] = XP;
+    if (XP >= 0) {
+      if (g_bin[XP].left == X) g_bin[XP].left = P; else g_bin[XP].right = P;
+    } else g_root = P;
+    refit_up(P);
+  }
+  printf("reinsertion pass: %zu of %zu nodes moved, SAH cost %.2f\n", moved, order.size(), sah_cost(g_root));
+}
+
 // ---- wide tree ---------------------------------------------------------------------------------------------------
 struct WChild {
   Box box;
@@ -723,6 +815,8 @@ int main(int argc, char** argv) {
   if (ploc_r > 0) g_root = build_ploc(ploc_r);
   else build_binary(idx, 0, (int)n);
   printf("%zu triangles, %zu binary nodes, %s, SAH cost %.2f\n", n, g_bin.size(), ploc_r > 0 ? "PLOC" : "binned SAH", sah_cost(g_root));
+  if (const char* rp = getenv("REINSERT"))
+    for (int k = 0; k < atoi(rp); ++k) reinsertion_pass();
 
   // rays: diffuse bounces -- a point on a random triangle, cosine-distributed direction about its (randomly flipped) normal
   std::mt19937 rng(12345);
