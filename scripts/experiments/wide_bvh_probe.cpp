@@ -167,10 +167,18 @@ static int build_ploc(int R) {
   while (cl.size() > 1) {
     const int m = (int)cl.size();
     nn.assign(m, 0);
+    // PLOC_ADAPT="m1 f1 m2 f2": the window grows to f1 * R once m <= m1 clusters are left, f2 * R below m2 (the top of the tree)
+    int Re = R;
+    if (const char* ad = getenv("PLOC_ADAPT")) {
+      int m1 = 0, f1 = 1, m2 = 0, f2 = 1;
+      sscanf(ad, "%d %d %d %d", &m1, &f1, &m2, &f2);
+      if (m <= m2) Re = R * f2; else if (m <= m1) Re = R * f1;
+    }
+#pragma omp parallel for schedule(dynamic, 1024)
     for (int i = 0; i < m; ++i) {
       float best = 3e38f;
       int bj = i > 0 ? i - 1 : i + 1;
-      for (int j = std::max(0, i - R); j <= std::min(m - 1, i + R); ++j) {
+      for (int j = std::max(0, i - Re); j <= std::min(m - 1, i + Re); ++j) {
         if (j == i) continue;
         Box u = g_bin[cl[i]].box;
         u.grow(g_bin[cl[j]].box);

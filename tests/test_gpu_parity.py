@@ -513,6 +513,42 @@ def test_triangle_soup_hits_do_not_depend_on_bvh(ctx, oracle_mod):
     assert (g2["prim"] == r2["prim"]).all()
 
 
+@pytest.mark.parametrize("ntris", [1, 3, 40, 100, 126, 128, 130, 190, 260, 700])
+def test_trees_around_the_size_of_the_lds_node_copy(ctx, oracle_mod, ntris):
+    """k_trace keeps the first 64 records of the node array in LDS and fetches the others from memory (pt_wavetrace.h).
+    Trees with fewer records than that, exactly about that many and a few times more: closest hits bit for bit, any-hit
+    verdicts, and a small frame."""
+    from gpuspectral_amd import scenes
+
+    rng = np.random.RandomState(1000 + ntris)
+    b = scenes.SceneBuilder()
+    c = rng.uniform(-1, 1, (ntris, 1, 3))
+    tris = (c + rng.normal(size=(ntris, 3, 3)) * 0.15).astype(np.float32).reshape(-1, 3)
+    nrm = np.zeros_like(tris)
+    nrm[:, 1] = 1.0
+    b.add_object(b.add_mesh(tris, nrm), scenes.trs(), b.diffuse((0.6, 0.6, 0.6)))
+    b.add_object(b.add_mesh(*scenes.rect_mesh()), scenes.trs((0, 1.8, 0), 0.5, 0.0), b.diffuse((0, 0, 0)), twofaced=True, emission=(9, 9, 9))
+    b.camera_lookat((0.2, 0.4, 3.5), (0, 0, 0), fov_deg=45)
+    sc = b.build()
+    o = oracle_mod.Oracle(sc)
+    ctx.upload_scene(sc)
+    st = ctx.stats()
+    assert st["num_triangles"] == ntris + 2
+    rays = random_rays(20000, 5 + ntris, lo=(-2, -2, -2), hi=(2, 2, 2))
+    got, ref = ctx.trace(rays), o.trace(rays)
+    assert (got["prim"] == ref["prim"]).all()
+    hit = ref["prim"] >= 0
+    for k in ("t", "u", "v"):
+        assert np.array_equal(np.ascontiguousarray(got[k][hit]).view(np.uint32), np.ascontiguousarray(ref[k][hit]).view(np.uint32)), k
+    sh = rays.copy()
+    sh[:, 3], sh[:, 7] = 0.01, 2.5
+    assert ((ctx.trace(sh, any_hit=True)["prim"] >= 0) == (o.trace(sh, any_hit=True)["prim"] >= 0)).all()
+    ctx.frame_begin(48, 32)
+    ctx.render(spp=4)
+    ref_img, _ = o.render(48, 32, spp=4)
+    assert np.array_equal(ctx.download().reshape(-1, 4), ref_img)
+
+
 def _nested_scene(n=520):
     """Concentric, geometrically growing quads + boxes around one point: equal Morton codes and nested boxes make the
     agglomerative build chain them up, so the BVH is far deeper than the 20 stack levels a lane keeps in LDS."""
