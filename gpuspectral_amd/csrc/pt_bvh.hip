@@ -23,6 +23,7 @@
 //             node are the grandchildren of its binary node (GSP_COLLAPSE=greedy / the 8-wide variant: greedy
 //             surface-area choice of up to kWide children); inner children of a node = consecutive nodes, leaf
 //             children = consecutive triangle slots: the collapse defines the final triangle order
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -396,11 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_ploc_apply(int n, const int32_t* __r
   hi_out[p] = mkq(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
 }
 
-// ---- collapse of the binary tree into the wide tree (pt_trace.h), one level per launch pair ---------------------------
-// A work item of a level = the binary node that becomes a wide node; the items of a level are consecutive wide nodes,
-// and so are the inner children of every node (exclusive scan of the per-item inner-child counts), which is what lets
-// a traversal name "the children of node X still to visit" as {base, which ones} instead of one pointer per child.
-// Leaf children likewise take consecutive triangle slots: the collapse defines the final triangle order.
+// a child of a binary node: box + code
 struct Pick {
   q4 lo, hi;
   int32_t code;  // >= 0 binary inner node, < 0 leaf (make_leaf)
@@ -415,6 +412,245 @@ __device__ __forceinline__ void load2(const q4* __restrict__ nodes2, int32_t b, 
   y.hi = mkq(d.y, d.z, d.w, 0.0f);
   y.code = (int32_t)__float_as_uint(k.y);
 }
+
+// ---- parallel reinsertion (r03) --------------------------------------------------------------------------------------
+// Insertion-based optimisation of the PLOC tree, after Meister & Bittner, "Parallel Reinsertion for Bounding Volume
+// Hierarchy Optimization" (2018).  One round: every node N (inner or leaf, neither the root nor one of its children)
+// searches the FROZEN tree for the node X beside which it would sit best -- the search climbs from N's parent P, descends
+// into the sibling subtrees of the path with branch and bound, and credits the shrinking of the path once N is gone; P is
+// recycled as the new parent of {X, N}.  Candidates with a positive gain take locks (atomicMax of {gain, id}) on the nodes
+// whose links they would rewrite -- N, P, the sibling S, the grandparent G, X and X's parent -- and the ones that hold all of
+// theirs are applied; then every box is refitted bottom-up.  The CPU probe (scripts/experiments/wide_bvh_probe.cpp,
+// PREINSERT=rounds: the same algorithm) says 6 rounds cut the node visits of the bench scene's rays by 10 % / 8 %
+// (closest hit / any hit); searches are short (tens to a few hundred node visits), so a round costs about one trace launch.
+// Node index space of the per-node arrays: inner node i -> i, leaf (Morton slot s) -> (n - 1) + s.
+#ifndef GSP_REINSERT_ROUNDS
+#define GSP_REINSERT_ROUNDS 6
+#endif
+constexpr int kReinsertRounds = GSP_REINSERT_ROUNDS;  // GSP_BVH_REINSERT=rounds overrides (0: the plain PLOC tree)
+constexpr uint32_t kRiStack = 48;      // entries of a search's stack (a deeper path is not followed further: still correct)
+constexpr uint32_t kRiBudget = 768;    // node visits a search may spend
+constexpr int32_t kRiNone = 0x7fffffff;
+
+__device__ __forceinline__ uint32_t ri_index(int32_t code, uint32_t n) {
+  return code >= 0 ? (uint32_t)code : (n - 1u) + (((uint32_t)~code) >> 2);
+}
+__device__ __forceinline__ int32_t ri_parent(int32_t code, const int32_t* __restrict__ parent_int,
+                                             const int32_t* __restrict__ parent_leaf) {
+  return code >= 0 ? parent_int[code] : parent_leaf[((uint32_t)~code) >> 2];
+}
+struct RiRec {  // a binary node's record, unpacked
+  q4 lo[2], hi[2];
+  int32_t code[2];
+};
+__device__ __forceinline__ RiRec ri_load(const q4* nodes2, int32_t b) {  // (no __restrict__: k_ri_apply reads what it wrote)
+  const q4* m = nodes2 + 4ll * b;
+  const q4 a = m[0], bq = m[1], d = m[2], k = m[3];
+  RiRec r;
+  r.lo[0] = mkq(a.x, a.y, a.z, 0.0f), r.hi[0] = mkq(a.w, bq.x, bq.y, 0.0f), r.code[0] = (int32_t)__float_as_uint(k.x);
+  r.lo[1] = mkq(bq.z, bq.w, d.x, 0.0f), r.hi[1] = mkq(d.y, d.z, d.w, 0.0f), r.code[1] = (int32_t)__float_as_uint(k.y);
+  return r;
+}
+__device__ __forceinline__ void ri_store(q4* nodes2, int32_t b, const RiRec& r) {
+  q4* N = nodes2 + 4ll * b;
+  N[0] = mkq(r.lo[0].x, r.lo[0].y, r.lo[0].z, r.hi[0].x);
+  N[1] = mkq(r.hi[0].y, r.hi[0].z, r.lo[1].x, r.lo[1].y);
+  N[2] = mkq(r.lo[1].z, r.hi[1].x, r.hi[1].y, r.hi[1].z);
+  N[3] = mkq(__uint_as_float((uint32_t)r.code[0]), __uint_as_float((uint32_t)r.code[1]), 0.0f, 0.0f);
+}
+__device__ __forceinline__ float ri_union_area(const q4& alo, const q4& ahi, const q4& blo, const q4& bhi) {
+  return half_area(mkq(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), 0.0f),
+                   mkq(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.0f));
+}
+
+__global__ __launch_bounds__(kBlock) void k_ri_search(uint32_t n, int32_t root, const q4* __restrict__ nodes2,
+                                                      const int32_t* __restrict__ parent_int,
+                                                      const int32_t* __restrict__ parent_leaf, int32_t* __restrict__ mv_x,
+                                                      int32_t* __restrict__ mv_xp, float* __restrict__ mv_gain) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 2u * n - 1u) return;
+  const int32_t in = t < n - 1u ? (int32_t)t : make_leaf(t - (n - 1u), 1);
+  int32_t best_x = kRiNone, best_xp = -1;
+  float best = 0.0f;
+  const int32_t P = in == root ? -1 : ri_parent(in, parent_int, parent_leaf);
+  if (P >= 0 && P != root) {
+    const RiRec rp = ri_load(nodes2, P);
+    const int side = rp.code[0] == in ? 0 : 1;
+    const q4 in_lo = rp.lo[side], in_hi = rp.hi[side];
+    const float a_parent = ri_union_area(rp.lo[0], rp.hi[0], rp.lo[1], rp.hi[1]);
+    float d_bound = 0.0f;
+    int32_t pivot = P;
+    uint32_t sib = ((uint32_t)P << 1) | (uint32_t)(side ^ 1);  // {node whose record holds it, side}
+    q4 pv_lo = mkq(3.0e38f, 3.0e38f, 3.0e38f, 0.0f), pv_hi = mkq(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f);
+    uint32_t st_n[kRiStack];
+    float st_d[kRiStack];
+    uint32_t visits = 0;
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {  // (the depth of a tree the build accepts)
+      uint32_t sp = 0;
+      st_n[0] = sib, st_d[0] = d_bound, sp = 1;
+      q4 sib_lo = pv_lo, sib_hi = pv_hi;
+      bool first = true;
+      while (sp > 0 && visits < kRiBudget) {
+        --sp;
+        const uint32_t e = st_n[sp];
+        const float d_par = st_d[sp];
+        const RiRec r = ri_load(nodes2, (int32_t)(e >> 1));
+        const int s2 = (int)(e & 1u);
+        if (first) sib_lo = r.lo[s2], sib_hi = r.hi[s2], first = false;
+        if (d_par + a_parent <= best) continue;  // not even a free insertion below here beats the best
+        ++visits;
+        const float a_merged = ri_union_area(r.lo[s2], r.hi[s2], in_lo, in_hi);
+        const float d_direct = a_parent - a_merged;  // P's old box goes, the merged one comes
+        if (d_par + d_direct > best) {
+          best = d_par + d_direct;
+          best_x = r.code[s2];
+          best_xp = (int32_t)(e >> 1);
+        }
+        if (r.code[s2] >= 0) {
+          const float d = d_par + half_area(r.lo[s2], r.hi[s2]) - a_merged;  // this node grows to the merged box
+          if (d + a_parent > best && sp + 2 <= kRiStack) {
+            st_n[sp] = ((uint32_t)r.code[s2] << 1), st_d[sp] = d, ++sp;
+            st_n[sp] = ((uint32_t)r.code[s2] << 1) | 1u, st_d[sp] = d, ++sp;
+          }
+        }
+      }
+      if (first) {  // budget spent before this sibling was read
+        const RiRec r = ri_load(nodes2, (int32_t)(sib >> 1));
+        sib_lo = r.lo[sib & 1u], sib_hi = r.hi[sib & 1u];
+      }
+      // climb: the pivot loses `in`
+      pv_lo = mkq(fminf(pv_lo.x, sib_lo.x), fminf(pv_lo.y, sib_lo.y), fminf(pv_lo.z, sib_lo.z), 0.0f);
+      pv_hi = mkq(fmaxf(pv_hi.x, sib_hi.x), fmaxf(pv_hi.y, sib_hi.y), fmaxf(pv_hi.z, sib_hi.z), 0.0f);
+      if (pivot != P) {
+        const RiRec r = ri_load(nodes2, pivot);
+        d_bound += ri_union_area(r.lo[0], r.hi[0], r.lo[1], r.hi[1]) - half_area(pv_lo, pv_hi);
+      }
+      if (pivot == root || visits >= kRiBudget) break;
+      const int32_t pp = parent_int[pivot];
+      if (pp < 0) break;
+      const RiRec r = ri_load(nodes2, pp);
+      sib = ((uint32_t)pp << 1) | (uint32_t)(r.code[0] == pivot ? 1 : 0);
+      pivot = pp;
+    }
+    // (the first candidate examined is N's own sibling with a gain of exactly 0: never chosen)
+  }
+  mv_x[t] = best_x;
+  mv_xp[t] = best_xp;
+  mv_gain[t] = best;
+}
+
+struct RiMove {
+  int32_t N, P, S, G, X, XP;
+  unsigned long long key;
+  bool valid;
+};
+__device__ __forceinline__ RiMove ri_move(uint32_t t, uint32_t n, const q4* nodes2, const int32_t* parent_int,
+                                          const int32_t* parent_leaf, const int32_t* mv_x, const int32_t* mv_xp,
+                                          const float* mv_gain) {
+  RiMove m;
+  m.valid = false;
+  const float g = mv_gain[t];
+  m.X = mv_x[t];
+  if (m.X == kRiNone || !(g > 0.0f)) return m;
+  m.N = t < n - 1u ? (int32_t)t : make_leaf(t - (n - 1u), 1);
+  m.P = ri_parent(m.N, parent_int, parent_leaf);
+  const RiRec rp = ri_load(nodes2, m.P);
+  m.S = rp.code[0] == m.N ? rp.code[1] : rp.code[0];
+  m.G = parent_int[m.P];
+  m.XP = mv_xp[t];
+  m.key = ((unsigned long long)__float_as_uint(g) << 32) | (unsigned long long)t;
+  m.valid = m.G >= 0 && m.XP >= 0 && m.X != m.S && m.X != m.P && m.XP != m.P;
+  return m;
+}
+__global__ __launch_bounds__(kBlock) void k_ri_lock(uint32_t n, const q4* __restrict__ nodes2,
+                                                    const int32_t* __restrict__ parent_int,
+                                                    const int32_t* __restrict__ parent_leaf, const int32_t* __restrict__ mv_x,
+                                                    const int32_t* __restrict__ mv_xp, const float* __restrict__ mv_gain,
+                                                    unsigned long long* __restrict__ lock) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 2u * n - 1u) return;
+  const RiMove m = ri_move(t, n, nodes2, parent_int, parent_leaf, mv_x, mv_xp, mv_gain);
+  if (!m.valid) return;
+  atomicMax(&lock[ri_index(m.N, n)], m.key);
+  atomicMax(&lock[ri_index(m.P, n)], m.key);
+  atomicMax(&lock[ri_index(m.S, n)], m.key);
+  atomicMax(&lock[ri_index(m.G, n)], m.key);
+  atomicMax(&lock[ri_index(m.X, n)], m.key);
+  atomicMax(&lock[ri_index(m.XP, n)], m.key);
+}
+__device__ __forceinline__ void ri_set_parent(int32_t code, int32_t p, int32_t* parent_int, int32_t* parent_leaf) {
+  if (code >= 0) parent_int[code] = p; else parent_leaf[((uint32_t)~code) >> 2] = p;
+}
+__global__ __launch_bounds__(kBlock) void k_ri_apply(uint32_t n, q4* nodes2, int32_t* parent_int, int32_t* parent_leaf,
+                                                     const int32_t* __restrict__ mv_x, const int32_t* __restrict__ mv_xp,
+                                                     const float* __restrict__ mv_gain,
+                                                     const unsigned long long* __restrict__ lock, uint32_t* __restrict__ applied) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 2u * n - 1u) return;
+  const RiMove m = ri_move(t, n, nodes2, parent_int, parent_leaf, mv_x, mv_xp, mv_gain);
+  if (!m.valid) return;
+  if (lock[ri_index(m.N, n)] != m.key || lock[ri_index(m.P, n)] != m.key || lock[ri_index(m.S, n)] != m.key ||
+      lock[ri_index(m.G, n)] != m.key || lock[ri_index(m.X, n)] != m.key || lock[ri_index(m.XP, n)] != m.key)
+    return;
+  // every record and parent entry written below belongs to a node this move holds the lock of
+  RiRec rp = ri_load(nodes2, m.P);
+  const int sn = rp.code[0] == m.N ? 0 : 1;
+  const q4 n_lo = rp.lo[sn], n_hi = rp.hi[sn], s_lo = rp.lo[sn ^ 1], s_hi = rp.hi[sn ^ 1];
+  {  // G: the slot that held P takes S
+    RiRec rg = ri_load(nodes2, m.G);
+    const int sg = rg.code[0] == m.P ? 0 : 1;
+    rg.code[sg] = m.S, rg.lo[sg] = s_lo, rg.hi[sg] = s_hi;
+    ri_store(nodes2, m.G, rg);
+  }
+  q4 x_lo, x_hi;
+  {  // XP (may be G, as rewritten above): the slot that held X takes P
+    RiRec rx = ri_load(nodes2, m.XP);
+    const int sx = rx.code[0] == m.X ? 0 : 1;
+    x_lo = rx.lo[sx], x_hi = rx.hi[sx];
+    rx.code[sx] = m.P;
+    rx.lo[sx] = mkq(fminf(x_lo.x, n_lo.x), fminf(x_lo.y, n_lo.y), fminf(x_lo.z, n_lo.z), 0.0f);
+    rx.hi[sx] = mkq(fmaxf(x_hi.x, n_hi.x), fmaxf(x_hi.y, n_hi.y), fmaxf(x_hi.z, n_hi.z), 0.0f);
+    ri_store(nodes2, m.XP, rx);
+  }
+  rp.code[0] = m.X, rp.lo[0] = x_lo, rp.hi[0] = x_hi;
+  rp.code[1] = m.N, rp.lo[1] = n_lo, rp.hi[1] = n_hi;
+  ri_store(nodes2, m.P, rp);
+  ri_set_parent(m.S, m.G, parent_int, parent_leaf);
+  parent_int[m.P] = m.XP;
+  ri_set_parent(m.X, m.P, parent_int, parent_leaf);
+  ri_set_parent(m.N, m.P, parent_int, parent_leaf);
+  atomicAdd(applied, 1u);
+}
+// every inner node's box, bottom-up, into the record of its parent (the leaves' boxes sit in their parents' records already)
+__global__ __launch_bounds__(kBlock) void k_ri_refit(uint32_t n, q4* nodes2, const int32_t* __restrict__ parent_int,
+                                                     const int32_t* __restrict__ parent_leaf, uint32_t* arrive) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  int32_t node = parent_leaf[s];
+  for (uint32_t guard = 0; node >= 0 && guard < 65536u; ++guard) {
+    __threadfence();
+    const uint32_t old = atomicAdd(&arrive[node], 1u);
+    if (old == 0) break;  // the other subtree is not done: whoever finishes it continues from here
+    __threadfence();
+    const int32_t pp = parent_int[node];
+    if (pp < 0) break;
+    // (the fence above invalidated this CU's L1: the loads see what the children's finishers wrote)
+    const float* N = (const float*)(nodes2 + 4ll * node);
+    const float lo[3] = {fminf(N[0], N[6]), fminf(N[1], N[7]), fminf(N[2], N[8])};
+    const float hi[3] = {fmaxf(N[3], N[9]), fmaxf(N[4], N[10]), fmaxf(N[5], N[11])};
+    float* Pn = (float*)(nodes2 + 4ll * pp);
+    const int off = (int32_t)__float_as_uint(Pn[12]) == node ? 0 : 6;  // record = {left lo, left hi, right lo, right hi, codes}: 6 words a side
+    Pn[off + 0] = lo[0], Pn[off + 1] = lo[1], Pn[off + 2] = lo[2];
+    Pn[off + 3] = hi[0], Pn[off + 4] = hi[1], Pn[off + 5] = hi[2];
+    node = pp;
+  }
+}
+
+// ---- collapse of the binary tree into the wide tree (pt_trace.h), one level per launch pair ---------------------------
+// A work item of a level = the binary node that becomes a wide node; the items of a level are consecutive wide nodes,
+// and so are the inner children of every node (exclusive scan of the per-item inner-child counts), which is what lets
+// a traversal name "the children of node X still to visit" as {base, which ones} instead of one pointer per child.
+// Leaf children likewise take consecutive triangle slots: the collapse defines the final triangle order.
 // Greedy surface-area collapse: the children of binary node b, then repeatedly the inner child with the largest box is
 // replaced by its own two children until the node is full (kWide) or only leaves are left.
 // mode 1 (GSP_COLLAPSE=parity, 4-wide only; r01 / r02's default): the children are the grandchildren of b.
@@ -730,6 +966,41 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       GSP_HIP_TRY(hipMemcpyAsync(&root2, code_a, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
       GSP_HIP_TRY(hipStreamSynchronize(stream));
       // leaf_lo/leaf_hi may have been overwritten by the ping-pong: nothing below reads them again
+      // ---- parallel reinsertion rounds (above): no host round trip inside
+      const char* re = getenv("GSP_BVH_REINSERT");
+      const int rounds = re ? std::min(std::max(atoi(re), 0), 64) : kReinsertRounds;
+      if (rounds > 0 && n >= 16) {
+        const size_t idx = 2ull * n;
+        int32_t *mv_x, *mv_xp;
+        float* mv_gain;
+        unsigned long long* lock;
+        uint32_t* applied;
+        GSP_HIP_TRY(S.alloc(&mv_x, idx));
+        GSP_HIP_TRY(S.alloc(&mv_xp, idx));
+        GSP_HIP_TRY(S.alloc(&mv_gain, idx));
+        GSP_HIP_TRY(S.alloc(&lock, idx));
+        GSP_HIP_TRY(S.alloc(&applied, 64));
+        GSP_HIP_TRY(hipMemsetAsync(applied, 0, 64 * sizeof(uint32_t), stream));
+        const uint32_t nb = blocks_for(2ull * n - 1);
+        for (int r = 0; r < rounds; ++r) {
+          GSP_HIP_TRY(hipMemsetAsync(lock, 0, idx * sizeof(unsigned long long), stream));
+          hipLaunchKernelGGL(k_ri_search, dim3(nb), dim3(kBlock), 0, stream, n, root2, nodes2, parent_int, parent_leaf, mv_x, mv_xp, mv_gain);
+          hipLaunchKernelGGL(k_ri_lock, dim3(nb), dim3(kBlock), 0, stream, n, nodes2, parent_int, parent_leaf, mv_x, mv_xp, mv_gain, lock);
+          hipLaunchKernelGGL(k_ri_apply, dim3(nb), dim3(kBlock), 0, stream, n, nodes2, parent_int, parent_leaf, mv_x, mv_xp, mv_gain, lock,
+                             applied + r);
+          GSP_HIP_TRY(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, stream));
+          hipLaunchKernelGGL(k_ri_refit, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, nodes2, parent_int, parent_leaf, arrive);
+          GSP_HIP_TRY(hipGetLastError());
+        }
+        if (getenv("GSP_BVH_TRACE")) {
+          uint32_t h[64];
+          GSP_HIP_TRY(hipMemcpyAsync(h, applied, sizeof(h), hipMemcpyDeviceToHost, stream));
+          GSP_HIP_TRY(hipStreamSynchronize(stream));
+          fprintf(stderr, "reinsertion: moves applied per round:");
+          for (int r = 0; r < rounds; ++r) fprintf(stderr, " %u", h[r]);
+          fprintf(stderr, "\n");
+        }
+      }
     }
   }
   // ---- collapse to the wide tree, level by level ----

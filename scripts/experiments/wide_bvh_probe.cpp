@@ -312,6 +312,136 @@ static void reinsertion_pass() {
   printf("reinsertion pass: %zu of %zu nodes moved, SAH cost %.2f\n", moved, order.size(), sah_cost(g_root));
 }
 
+// ---- parallel reinsertion (Meister & Bittner 2018), PREINSERT="rounds": every node searches on the FROZEN tree (no removal:
+// the search climbs from the node's parent and accounts for the shrinking of the path), candidates lock the nodes whose
+// links they would change (largest gain wins), the winners are applied, all boxes are refitted.  What a device pass would do.
+struct PMove {
+  int x;
+  float gain;
+};
+static inline int sibling_of(int n) {
+  const int p = g_parent[n];
+  return g_bin[p].left == n ? g_bin[p].right : g_bin[p].left;
+}
+static long g_budget = 0;
+static std::vector<long> g_visit_hist(8, 0);
+static PMove find_best(int in) {
+  PMove r{-1, 0.0f};
+  long visits = 0;
+  const int P = g_parent[in];
+  const Box inb = g_bin[in].box;
+  const float a_parent = g_bin[P].box.area();
+  float d_bound = 0.0f;  // area freed on the path from P up to (not including) the pivot
+  int pivot = P, sib = sibling_of(in);
+  Box pivot_box;  // what the pivot's box becomes once `in` is gone
+  int stack_n[128];
+  float stack_d[128];
+  while (true) {
+    int sp = 0;
+    stack_n[sp] = sib, stack_d[sp] = d_bound, ++sp;
+    while (sp > 0) {
+      if (g_budget > 0 && ++visits > g_budget) return r;  // PREINSERT_BUDGET: node visits a search may spend
+      --sp;
+      const int out = stack_n[sp];
+      const float d_par = stack_d[sp];
+      if (d_par + a_parent <= r.gain) continue;  // even a free insertion below cannot beat the best
+      Box m = g_bin[out].box;
+      m.grow(inb);
+      const float d_direct = a_parent - m.area();  // P is recycled: its old box goes, the merged one comes
+      if (d_par + d_direct > r.gain && out != sib + 0 * in) r.gain = d_par + d_direct, r.x = out;
+      if (!g_bin[out].leaf()) {
+        const float d = d_par + g_bin[out].box.area() - m.area();  // `out` grows to the merged box if we go below it
+        if (d + a_parent > r.gain && sp + 2 <= 128) {
+          stack_n[sp] = g_bin[out].left, stack_d[sp] = d, ++sp;
+          stack_n[sp] = g_bin[out].right, stack_d[sp] = d, ++sp;
+        }
+      }
+    }
+    // climb: the pivot loses `in`
+    pivot_box.grow(g_bin[sib].box);
+    if (pivot != P) d_bound += g_bin[pivot].box.area() - pivot_box.area();
+    if (pivot == g_root) break;
+    sib = sibling_of(pivot);
+    pivot = g_parent[pivot];
+  }
+  return r;
+}
+static void parallel_reinsertion(int rounds) {
+  const int nn = (int)g_bin.size();
+  std::vector<PMove> mv(nn);
+  std::vector<unsigned long long> lock(nn);
+  for (int round = 0; round < rounds; ++round) {
+    g_parent.assign(nn, -1);
+    for (int i = 0; i < nn; ++i)
+      if (!g_bin[i].leaf()) g_parent[g_bin[i].left] = i, g_parent[g_bin[i].right] = i;
+    const int k0 = getenv("PREINSERT_K0") ? atoi(getenv("PREINSERT_K0")) : 9;
+    const int k = std::max(1, k0 - round);  // sparse selection, denser every round
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < nn; ++i) {
+      mv[i] = PMove{-1, 0.0f};
+      if (i == g_root || g_parent[i] == g_root || (i % k) != (round % k)) continue;
+      mv[i] = find_best(i);
+      if (mv[i].x == sibling_of(i)) mv[i].x = -1;  // where it is
+    }
+    std::fill(lock.begin(), lock.end(), 0ull);
+    auto key = [&](int i) { unsigned u; memcpy(&u, &mv[i].gain, 4); return ((unsigned long long)u << 32) | (unsigned)i; };
+    auto touched = [&](int i, int* t) {
+      const int P = g_parent[i], S = sibling_of(i), G = g_parent[P], X = mv[i].x, XP = g_parent[X];
+      t[0] = i, t[1] = P, t[2] = S, t[3] = G, t[4] = X, t[5] = XP;
+    };
+    for (int i = 0; i < nn; ++i) {
+      if (mv[i].x < 0 || mv[i].gain <= 0.0f) continue;
+      int t[6];
+      touched(i, t);
+      for (int q = 0; q < 6; ++q)
+        if (t[q] >= 0) lock[t[q]] = std::max(lock[t[q]], key(i));
+    }
+    size_t applied = 0, cands = 0;
+    for (int i = 0; i < nn; ++i) {
+      if (mv[i].x < 0 || mv[i].gain <= 0.0f) continue;
+      ++cands;
+      int t[6];
+      touched(i, t);
+      bool ok = true;
+      for (int q = 0; q < 6; ++q)
+        if (t[q] >= 0 && lock[t[q]] != key(i)) ok = false;
+      if (!ok) continue;
+      const int N = i, P = t[1], S = t[2], G = t[3], X = t[4], XP = t[5];
+      // X inside N's subtree cannot happen (the search never enters it); X == P is excluded by the locks (P is N's parent: key equal) -- skip it
+      if (X == P) continue;
+      if (g_bin[G].left == P) g_bin[G].left = S; else g_bin[G].right = S;
+      g_parent[S] = G;
+      const int XP2 = (XP == P) ? G : XP;  // X was the sibling's child?  (X == S is filtered above; XP == P only if X == S)
+      if (g_bin[XP2].left == X) g_bin[XP2].left = P; else g_bin[XP2].right = P;
+      g_parent[P] = XP2;
+      g_bin[P].left = X;
+      g_bin[P].right = N;
+      g_parent[X] = P;
+      g_parent[N] = P;
+      ++applied;
+    }
+    // refit everything bottom-up (post-order over the new topology)
+    {
+      std::vector<int> st = {g_root}, post;
+      while (!st.empty()) {
+        const int b = st.back();
+        st.pop_back();
+        if (g_bin[b].leaf()) continue;
+        post.push_back(b);
+        st.push_back(g_bin[b].left), st.push_back(g_bin[b].right);
+      }
+      for (size_t q = post.size(); q-- > 0;) {
+        BNode& b = g_bin[post[q]];
+        Box nb = g_bin[b.left].box;
+        nb.grow(g_bin[b.right].box);
+        b.box = nb;
+      }
+      if (post.size() != (size_t)(nn - 1) / 2 + 0 && round == 0) printf("(inner nodes reachable: %zu)\n", post.size());
+    }
+    printf("parallel reinsertion round %d (every %d-th node): %zu candidates, %zu applied, SAH cost %.2f\n", round, k, cands, applied, sah_cost(g_root));
+  }
+}
+
 // ---- wide tree ---------------------------------------------------------------------------------------------------
 struct WChild {
   Box box;
@@ -823,6 +953,8 @@ int main(int argc, char** argv) {
   if (ploc_r > 0) g_root = build_ploc(ploc_r);
   else build_binary(idx, 0, (int)n);
   printf("%zu triangles, %zu binary nodes, %s, SAH cost %.2f\n", n, g_bin.size(), ploc_r > 0 ? "PLOC" : "binned SAH", sah_cost(g_root));
+  if (const char* bg = getenv("PREINSERT_BUDGET")) g_budget = atol(bg);
+  if (const char* pr = getenv("PREINSERT")) parallel_reinsertion(atoi(pr));
   if (const char* rp = getenv("REINSERT"))
     for (int k = 0; k < atoi(rp); ++k) reinsertion_pass();
 
