@@ -549,6 +549,31 @@ def test_trees_around_the_size_of_the_lds_node_copy(ctx, oracle_mod, ntris):
     assert np.array_equal(ctx.download().reshape(-1, 4), ref_img)
 
 
+@pytest.mark.parametrize("rounds", ["0", "1", "17"])
+def test_reinsertion_rounds_change_the_tree_not_the_hits(ctx, oracle_mod, materials_scene, monkeypatch, rounds):
+    """The BVH build runs parallel reinsertion rounds behind PLOC (pt_bvh.hip k_ri_*; GSP_BVH_REINSERT overrides the default 6):
+    whatever their number, closest hits, any-hit verdicts and a frame equal the oracle's -- on the full-BSDF scene and on the
+    triangle soup with its duplicates, degenerate triangles and mirrored instances."""
+    monkeypatch.setenv("GSP_BVH_REINSERT", rounds)
+    for sc, rays in ((materials_scene, random_rays(30000, 31)), (_soup_scene(), _soup_rays())):
+        o = oracle_mod.Oracle(sc)
+        ctx.upload_scene(sc)
+        got, ref = ctx.trace(rays), o.trace(rays)
+        assert (got["prim"] == ref["prim"]).all()
+        hit = ref["prim"] >= 0
+        for k in ("t", "u", "v"):
+            assert np.array_equal(np.ascontiguousarray(got[k][hit]).view(np.uint32), np.ascontiguousarray(ref[k][hit]).view(np.uint32)), k
+        sh = rays.copy()
+        sh[:, 3] = 0.01
+        sh[:, 7] = np.random.RandomState(4).uniform(0.05, 4.0, len(sh)).astype(np.float32)
+        assert (ctx.trace(sh, any_hit=True)["prim"] == o.trace(sh, any_hit=True)["prim"]).all()
+    ctx.upload_scene(materials_scene)
+    ctx.frame_begin(64, 48)
+    ctx.render(spp=4)
+    ref_img, _ = oracle_mod.Oracle(materials_scene).render(64, 48, spp=4)
+    assert np.array_equal(ctx.download().reshape(-1, 4), ref_img)
+
+
 def _nested_scene(n=520):
     """Concentric, geometrically growing quads + boxes around one point: equal Morton codes and nested boxes make the
     agglomerative build chain them up, so the BVH is far deeper than the 20 stack levels a lane keeps in LDS."""
