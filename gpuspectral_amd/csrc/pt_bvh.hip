@@ -428,8 +428,14 @@ __device__ __forceinline__ void load2(const q4* __restrict__ nodes2, int32_t b, 
 #define GSP_REINSERT_ROUNDS 6
 #endif
 constexpr int kReinsertRounds = GSP_REINSERT_ROUNDS;  // GSP_BVH_REINSERT=rounds overrides (0: the plain PLOC tree)
-constexpr uint32_t kRiStack = 48;      // entries of a search's stack (a deeper path is not followed further: still correct)
-constexpr uint32_t kRiBudget = 768;    // node visits a search may spend
+#ifndef GSP_RI_STACK
+#define GSP_RI_STACK 48
+#endif
+constexpr uint32_t kRiStack = GSP_RI_STACK;      // entries of a search's stack (a deeper path is not followed further: still correct)
+#ifndef GSP_RI_BUDGET
+#define GSP_RI_BUDGET 768
+#endif
+constexpr uint32_t kRiBudget = GSP_RI_BUDGET;    // node visits a search may spend
 constexpr int32_t kRiNone = 0x7fffffff;
 
 __device__ __forceinline__ uint32_t ri_index(int32_t code, uint32_t n) {
@@ -621,27 +627,38 @@ __global__ __launch_bounds__(kBlock) void k_ri_apply(uint32_t n, q4* nodes2, int
   ri_set_parent(m.N, m.P, parent_int, parent_leaf);
   atomicAdd(applied, 1u);
 }
-// every inner node's box, bottom-up, into the record of its parent (the leaves' boxes sit in their parents' records already)
+// every inner node's box, bottom-up, into the record of its parent (the leaves' boxes sit in their parents' records already).
+// The hand-over between the finisher of a child and the thread that continues from the parent goes through memory the
+// XCDs agree on: write-through (sc1) stores, drained before the arrive counter is bumped, and sc1 loads behind the counter --
+// NOT __threadfence(), which at agent scope is an L2 write-back + invalidate per call (the first version spent 5 ms a round there).
+__device__ __forceinline__ void ri_store_word(float* p, float v) {
+  __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ri_load_word(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 __global__ __launch_bounds__(kBlock) void k_ri_refit(uint32_t n, q4* nodes2, const int32_t* __restrict__ parent_int,
                                                      const int32_t* __restrict__ parent_leaf, uint32_t* arrive) {
   const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
   if (s >= n) return;
   int32_t node = parent_leaf[s];
   for (uint32_t guard = 0; node >= 0 && guard < 65536u; ++guard) {
-    __threadfence();
-    const uint32_t old = atomicAdd(&arrive[node], 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's box stores have left before it announces itself
+    const uint32_t old = __hip_atomic_fetch_add(&arrive[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == 0) break;  // the other subtree is not done: whoever finishes it continues from here
-    __threadfence();
     const int32_t pp = parent_int[node];
     if (pp < 0) break;
-    // (the fence above invalidated this CU's L1: the loads see what the children's finishers wrote)
-    const float* N = (const float*)(nodes2 + 4ll * node);
-    const float lo[3] = {fminf(N[0], N[6]), fminf(N[1], N[7]), fminf(N[2], N[8])};
-    const float hi[3] = {fmaxf(N[3], N[9]), fmaxf(N[4], N[10]), fmaxf(N[5], N[11])};
+    const float* N = (const float*)(nodes2 + 4ll * node);  // record = {left lo, left hi, right lo, right hi, codes}: 6 words a side
+    float w[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) w[k] = ri_load_word(N + k);
     float* Pn = (float*)(nodes2 + 4ll * pp);
-    const int off = (int32_t)__float_as_uint(Pn[12]) == node ? 0 : 6;  // record = {left lo, left hi, right lo, right hi, codes}: 6 words a side
-    Pn[off + 0] = lo[0], Pn[off + 1] = lo[1], Pn[off + 2] = lo[2];
-    Pn[off + 3] = hi[0], Pn[off + 4] = hi[1], Pn[off + 5] = hi[2];
+    const int off = (int32_t)__float_as_uint(Pn[12]) == node ? 0 : 6;  // (the codes do not change in this kernel)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ri_store_word(Pn + off + k, fminf(w[k], w[6 + k]));
+      ri_store_word(Pn + off + 3 + k, fmaxf(w[3 + k], w[9 + k]));
+    }
     node = pp;
   }
 }
