@@ -1,4 +1,4 @@
-// pt_bvh.hip -- device-side scene bake + LBVH build for gfx950.
+// pt_bvh.hip -- device-side scene bake + BVH build (PLOC, reinsertion, wide collapse) for gfx950.
 //
 // Replaces the driver-side acceleration-structure build of the reference
 // (Renderer::getOrCreateBLAS S/renderer/Renderer.cpp:122-131, createTLAS
@@ -18,7 +18,8 @@
 //             Meister & Bittner 2018: repeatedly merge mutual nearest neighbours, by merged surface
 //             area, within a window of the cluster array) -- near-SAH quality; the Karras 2012 radix
 //             tree (LBVH) is kept behind GSP_BVH=lbvh for comparison
-//   fit       bottom-up boxes of the binary tree (each binary node holds both child boxes)
+//   fit       (LBVH only) bottom-up boxes of the binary tree; a binary node's record holds both child boxes + codes
+//   reinsert  6 rounds of parallel reinsertion over the PLOC tree (k_ri_*, below): -8 % / -6 % node visits per ray
 //   collapse  binary tree -> wide BVH with contiguous children (pt_trace.h), level by level: the children of a 4-wide
 //             node are the grandchildren of its binary node (GSP_COLLAPSE=greedy / the 8-wide variant: greedy
 //             surface-area choice of up to kWide children); inner children of a node = consecutive nodes, leaf

@@ -20,7 +20,13 @@
 //     speed only), i.e. one atomic per 256 rays on a line no other XCD touches;
 //   * per-lane stack of node groups in LDS ([level][lane]: conflict-free) with an HBM spill region behind
 //     it; a node step pushes at most ONE entry (the rest of the group it descends from: r03, pt_trace.h), so the
-//     stack is as deep as the tree, not three times that; a sentinel at the bottom removes the empty-stack test.
+//     stack is as deep as the tree, not three times that; a sentinel at the bottom removes the empty-stack test;
+//   * the first kTopNodes records of the node array (the top levels of the tree: half of a ray's node visits) are
+//     staged into LDS by every block and read with ds_read_b128 (r03);
+//   * the leaf step is straight-line code: every update a select on the variable's own register, the triangle test
+//     without early exits and with its axis permutation applied through lane masks (pt_trace.h intersect_tri_rot).
+// What it runs against (r03, profiles/r03_trace_bound.txt): no single resource -- 70-85 % of VALU issue (by class), of the
+// L1 request path and of what 7 waves per SIMD cover in latency; work per ray (node visits) is what moves it.
 #pragma once
 #include "pt_trace.h"
 
