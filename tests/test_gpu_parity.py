@@ -576,7 +576,7 @@ def test_reinsertion_rounds_change_the_tree_not_the_hits(ctx, oracle_mod, materi
 
 def _nested_scene(n=520):
     """Concentric, geometrically growing quads + boxes around one point: equal Morton codes and nested boxes make the
-    agglomerative build chain them up, so the BVH is far deeper than the 20 stack levels a lane keeps in LDS."""
+    agglomerative build chain them up, so the BVH is far deeper than the 16 stack levels a lane keeps in LDS."""
     from gpuspectral_amd import scenes
 
     b = scenes.SceneBuilder()
