@@ -468,6 +468,10 @@ static void quantise(WNode& nd) {
     if (ext > 0) (void)frexpf(ext / 255.0f, &ex);
     sc[a] = ldexpf(1.0f, ex);
     while (lo[a] + 255.0f * sc[a] < hi[a]) sc[a] *= 2;
+    if (getenv("TIGHT_SCALE") && ext > 0) {  // any float step instead of a power of two: extent / 255, nudged up until 255 steps reach the far side
+      sc[a] = ext / 255.0f;
+      while (lo[a] + 255.0f * sc[a] < hi[a]) sc[a] = nextafterf(sc[a], 3e38f);
+    }
   }
   for (int k = 0; k < nd.n; ++k) {
     float* cl = &nd.c[k].box.lo.x;
