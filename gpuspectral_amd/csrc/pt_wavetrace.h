@@ -415,24 +415,25 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
     // Written without conditional blocks around the state: every update is a select on the variable's own register.
     // (A divergent block that assigns loop-carried variables leaves the compiler with two copies of each -- the
     // value before and after -- and the loop then moves them back and forth: 67 v_mov per leaf step, a third of
-    // its instructions.)  Only the loads sit under the lane's condition; their results are dead in the other lanes.
+    // its instructions.)
     {
       const bool act = !tris_empty(tm);
       uint32_t tm_n = tm;
       const uint32_t slot = tris_next(tb, tm_n);  // (tm == 0: some slot number, unused)
       tm = act ? tm_n : tm;
-      float ax, ay, az, aw, bx, by, bz, cx, cy, cz;
-      asm("" : "=v"(ax), "=v"(ay), "=v"(az), "=v"(aw), "=v"(bx), "=v"(by), "=v"(bz), "=v"(cx), "=v"(cy), "=v"(cz));  // any value
+      // the test itself runs under the lane's condition (lanes without a triangle stay switched off: their arithmetic
+      // would be thrown away, and on a chip that regulates its clock by power it is not free); what leaves the block are
+      // temporaries -- defined by an empty asm in the other lanes, so no copy is needed at the join -- and `hit`
+      float t, u, v, aw;
+      asm("" : "=v"(t), "=v"(u), "=v"(v), "=v"(aw));  // any value
+      bool hit = false;
       if (act) {
         const q4* p = tris + 3ll * slot;
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
-        ax = p0.x, ay = p0.y, az = p0.z, aw = p0.w;
-        bx = p1.x, by = p1.y, bz = p1.z;
-        cx = p2.x, cy = p2.y, cz = p2.z;
+        aw = p0.w;
+        hit = intersect_tri_rot(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u, v);
       }
       if (STATS) c_tris += act ? 1u : 0u;
-      float t, u, v;
-      const bool hit = act & intersect_tri_rot(mk3(ax, ay, az), mk3(bx, by, bz), mk3(cx, cy, cz), rb.o, rs, tmin, tmax, t, u, v);
       if (ANY) {  // the first accepted triangle ends the ray
         h.t = hit ? t : h.t;
         h.slot = hit ? (int32_t)slot : h.slot;
