@@ -149,6 +149,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="with one rank and no launcher: still create the process group and run the gather through it "
                          "(RCCL initialisation + torch / HIP-runtime coexistence smoke run on a one-GPU box)")
+    ap.add_argument("--dist-timeout", type=float, default=120.0,
+                    help="seconds a rank waits in a collective of the process group before it gives up (N > 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo = host tensors, for dry runs)")
     return ap.parse_args()
@@ -225,6 +227,23 @@ def _launch_ranks(args):
 
 
 def main():
+    """Entry point: any exception of a rank is printed WITH its rank and ends the process with status 1 -- a plain exit,
+    never a re-exec -- so that the launcher tears the other ranks down instead of leaving them in a barrier."""
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 (the rank must die loudly whatever it was)
+        import traceback
+
+        traceback.print_exc()
+        print("bench.py: rank %s of %s failed: %s: %s" % (os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"),
+                                                          type(e).__name__, e), file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(1)  # (not sys.exit: a process group that is half torn down may hang in its destructors)
+
+
+def _main():
     args = parse()
     if args.gpus is None:
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,18 +268,30 @@ def main():
         sk.close()
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+    import gpuspectral_amd as g
+    from gpuspectral_amd import multigpu, scenes  # noqa: F401
+
     if world > 1 or args.force_dist:
+        from datetime import timedelta
+
+        # RCCL wants one GPU per rank: refuse an over-subscribed launch BEFORE any GPU call (gsp_device_count and
+        # torch.cuda.device_count only count devices; neither initialises one)
+        if args.backend == "nccl" and world > max(1, g.device_count()):
+            if rank == 0:
+                print("bench.py: --gpus %d over the nccl backend needs %d visible GPUs, this node shows %d "
+                      "(use --backend gloo for a dry run that shares GPUs)" % (world, world, g.device_count()), file=sys.stderr)
+            sys.exit(2)
         import torch
         import torch.distributed as dist
 
+        # a rank that dies must not leave the others in a collective until the driver's limit: every wait of this group
+        # gives up after --dist-timeout seconds
+        tmo = timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
-            dist.init_process_group("gloo")
-
-    import gpuspectral_amd as g
-    from gpuspectral_amd import multigpu, scenes  # noqa: F401
+            dist.init_process_group("gloo", timeout=tmo)
 
     sc, scene_name = make_scene(args)
     W, H = args.width, args.height
@@ -328,6 +359,16 @@ def main():
          st["shade_kernel_ms"], st["connect_kernel_ms"], st["shaded_vertices"], st["memoised_rays"], st["memo_build_rays"]],
         np.float64,
     )
+    # what a first 8-GPU run needs in order to explain its own imbalance: every rank's own clock, work and pool
+    mine = np.array([elapsed, st["traced_rays"], st["samples"], npix_local, st["extend_kernel_ms"] + st["shade_kernel_ms"] + st["connect_kernel_ms"],
+                     st["extend_launches"], st["device_bytes"], st["render_seconds"], upload_s], np.float64)
+    per_rank = [mine]
+    if dist is not None:
+        tm = torch.from_numpy(mine).to(tdev)
+        got = [torch.zeros_like(tm) for _ in range(world)] if rank == 0 else None
+        dist.gather(tm, got, dst=0)
+        if rank == 0:
+            per_rank = [x.cpu().numpy() for x in got]
     if dist is not None:
         t = torch.from_numpy(local).to(tdev)
         tmax = t.clone()
@@ -355,7 +396,8 @@ def main():
         b_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray  # ray + hit + node / triangle records
         ext_ms = st["extend_kernel_ms"]
         launches = max(1, st["extend_launches"])
-        ext_traced0 = st["extension_rays"] - st["memoised_rays"]  # rays rank 0's extend launches traced in the timed region
+        # rays rank 0's closest-hit launches traced in the timed region (the one trace of each camera ray for the memo included)
+        ext_traced0 = st["extension_rays"] - st["memoised_rays"] + st["memo_build_rays"]
         alg_bytes = ext_traced0 * b_ray
         cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S,
                    "steps": args.steps, "warmup": args.warmup, "primary_memo": bool(st["memoised_rays"] > 0)}
@@ -397,7 +439,7 @@ def main():
             if "SQ_THREAD_CYCLES_VALU" in c:
                 roof["valu_lane_instr_per_ray"] = c["SQ_THREAD_CYCLES_VALU"] / ext_traced0
         out = {
-            "metric": "Mrays/s (extension + shadow rays), ~1M-tri Mitsuba-style scene at 1080p",
+            "metric": "Mrays/s (traced rays: extension + shadow; memoised camera segments excluded), ~1M-tri Mitsuba-style scene at 1080p",
             "value": rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "msamples_per_s": samples / elapsed / 1e6,
@@ -428,6 +470,9 @@ def main():
                 "bvh_build_ms": st["bvh_build_ms"],
                 "scene_upload_ms": upload_s * 1e3,
                 "library_digest": digest,
+                "per_rank": [{"rank": r, "elapsed_s": float(v[0]), "traced_rays": int(v[1]), "samples": int(v[2]), "pixels": int(v[3]),
+                              "kernel_ms": float(v[4]), "launches": int(v[5]), "device_bytes": int(v[6]),
+                              "render_call_s": float(v[7]), "scene_upload_s": float(v[8])} for r, v in enumerate(per_rank)],
             },
             "roofline": roof,
         }

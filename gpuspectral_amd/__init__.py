@@ -7,6 +7,6 @@ PathTracer interfaces.  This Python package is only a ctypes binding for tests
 and ``bench.py``; there is no CPU rendering path.
 """
 from . import abi  # noqa: F401
-from .pt import Context, GspError, device_count, lib_path  # noqa: F401
+from .pt import Context, GspError, MultiContext, device_count, lib_path  # noqa: F401
 
-__all__ = ["abi", "Context", "GspError", "device_count", "lib_path"]
+__all__ = ["abi", "Context", "MultiContext", "GspError", "device_count", "lib_path"]

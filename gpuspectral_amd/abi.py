@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-GSP_ABI_VERSION = 4
+GSP_ABI_VERSION = 5
 
 BSDF_DIFFUSE = 0
 BSDF_SMOOTH_DIELECTRIC = 1
@@ -137,12 +137,63 @@ class RenderParams(C.Structure):
         ("timestamps_in_flight", C.c_uint32),
         ("collect_traversal_stats", C.c_uint32),
         ("collect_kernel_times", C.c_uint32),
+        ("nee", C.c_uint32),  # (ABI 5) RenderParams.nee, PathTracer.h:36-41; 1 = the shipped shader (`#define NEE true`)
     ]
 
 
 def default_render_params(spp=1, first_timestamp=0):
-    """The reference's shader literals: raygen.rgen:27,60,66."""
-    return RenderParams(spp, first_timestamp, 50, 10, 20.0, 0, 0, 0)
+    """The reference's shader literals: raygen.rgen:27,60,66; rayhit.rchit:656."""
+    return RenderParams(spp, first_timestamp, 50, 10, 20.0, 0, 0, 0, 1)
+
+
+GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2
+
+
+class CtxOptions(C.Structure):
+    """gsp_ctx_options (ABI 5); a field left 0 means "default"."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("lanes", C.c_uint32),
+        ("pool_paths", C.c_uint64),
+        ("ring_bytes", C.c_uint64),
+        ("memory_share", C.c_double),
+        ("primary_memo", C.c_uint32),
+        ("finish_paths", C.c_uint32),
+        ("reinsert_rounds", C.c_uint32),
+        ("gather_route", C.c_uint32),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_size = C.sizeof(CtxOptions)
+
+
+def options_from_env(env=None):
+    """TEST / A-B TOOLING: the GSP_* variables the probe scripts of earlier rounds set, mapped onto gsp_ctx_options (the
+    library itself never reads the environment).  GSP_POOL_PATHS, GSP_RING_BYTES, GSP_MEMORY_SHARE, GSP_PRIMARY_MEMO=0|1,
+    GSP_FINISH_PATHS (0 = never), GSP_LANES, GSP_BVH_REINSERT=rounds, GSP_MULTI_GATHER=rccl|copy."""
+    import os
+
+    e = os.environ if env is None else env
+    o = CtxOptions()
+    if "GSP_POOL_PATHS" in e:
+        o.pool_paths = int(e["GSP_POOL_PATHS"])
+    if "GSP_RING_BYTES" in e:
+        o.ring_bytes = int(e["GSP_RING_BYTES"])
+    if "GSP_MEMORY_SHARE" in e:
+        o.memory_share = float(e["GSP_MEMORY_SHARE"])
+    if "GSP_PRIMARY_MEMO" in e:
+        o.primary_memo = 1 if int(e["GSP_PRIMARY_MEMO"]) else 2
+    if "GSP_FINISH_PATHS" in e:
+        o.finish_paths = int(e["GSP_FINISH_PATHS"]) or 0xFFFFFFFF
+    if "GSP_LANES" in e:
+        o.lanes = int(e["GSP_LANES"])
+    if "GSP_BVH_REINSERT" in e:
+        o.reinsert_rounds = int(e["GSP_BVH_REINSERT"]) + 1
+    if "GSP_MULTI_GATHER" in e:
+        o.gather_route = {"rccl": GATHER_RCCL, "copy": GATHER_COPY}.get(e["GSP_MULTI_GATHER"], GATHER_AUTO)
+    return o
 
 
 class Stats(C.Structure):
@@ -170,6 +221,7 @@ class Stats(C.Structure):
         ("memoised_rays", C.c_uint64),
         ("memo_build_rays", C.c_uint64),
         ("bvh_depth", C.c_uint64),
+        ("scene_updates", C.c_uint64),
     ]
 
     def as_dict(self):

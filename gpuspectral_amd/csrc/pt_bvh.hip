@@ -16,14 +16,16 @@
 //   scatter   packets into leaf (Morton) order -> coherent rays touch adjacent HBM lines
 //   hierarchy binary tree over the Morton-sorted leaves: PLOC (parallel locally-ordered clustering,
 //             Meister & Bittner 2018: repeatedly merge mutual nearest neighbours, by merged surface
-//             area, within a window of the cluster array) -- near-SAH quality; the Karras 2012 radix
-//             tree (LBVH) is kept behind GSP_BVH=lbvh for comparison
-//   fit       (LBVH only) bottom-up boxes of the binary tree; a binary node's record holds both child boxes + codes
-//   reinsert  6 rounds of parallel reinsertion over the PLOC tree (k_ri_*, below): -8 % / -6 % node visits per ray
+//             area, within a window of the cluster array) -- near-SAH quality; a binary node's record holds both child
+//             boxes + codes.  (The Karras 2012 radix tree it replaced in r01 is in the history: interior +7.5 %,
+//             Cornell-materials +34 %, caustics +60 % Mrays/s for PLOC, LAB_NOTES.md)
+//   reinsert  6 rounds of parallel reinsertion over the PLOC tree (k_ri_*, below): -8 % / -6 % node visits per ray;
+//             the boxes of the result are VALIDATED on the device (k_ri_validate) before the tree is used
 //   collapse  binary tree -> wide BVH with contiguous children (pt_trace.h), level by level: the children of a 4-wide
-//             node are the grandchildren of its binary node (GSP_COLLAPSE=greedy / the 8-wide variant: greedy
-//             surface-area choice of up to kWide children); inner children of a node = consecutive nodes, leaf
-//             children = consecutive triangle slots: the collapse defines the final triangle order
+//             node are the grandchildren of its binary node ("parity" collapse; the greedy surface-area choice loses on
+//             PLOC trees, 15.1 vs 14.7 nodes per extension ray, profiles/r03_collapse.txt, and is in the history);
+//             inner children of a node = consecutive nodes, leaf children = consecutive triangle slots: the collapse
+//             defines the final triangle order
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -213,106 +215,6 @@ __global__ __launch_bounds__(kBlock) void k_scatter(uint32_t n, const uint32_t* 
   slot_to_global[s] = g;
 }
 
-// common-prefix length of sorted keys i and j (index breaks ties), -1 outside the array
-__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
-  if (j < 0 || j >= n) return -1;
-  const uint64_t a = keys[i], b = keys[j];
-  if (a == b) return 64 + __clz((unsigned)(i ^ j));
-  return __clzll((long long)(a ^ b));
-}
-
-// Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees"
-__global__ __launch_bounds__(kBlock) void k_hierarchy(int n, const uint64_t* __restrict__ keys,
-                                                      int32_t* __restrict__ child_l, int32_t* __restrict__ child_r,
-                                                      int32_t* __restrict__ parent_int,
-                                                      int32_t* __restrict__ parent_leaf) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n - 1) return;
-  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
-  const int dmin = delta(keys, n, i, i - d);
-  int lmax = 2;
-  while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
-  int l = 0;
-  for (int t = lmax >> 1; t >= 1; t >>= 1)
-    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-  const int j = i + l * d;
-  const int dnode = delta(keys, n, i, j);
-  int s = 0;
-  int t = l;
-  do {
-    t = (t + 1) >> 1;
-    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-  } while (t > 1);
-  const int gamma = i + s * d + min(d, 0);
-  const int lo = min(i, j), hi = max(i, j);
-  if (lo == gamma) {
-    child_l[i] = make_leaf((uint32_t)gamma, 1);
-    parent_leaf[gamma] = i;
-  } else {
-    child_l[i] = gamma;
-    parent_int[gamma] = i;
-  }
-  if (hi == gamma + 1) {
-    child_r[i] = make_leaf((uint32_t)(gamma + 1), 1);
-    parent_leaf[gamma + 1] = i;
-  } else {
-    child_r[i] = gamma + 1;
-    parent_int[gamma + 1] = i;
-  }
-  if (i == 0) parent_int[0] = -1;
-}
-
-__device__ __forceinline__ void child_box(int32_t code, const q4* __restrict__ leaf_lo, const q4* __restrict__ leaf_hi,
-                                          const q4* int_lo, const q4* int_hi, q4& lo, q4& hi) {
-  if (code < 0) {
-    const uint32_t slot = ((uint32_t)~code) >> 2;
-    lo = leaf_lo[slot];
-    hi = leaf_hi[slot];
-  } else {
-    lo = int_lo[code];
-    hi = int_hi[code];
-  }
-}
-
-// Bottom-up fit: the second thread to reach a node (arrival counter) owns it.
-// Boxes written by the sibling subtree come from another CU / XCD, hence the
-// agent-scope fences on both sides of the counter (MI355X: per-CU L1 and
-// per-XCD L2 are not coherent).
-__global__ __launch_bounds__(kBlock) void k_fit(int n, const int32_t* __restrict__ child_l,
-                                                const int32_t* __restrict__ child_r,
-                                                const int32_t* __restrict__ parent_int,
-                                                const int32_t* __restrict__ parent_leaf,
-                                                const q4* __restrict__ leaf_lo, const q4* __restrict__ leaf_hi,
-                                                q4* int_lo, q4* int_hi, uint32_t* arrive, q4* __restrict__ nodes,
-                                                uint32_t* __restrict__ max_depth) {
-  const int s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= n) return;
-  int node = parent_leaf[s];
-  uint32_t depth = 0;
-  while (node >= 0) {
-    ++depth;
-    __threadfence();
-    const uint32_t old = atomicAdd(&arrive[node], 1u);
-    if (old == 0) break;  // sibling subtree not finished: it will continue from here
-    __threadfence();
-    const int32_t cl = child_l[node], cr = child_r[node];
-    q4 llo, lhi, rlo, rhi;
-    child_box(cl, leaf_lo, leaf_hi, int_lo, int_hi, llo, lhi);
-    child_box(cr, leaf_lo, leaf_hi, int_lo, int_hi, rlo, rhi);
-    q4* N = nodes + 4ll * node;
-    N[0] = mkq(llo.x, llo.y, llo.z, lhi.x);
-    N[1] = mkq(lhi.y, lhi.z, rlo.x, rlo.y);
-    N[2] = mkq(rlo.z, rhi.x, rhi.y, rhi.z);
-    N[3] = mkq(__uint_as_float((uint32_t)cl), __uint_as_float((uint32_t)cr), 0.0f, 0.0f);
-    int_lo[node] = mkq(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.0f);
-    int_hi[node] = mkq(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
-    node = parent_int[node];
-  }
-  // a thread that walked to the root saw every level of its own path
-  if (node < 0) atomicMax(max_depth, depth);
-}
-
-
 // ---- PLOC ------------------------------------------------------------------------------------
 #ifndef GSP_PLOC_RADIUS
 #define GSP_PLOC_RADIUS 32
@@ -428,7 +330,7 @@ __device__ __forceinline__ void load2(const q4* __restrict__ nodes2, int32_t b, 
 #ifndef GSP_REINSERT_ROUNDS
 #define GSP_REINSERT_ROUNDS 6
 #endif
-constexpr int kReinsertRounds = GSP_REINSERT_ROUNDS;  // GSP_BVH_REINSERT=rounds overrides (0: the plain PLOC tree)
+constexpr int kReinsertRounds = GSP_REINSERT_ROUNDS;  // gsp_ctx_options.reinsert_rounds overrides (1 = none: the plain PLOC tree)
 #ifndef GSP_RI_STACK
 #define GSP_RI_STACK 48
 #endif
@@ -632,6 +534,11 @@ __global__ __launch_bounds__(kBlock) void k_ri_apply(uint32_t n, q4* nodes2, int
 // The hand-over between the finisher of a child and the thread that continues from the parent goes through memory the
 // XCDs agree on: write-through (sc1) stores, drained before the arrive counter is bumped, and sc1 loads behind the counter --
 // NOT __threadfence(), which at agent scope is an L2 write-back + invalidate per call (the first version spent 5 ms a round there).
+// ARCHITECTURE ASSUMPTION (gfx942 / gfx950): an agent-scope atomic store / load is emitted with sc1 and goes through to
+// the memory the eight XCDs share instead of staying in the issuing XCD's L2, and `s_waitcnt vmcnt(0)` retires this
+// thread's stores before the counter is bumped.  A box that arrived late would make a parent too SMALL -- wrong hits, not
+// a crash -- so the result is checked: k_ri_validate below recomputes every inner node's box from its children's after
+// the last round (one pass, ~0.1 ms for a million triangles) and the build fails loudly on any difference.
 __device__ __forceinline__ void ri_store_word(float* p, float v) {
   __hip_atomic_store((uint32_t*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -664,57 +571,54 @@ __global__ __launch_bounds__(kBlock) void k_ri_refit(uint32_t n, q4* nodes2, con
   }
 }
 
+// every binary inner node: the box its parent's record holds for it == the union of the two boxes its own record holds,
+// bit for bit (the refit computes exactly that union).  Runs in a launch of its own after the last round, so it reads
+// what the memory holds, not what a cache of the refit kernel saw.
+__global__ __launch_bounds__(kBlock) void k_ri_validate(uint32_t n, int32_t root, const q4* __restrict__ nodes2,
+                                                        const int32_t* __restrict__ parent_int, uint32_t* __restrict__ bad) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n - 1u || (int32_t)t == root) return;
+  const int32_t pp = parent_int[t];
+  if (pp < 0) {
+    atomicAdd(bad, 1u);
+    return;
+  }
+  const RiRec r = ri_load(nodes2, (int32_t)t), rp = ri_load(nodes2, pp);
+  const int s = rp.code[0] == (int32_t)t ? 0 : 1;
+  const bool ok = rp.code[s] == (int32_t)t && rp.lo[s].x == fminf(r.lo[0].x, r.lo[1].x) && rp.lo[s].y == fminf(r.lo[0].y, r.lo[1].y) &&
+                  rp.lo[s].z == fminf(r.lo[0].z, r.lo[1].z) && rp.hi[s].x == fmaxf(r.hi[0].x, r.hi[1].x) &&
+                  rp.hi[s].y == fmaxf(r.hi[0].y, r.hi[1].y) && rp.hi[s].z == fmaxf(r.hi[0].z, r.hi[1].z);
+  if (!ok) atomicAdd(bad, 1u);
+}
+
 // ---- collapse of the binary tree into the wide tree (pt_trace.h), one level per launch pair ---------------------------
 // A work item of a level = the binary node that becomes a wide node; the items of a level are consecutive wide nodes,
 // and so are the inner children of every node (exclusive scan of the per-item inner-child counts), which is what lets
 // a traversal name "the children of node X still to visit" as {base, which ones} instead of one pointer per child.
 // Leaf children likewise take consecutive triangle slots: the collapse defines the final triangle order.
-// Greedy surface-area collapse: the children of binary node b, then repeatedly the inner child with the largest box is
-// replaced by its own two children until the node is full (kWide) or only leaves are left.
-// mode 1 (GSP_COLLAPSE=parity, 4-wide only; r01 / r02's default): the children are the grandchildren of b.
-__device__ __forceinline__ int gather_children(const q4* __restrict__ nodes2, int32_t b, Pick* e, int mode) {
-  load2(nodes2, b, e[0], e[1]);
-  int cnt = 2;
-  if (mode == 1 && kWide == 4) {
-    const Pick l = e[0], r = e[1];
-    cnt = 0;
-    if (l.code >= 0) {
-      load2(nodes2, l.code, e[0], e[1]);
-      cnt = 2;
-    } else {
-      e[cnt++] = l;
-    }
-    if (r.code >= 0) {
-      load2(nodes2, r.code, e[cnt], e[cnt + 1]);
-      cnt += 2;
-    } else {
-      e[cnt++] = r;
-    }
-    return cnt;
+// The children of a wide node are the grandchildren of its binary node b ("parity" collapse): 2 to 4 of them.
+__device__ __forceinline__ int gather_children(const q4* __restrict__ nodes2, int32_t b, Pick* e) {
+  Pick l, r;
+  load2(nodes2, b, l, r);
+  int cnt = 0;
+  if (l.code >= 0) {
+    load2(nodes2, l.code, e[0], e[1]);
+    cnt = 2;
+  } else {
+    e[cnt++] = l;
   }
-  while (cnt < kWide) {
-    int best = -1;
-    float best_area = -1.0f;
-    for (int k = 0; k < cnt; ++k) {
-      if (e[k].code < 0) continue;
-      const float ar = half_area(e[k].lo, e[k].hi);
-      if (ar > best_area) {
-        best_area = ar;
-        best = k;
-      }
-    }
-    if (best < 0) break;
-    Pick x, y;
-    load2(nodes2, e[best].code, x, y);
-    e[best] = x;
-    e[cnt++] = y;
+  if (r.code >= 0) {
+    load2(nodes2, r.code, e[cnt], e[cnt + 1]);
+    cnt += 2;
+  } else {
+    e[cnt++] = r;
   }
   return cnt;
 }
 
 __global__ __launch_bounds__(kBlock) void k_wide_count(int count, const int32_t* __restrict__ items,
                                                        const q4* __restrict__ nodes2, uint32_t* __restrict__ n_inner,
-                                                       uint32_t* __restrict__ n_leaf, int mode) {
+                                                       uint32_t* __restrict__ n_leaf) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t > count) return;
   if (t == count) {  // the scans run over count + 1 elements: the last one yields the totals
@@ -723,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_count(int count, const int32_t*
     return;
   }
   Pick e[kWide];
-  const int cnt = gather_children(nodes2, items[t], e, mode);
+  const int cnt = gather_children(nodes2, items[t], e);
   uint32_t ni = 0;
   for (int k = 0; k < cnt; ++k) ni += e[k].code >= 0 ? 1u : 0u;
   n_inner[t] = ni;
@@ -736,34 +640,13 @@ __global__ __launch_bounds__(kBlock) void k_wide_emit(int count, const int32_t* 
                                                       const q4* __restrict__ nodes2, const uint32_t* __restrict__ inner_off,
                                                       const uint32_t* __restrict__ leaf_off, uint32_t node_first,
                                                       uint32_t child_first, uint32_t tri_first, q4* __restrict__ nodes_out,
-                                                      int32_t* __restrict__ next_items, uint32_t* __restrict__ tri_src, int mode) {
+                                                      int32_t* __restrict__ next_items, uint32_t* __restrict__ tri_src) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= count) return;
   Pick e[kWide];
-  const int cnt = gather_children(nodes2, items[t], e, mode);
+  const int cnt = gather_children(nodes2, items[t], e);
   const uint32_t child_base = child_first + inner_off[t], tri_base = tri_first + leaf_off[t];
   q4* out = nodes_out + (size_t)kNodeQuads * (node_first + (uint32_t)t);
-#if GSP_WIDE == 8
-  WideChild wc[8], by_slot[8];
-  int slot_of[8];
-  for (int k = 0; k < cnt; ++k) wc[k].lo = e[k].lo, wc[k].hi = e[k].hi;
-  assign_slots_w8(wc, cnt, slot_of);
-  uint32_t imask = 0, lmask = 0;
-  int32_t code_of[8];
-  for (int s = 0; s < 8; ++s) code_of[s] = 0;
-  for (int k = 0; k < cnt; ++k) {
-    by_slot[slot_of[k]] = wc[k];
-    code_of[slot_of[k]] = e[k].code;
-    if (e[k].code >= 0) imask |= 1u << slot_of[k];
-    else lmask |= 1u << slot_of[k];
-  }
-  encode_node_w8(out, by_slot, imask, lmask, child_base, tri_base);
-  uint32_t ri = 0, rl = 0;
-  for (int s = 0; s < 8; ++s) {  // ranks in slot order
-    if ((imask >> s) & 1u) next_items[child_base - child_first + ri++] = code_of[s];
-    else if ((lmask >> s) & 1u) tri_src[tri_base + rl++] = ((uint32_t)~code_of[s]) >> 2;
-  }
-#else
   WideChild wc[4];
   int ni = 0, nl = 0;
   for (int k = 0; k < cnt; ++k)  // inner children first, in the order the collapse found them
@@ -779,7 +662,6 @@ __global__ __launch_bounds__(kBlock) void k_wide_emit(int count, const int32_t* 
       ++nl;
     }
   encode_node_w4(out, wc, ni, nl, child_base, tri_base);
-#endif
 }
 
 // triangle packets into their final slots: slot s takes what Morton slot tri_src[s] held
@@ -832,7 +714,11 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   const uint32_t n = in.num_tris;
   // triangle slots are handed out from kFirstSlot on: a node's tri_base - ni (pt_trace.h) is then never negative and
   // fits the 28 bits the traversal packs it into; the leading slots stay all-zero triangles (det == 0: never hit)
-  const uint32_t slots = n + kFirstSlot;
+  // ... and kWide - 1 all-zero slots FOLLOW the last triangle: an unused child position of a node is marked only by an inverted
+  // quantised box, and when a node's extent is below ~8 ulp of the ray's distance to it the 8-ulp slack of the box test lets
+  // such a position through as "leaf slot tri_base + p" -- a neighbouring triangle for most nodes (harmless: tested, and
+  // accepted only if really hit), the slots behind the array for the last one
+  const uint32_t slots = n + kFirstSlot + (kWide - 1);
   out.num_tris = n;
   out.first_slot = kFirstSlot;
   out.num_nodes = 0;
@@ -848,11 +734,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   out.depth = 1;
   if (n == 0) {  // one node without children: every ray misses
     q4 node[kNodeQuads];
-#if GSP_WIDE == 8
-    encode_node_w8(node, nullptr, 0u, 0u, 0u, kFirstSlot);
-#else
     encode_node_w4(node, nullptr, 0, 0, 0u, kFirstSlot);
-#endif
     GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeAllocMin));
     GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
     out.bytes += kNodeBytes;
@@ -919,11 +801,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     WideChild c[8];
     c[0].lo = box[0];
     c[0].hi = box[1];
-#if GSP_WIDE == 8
-    encode_node_w8(node, c, 0u, 1u, 0u, kFirstSlot);
-#else
     encode_node_w4(node, c, 0, 1, 0u, kFirstSlot);
-#endif
     GSP_HIP_TRY(hipMalloc((void**)&out.nodes, kNodeAllocMin));
     GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
     GSP_HIP_TRY(hipMemcpyAsync(out.tri_isect + 3ull * kFirstSlot, isect_m, 48, hipMemcpyDeviceToDevice, stream));
@@ -936,14 +814,9 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   }
 
   int32_t root2 = 0;  // binary root
+  uint32_t* ri_bad = nullptr;  // violations k_ri_validate counted (read back with the first collapse level's totals)
   {
-    const char* mode = getenv("GSP_BVH");
-    if (mode && std::string(mode) == "lbvh") {
-      hipLaunchKernelGGL(k_hierarchy, dim3(blocks_for(n - 1)), dim3(kBlock), 0, stream, (int)n, keys_out, child_l, child_r,
-                         parent_int, parent_leaf);
-      hipLaunchKernelGGL(k_fit, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, child_l, child_r, parent_int,
-                         parent_leaf, leaf_lo, leaf_hi, int_lo, int_hi, arrive, nodes2, d_depth);
-    } else {
+    {
       // PLOC: cluster arrays ping-pong between (code_a, leaf_lo/hi) and (code_b, int_lo/hi)
       int32_t *code_a = child_l, *code_b = child_r, *nn = (int32_t*)arrive;
       uint32_t *keep = flag, *isnew = idx4, *kpos, *npos;
@@ -985,8 +858,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       GSP_HIP_TRY(hipStreamSynchronize(stream));
       // leaf_lo/leaf_hi may have been overwritten by the ping-pong: nothing below reads them again
       // ---- parallel reinsertion rounds (above): no host round trip inside
-      const char* re = getenv("GSP_BVH_REINSERT");
-      const int rounds = re ? std::min(std::max(atoi(re), 0), 64) : kReinsertRounds;
+      const int rounds = in.reinsert_rounds < 0 ? kReinsertRounds : std::min(in.reinsert_rounds, 64);
       if (rounds > 0 && n >= 16) {
         const size_t idx = 2ull * n;
         int32_t *mv_x, *mv_xp;
@@ -1010,14 +882,10 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
           hipLaunchKernelGGL(k_ri_refit, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, nodes2, parent_int, parent_leaf, arrive);
           GSP_HIP_TRY(hipGetLastError());
         }
-        if (getenv("GSP_BVH_TRACE")) {
-          uint32_t h[64];
-          GSP_HIP_TRY(hipMemcpyAsync(h, applied, sizeof(h), hipMemcpyDeviceToHost, stream));
-          GSP_HIP_TRY(hipStreamSynchronize(stream));
-          fprintf(stderr, "reinsertion: moves applied per round:");
-          for (int r = 0; r < rounds; ++r) fprintf(stderr, " %u", h[r]);
-          fprintf(stderr, "\n");
-        }
+        GSP_HIP_TRY(S.alloc(&ri_bad, 1));
+        GSP_HIP_TRY(hipMemsetAsync(ri_bad, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_ri_validate, dim3(blocks_for(n - 1)), dim3(kBlock), 0, stream, n, root2, nodes2, parent_int, ri_bad);
+        GSP_HIP_TRY(hipGetLastError());
       }
     }
   }
@@ -1039,20 +907,24 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   // 4-wide default: the parity collapse (children = grandchildren).  On PLOC trees it beats the greedy surface-area
   // collapse -- bench scene 14.7 vs 15.1 nodes per extension ray, 7.5 vs 9.2 per shadow ray (profiles/r03_collapse.txt;
   // the CPU probe agrees: 10.2 vs 10.4, 7.7 vs 8.3) -- while on top-down SAH trees it is the other way round.
-  const char* cmode = getenv("GSP_COLLAPSE");
-  const int mode = cmode ? (std::string(cmode) == "parity" ? 1 : 0) : (kWide == 4 ? 1 : 0);
   while (count > 0) {
-    hipLaunchKernelGGL(k_wide_count, dim3(blocks_for(count + 1ull)), dim3(kBlock), 0, stream, (int)count, items_a, nodes2, n_inner, n_leaf, mode);
+    hipLaunchKernelGGL(k_wide_count, dim3(blocks_for(count + 1ull)), dim3(kBlock), 0, stream, (int)count, items_a, nodes2, n_inner, n_leaf);
     GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, n_inner, inner_off, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
     GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, n_leaf, leaf_off, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
     const uint32_t child_first = node_first + count;
     hipLaunchKernelGGL(k_wide_emit, dim3(blocks_for(count)), dim3(kBlock), 0, stream, (int)count, items_a, nodes2, inner_off, leaf_off,
-                       node_first, child_first, tri_done, wide, items_b, tri_src, mode);
-    uint32_t totals[2] = {0, 0};
+                       node_first, child_first, tri_done, wide, items_b, tri_src);
+    uint32_t totals[2] = {0, 0}, bad = 0;
     GSP_HIP_TRY(hipMemcpyAsync(&totals[0], inner_off + count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSP_HIP_TRY(hipMemcpyAsync(&totals[1], leaf_off + count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (levels == 0 && ri_bad) GSP_HIP_TRY(hipMemcpyAsync(&bad, ri_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSP_HIP_TRY(hipStreamSynchronize(stream));
     GSP_HIP_TRY(hipGetLastError());
+    if (bad) {
+      err = "BVH build: " + std::to_string(bad) + " node boxes of the reinserted tree do not bound their children (internal error: "
+            "the cross-XCD hand-over of k_ri_refit failed)";
+      return GSP_ERR_DEVICE;
+    }
     node_first = child_first;
     tri_done += totals[1];
     count = totals[0];
@@ -1069,7 +941,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   }
   const uint32_t num_nodes = node_first;
   if (num_nodes >= kMaxNodes) {
-    err = "scene too large: more BVH nodes than the traversal's node index holds";
+    err = "scene too large: more BVH nodes than the traversal's node index holds (internal error: gsp_upload_scene bounds the triangle count)";
     return GSP_ERR_INVALID;
   }
   out.num_nodes = num_nodes;

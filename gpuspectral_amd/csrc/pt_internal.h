@@ -41,17 +41,18 @@ struct BuildInput {
   const float* positions;  // device, object space
   const float* normals;    // device
   uint32_t num_tris;
+  int reinsert_rounds = -1;  // parallel-reinsertion rounds of the build, < 0 = the default (gsp_ctx_options.reinsert_rounds - 1)
 };
 
 // ---- internal entry points of a context for pt_multi.hip (same library, not exported) ------------------------------
 // Completes everything queued and returns the context's compact RGBA32F accumulate buffer (device memory on the
 // context's device, num_pixels records) and the stream its copies are ordered on.
 __attribute__((visibility("hidden"))) int gsp_internal_accum(gsp_context* ctx, void** accum, uint64_t* num_pixels, hipStream_t* stream);
-// Share of the device memory that is free when a render starts that this context's path pool + result ring may take
-// (default 0.4): several shares of one gsp_multi on one device size their pools concurrently.
-__attribute__((visibility("hidden"))) void gsp_internal_set_memory_share(gsp_context* ctx, double fraction);
+// The options a context was created with, defaults filled in (pt_multi.hip divides memory_share among the shares of a device).
+__attribute__((visibility("hidden"))) void gsp_internal_resolve_options(const gsp_ctx_options* in, gsp_ctx_options* out);
 
-// Builds the LBVH on `stream`.  Returns GSP_OK or an error code with `err` set.
+// Bakes the instances' triangles to world space and builds the wide BVH (PLOC + reinsertion + collapse) on `stream`.
+// Returns GSP_OK or an error code with `err` set.
 int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::string& err);
 void free_bvh(DeviceBvh& b);
 

@@ -10,7 +10,9 @@
 // single-process communicator (ncclCommInitAll) -- the north_star's "single RCCL gather of HDR tiles".  A device list
 // with repeats (several shares on one GPU: how the one-GPU test box runs partition + gather + scatter with 2 / 3 / 8
 // shares) cannot form a communicator -- RCCL wants one rank per device -- and takes the peer-copy route
-// (hipMemcpyPeerAsync, a plain copy on the same device); GSP_MULTI_GATHER=copy / rccl forces a route.
+// (hipMemcpyPeerAsync, a plain copy on the same device); so does a node where librccl is absent or ncclCommInitAll fails
+// (no /dev/shm, P2P disabled, ...) unless gsp_ctx_options.gather_route demands RCCL.  librccl is loaded with dlopen at
+// the first multi-GPU create: a single-GPU host application links and loads this library without it.
 //
 // A C++ caller (the reference's host is C++: S/main.cpp:15-30, S/renderer/Renderer.h:22-25,44) gets N GPUs through
 // this file without Python or torch; bench.py's one-process-per-GPU path (torch.distributed, RCCL gather) uses the
@@ -28,12 +30,55 @@
 #include <thread>
 #include <vector>
 
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the entry points are resolved at run time (rccl_api below)
 
 #include "pt_internal.h"
 
 namespace gsp {
 namespace {
+
+// The six RCCL entry points of the gather, from librccl.so.1 as the loader finds it (LD_LIBRARY_PATH, ld.so.conf, rpath)
+// or from the ROCm default location.  Loaded once; a missing library is an error message, not a load failure of ours.
+struct RcclApi {
+  void* handle = nullptr;
+  std::string err;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+const RcclApi& rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (a.handle) break;
+      if (const char* e = dlerror()) a.err = e;
+    }
+    if (!a.handle) {
+      a.err = "librccl not loadable (" + a.err + ")";
+      return a;
+    }
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(a.handle, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
+    a.Send = (decltype(a.Send))dlsym(a.handle, "ncclSend");
+    a.Recv = (decltype(a.Recv))dlsym(a.handle, "ncclRecv");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv || !a.GetErrorString) {
+      a.err = "librccl lacks an entry point of the gather";
+      dlclose(a.handle);
+      a.handle = nullptr;
+    }
+    return a;
+  }();
+  return api;
+}
 
 // frame[ids[i]] = compact[i]: the tiles of one share into the full frame (16-B records, coalesced reads; writes are
 // runs of 32 pixels = 512 B)
@@ -66,6 +111,7 @@ struct gsp_multi {
   std::vector<hipStream_t> comm_streams;  // one per share, on its device
   std::vector<char> peer_ok;              // per share: peer access towards devices[0] was obtained (copy route)
   bool use_rccl = false;
+  std::string route_note;                       // why the gathers take the route they take
   uint64_t rccl_gathers = 0, copy_gathers = 0;  // gathers through each route so far (gsp_multi_gather_route)
 };
 
@@ -160,7 +206,7 @@ void gsp_multi_destroy(gsp_multi* m) {
   if (!m) return;
   for (size_t r = 0; r < m->comms.size(); ++r) {
     (void)hipSetDevice(m->devices[r]);
-    if (m->comms[r]) (void)ncclCommDestroy(m->comms[r]);
+    if (m->comms[r]) (void)rccl_api().CommDestroy(m->comms[r]);
   }
   for (size_t r = 0; r < m->comm_streams.size(); ++r) {
     (void)hipSetDevice(m->devices[r]);
@@ -175,32 +221,39 @@ void gsp_multi_destroy(gsp_multi* m) {
   delete m;
 }
 
-int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
+int gsp_multi_create(const int* devices, int n, gsp_multi** out) { return gsp_multi_create_ex(devices, n, nullptr, out); }
+
+int gsp_multi_create_ex(const int* devices, int n, const gsp_ctx_options* options, gsp_multi** out) {
   if (!out) return GSP_ERR_INVALID;
   *out = nullptr;
   if (!devices || n <= 0 || n > 64) {
     set_multi_create_error("gsp_multi_create: need 1..64 devices");
     return GSP_ERR_INVALID;
   }
+  if (options && options->struct_size < 8) {
+    set_multi_create_error("gsp_ctx_options.struct_size is not set");
+    return GSP_ERR_INVALID;
+  }
+  gsp_ctx_options opt;
+  gsp_internal_resolve_options(options, &opt);
   gsp_multi* m = new gsp_multi();
   m->devices.assign(devices, devices + n);
+  bool repeats = false;
   for (int r = 0; r < n; ++r) {
+    // shares that sit on one device size their path pools concurrently: each takes its part of the share a lone context may
+    int same = 0;
+    for (int q = 0; q < n; ++q) same += devices[q] == devices[r] ? 1 : 0;
+    repeats = repeats || same > 1;
+    gsp_ctx_options o = opt;
+    o.memory_share = opt.memory_share / same;
     gsp_context* c = nullptr;
-    int rc = gsp_ctx_create(devices[r], &c);
+    int rc = gsp_ctx_create_ex(devices[r], &o, &c);
     if (rc != GSP_OK) {
       set_multi_create_error(std::string("share ") + std::to_string(r) + ": " + gsp_last_error(nullptr));
       gsp_multi_destroy(m);
       return rc;
     }
     m->ctx.push_back(c);
-  }
-  // shares that sit on one device size their path pools concurrently: each takes its part of the 40 % a lone context may
-  bool repeats = false;
-  for (int r = 0; r < n; ++r) {
-    int same = 0;
-    for (int q = 0; q < n; ++q) same += devices[q] == devices[r] ? 1 : 0;
-    repeats = repeats || same > 1;
-    gsp_internal_set_memory_share(m->ctx[r], 0.4 / same);
   }
   // peer access towards the gathering device (xGMI) for the copy route; a share on the gathering device needs none
   m->peer_ok.assign(n, 1);
@@ -215,29 +268,50 @@ int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
       (void)hipGetLastError();  // (without peer access hipMemcpyPeerAsync stages through the host: slower, still correct)
     }
   }
-  // RCCL communicator over the shares (ranks = share indices): needs one device per rank
-  const char* route = getenv("GSP_MULTI_GATHER");
-  const bool want_rccl = route ? std::string(route) == "rccl" : (n > 1 && !repeats);
-  if (want_rccl && !repeats) {
-    m->comms.assign(n, nullptr);
-    m->comm_streams.assign(n, nullptr);
-    const ncclResult_t nr = ncclCommInitAll(m->comms.data(), n, devices);
-    if (nr != ncclSuccess) {
-      set_multi_create_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(nr));
-      m->comms.clear();
-      gsp_multi_destroy(m);
-      return GSP_ERR_DEVICE;
+  // RCCL communicator over the shares (ranks = share indices): needs one device per rank.  GSP_GATHER_AUTO falls back to
+  // the copy route when librccl or the communicator is unavailable; GSP_GATHER_RCCL makes that an error.
+  const bool forced = opt.gather_route == GSP_GATHER_RCCL;
+  const bool want_rccl = forced || (opt.gather_route == GSP_GATHER_AUTO && n > 1 && !repeats);
+  m->route_note = opt.gather_route == GSP_GATHER_COPY ? "copy route requested" : (n == 1 ? "one share: no gather" : "device list with repeats: RCCL wants one rank per device");
+  if (want_rccl && repeats) {
+    set_multi_create_error("GSP_GATHER_RCCL with a repeated device: RCCL wants one rank per device");
+    gsp_multi_destroy(m);
+    return GSP_ERR_INVALID;
+  }
+  if (want_rccl) {
+    const RcclApi& api = rccl_api();
+    std::string why;
+    if (!api.handle) {
+      why = api.err;
+    } else {
+      m->comms.assign(n, nullptr);
+      const ncclResult_t nr = api.CommInitAll(m->comms.data(), n, devices);
+      if (nr != ncclSuccess) {
+        why = std::string("ncclCommInitAll: ") + api.GetErrorString(nr);
+        m->comms.clear();
+      }
     }
-    for (int r = 0; r < n; ++r) {
-      hipError_t se = hipSetDevice(devices[r]);
-      if (se == hipSuccess) se = hipStreamCreateWithFlags(&m->comm_streams[r], hipStreamNonBlocking);
-      if (se != hipSuccess) {
-        set_multi_create_error(std::string("gsp_multi_create (RCCL stream): ") + hipGetErrorString(se));
+    if (!why.empty()) {
+      if (forced) {
+        set_multi_create_error(why);
         gsp_multi_destroy(m);
         return GSP_ERR_DEVICE;
       }
+      m->route_note = "copy route: " + why;
+    } else {
+      m->comm_streams.assign(n, nullptr);
+      for (int r = 0; r < n; ++r) {
+        hipError_t se = hipSetDevice(devices[r]);
+        if (se == hipSuccess) se = hipStreamCreateWithFlags(&m->comm_streams[r], hipStreamNonBlocking);
+        if (se != hipSuccess) {
+          set_multi_create_error(std::string("gsp_multi_create (RCCL stream): ") + hipGetErrorString(se));
+          gsp_multi_destroy(m);
+          return GSP_ERR_DEVICE;
+        }
+      }
+      m->use_rccl = true;
+      m->route_note = "RCCL send / recv group";
     }
-    m->use_rccl = true;
   }
   hipError_t e = hipSetDevice(devices[0]);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
@@ -246,6 +320,7 @@ int gsp_multi_create(const int* devices, int n, gsp_multi** out) {
     gsp_multi_destroy(m);
     return GSP_ERR_DEVICE;
   }
+  m->err = "gather route: " + m->route_note;  // (readable through gsp_multi_last_error until a call fails)
   *out = m;
   return GSP_OK;
 }
@@ -259,6 +334,33 @@ int gsp_multi_upload_scene(gsp_multi* m, const gsp_scene_desc* scene) {
     return GSP_ERR_INVALID;
   }
   return for_each_share(m, [&](size_t r) { return gsp_upload_scene(m->ctx[r], scene); });
+}
+
+int gsp_multi_update_camera(gsp_multi* m, const gsp_camera* camera) {
+  if (!m) return GSP_ERR_INVALID;
+  if (!camera) {
+    m->err = "gsp_multi_update_camera: null camera";
+    return GSP_ERR_INVALID;
+  }
+  return for_each_share(m, [&](size_t r) { return gsp_update_camera(m->ctx[r], camera); });
+}
+
+int gsp_multi_update_instances(gsp_multi* m, const gsp_instance* instances, uint32_t num_instances) {
+  if (!m) return GSP_ERR_INVALID;
+  if (!instances && num_instances) {
+    m->err = "gsp_multi_update_instances: null instances";
+    return GSP_ERR_INVALID;
+  }
+  return for_each_share(m, [&](size_t r) { return gsp_update_instances(m->ctx[r], instances, num_instances); });
+}
+
+int gsp_multi_update_tables(gsp_multi* m, const gsp_scene_desc* scene) {
+  if (!m) return GSP_ERR_INVALID;
+  if (!scene) {
+    m->err = "gsp_multi_update_tables: null scene";
+    return GSP_ERR_INVALID;
+  }
+  return for_each_share(m, [&](size_t r) { return gsp_update_tables(m->ctx[r], scene); });
 }
 
 int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height) {
@@ -348,16 +450,17 @@ int gsp_multi_gather(gsp_multi* m, void** device_frame) {
     }
   if (m->use_rccl) {
     // the one exchange of the job, as ONE RCCL group: share r sends its tiles, GPU 0 receives them side by side
-    ncclResult_t nr = ncclGroupStart();
+    const RcclApi& api = rccl_api();
+    ncclResult_t nr = api.GroupStart();
     for (uint32_t r = 0; r < world && nr == ncclSuccess; ++r) {
       if (cnt[r] == 0) continue;
-      nr = ncclSend(src[r], cnt[r] * 4, ncclFloat, 0, m->comms[r], m->comm_streams[r]);
-      if (nr == ncclSuccess) nr = ncclRecv(m->staging + m->offset[r], cnt[r] * 4, ncclFloat, (int)r, m->comms[0], m->comm_streams[0]);
+      nr = api.Send(src[r], cnt[r] * 4, ncclFloat, 0, m->comms[r], m->comm_streams[r]);
+      if (nr == ncclSuccess) nr = api.Recv(m->staging + m->offset[r], cnt[r] * 4, ncclFloat, (int)r, m->comms[0], m->comm_streams[0]);
     }
-    const ncclResult_t ge = ncclGroupEnd();
+    const ncclResult_t ge = api.GroupEnd();
     if (nr == ncclSuccess) nr = ge;
     if (nr != ncclSuccess) {
-      m->err = std::string("RCCL gather: ") + ncclGetErrorString(nr);
+      m->err = std::string("RCCL gather: ") + api.GetErrorString(nr);
       return GSP_ERR_DEVICE;
     }
     for (uint32_t r = 0; r < world; ++r) {
@@ -442,6 +545,7 @@ int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
       t.memoised_rays += s.memoised_rays;
       t.memo_build_rays += s.memo_build_rays;
       t.bvh_depth = std::max(t.bvh_depth, s.bvh_depth);
+      t.scene_updates = std::max(t.scene_updates, s.scene_updates);
       t.extend_launches += s.extend_launches;
       t.device_bytes += s.device_bytes;
       t.render_seconds = std::max(t.render_seconds, s.render_seconds);

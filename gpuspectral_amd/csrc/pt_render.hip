@@ -644,6 +644,16 @@ struct gsp_context {
   uint32_t num_lights = 0;
   gsp_camera camera{};
   double bvh_build_ms = 0.0;
+  // what gsp_upload_scene leaves resident for the per-frame edits (gsp_update_instances re-bakes from it, as the reference
+  // keeps the BLAS of a mesh and rebuilds the TLAS, Renderer.cpp:122-131 / PathTracer.cpp:10-19): the object-space
+  // vertex arrays (72 B per triangle), the instance table and its host copy, the table sizes
+  DevBuf<gsp_instance> d_inst;
+  DevBuf<float> d_invt, d_pos, d_nrm, d_uv;
+  DevBuf<uint32_t> d_first;
+  std::vector<gsp_instance> h_inst;
+  uint32_t num_bsdfs[GSP_BSDF_TYPE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t num_vertices = 0, total_tris = 0;
+  gsp_ctx_options opt{};  // resolved at creation (gsp_internal_resolve_options)
 
   // frame
   bool have_frame = false;
@@ -722,12 +732,12 @@ struct gsp_context {
   };
   static constexpr int kMaxLanes = 2;
   Lane lanes[kMaxLanes];
-  uint32_t num_lanes = 1;  // GSP_LANES=2: +11 % with 8 M-path pools, +-0 with the 32 M-path pool and k_finish
+  uint32_t num_lanes = 1;  // gsp_ctx_options.lanes = 2: +11 % with 8 M-path pools, +-0 with the 32 M-path pool and k_finish
   gsp_render_params pipe_params{};  // integrator constants the lanes are running with
   uint32_t folded_idle = 0;         // timestamps folded when no pipeline is running (gsp_peek)
-  uint32_t finish_paths = 0;        // k_finish takes over below this many live paths (GSP_FINISH_PATHS, 0 = never)
-  bool primary_memo = true;         // GSP_PRIMARY_MEMO=0: every sample traces its camera ray
-  double memory_share = 0.4;        // of the free device memory, for the path pool + result ring (gsp_internal_set_memory_share)
+  uint32_t finish_paths = 0;        // k_finish takes over below this many live paths (gsp_ctx_options.finish_paths; 0 = never)
+  bool primary_memo = true;         // gsp_ctx_options.primary_memo = 2: every sample traces its camera ray
+  double memory_share = 0.4;        // of the free device memory, for the path pool + result ring (gsp_ctx_options.memory_share)
   bool pipe_active = false;
 
   SceneView view() const {
@@ -815,6 +825,7 @@ void gsp_default_render_params(gsp_render_params* p) {
   p->max_depth = 50;       // raygen.rgen:27
   p->rr_start_depth = 10;  // raygen.rgen:66
   p->clamp = 20.0f;        // raygen.rgen:60
+  p->nee = 1;              // `#define NEE true`, rayhit.rchit:656
 }
 
 int gsp_abi_version(void) { return GSP_ABI_VERSION; }
@@ -842,10 +853,53 @@ static void set_create_error(const std::string& s) {
 
 static int pipeline_drain(gsp_context* ctx);
 void gsp_ctx_destroy(gsp_context* ctx);
+int gsp_ctx_create_ex(int device, const gsp_ctx_options* options, gsp_context** out);
 
-int gsp_ctx_create(int device, gsp_context** out) {
+void gsp_default_ctx_options(gsp_ctx_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = (uint32_t)sizeof(*o);
+  o->lanes = 1;
+  o->pool_paths = 96ull << 20;   // r03 scan: 32 M 7.84 / 48 M 7.98 / 64 M 8.09 / 96 M 8.24 / 128 M 8.21 Grays/s (profiles/r03_ab_pool_size.txt)
+  o->ring_bytes = 16ull << 30;
+  o->memory_share = 0.4;
+  o->primary_memo = 1;
+  o->finish_paths = kFinishPaths;
+  o->reinsert_rounds = 7;        // 6 rounds
+  o->gather_route = GSP_GATHER_AUTO;
+}
+
+}  // extern "C"
+
+// defaults for the fields the caller left 0 or whose header is older than this library's
+void gsp::gsp_internal_resolve_options(const gsp_ctx_options* in, gsp_ctx_options* out) {
+  gsp_ctx_options d;
+  gsp_default_ctx_options(&d);
+  gsp_ctx_options c;
+  std::memset(&c, 0, sizeof(c));
+  if (in) std::memcpy(&c, in, std::min<size_t>(in->struct_size, sizeof(c)));
+  *out = d;
+  if (c.lanes) out->lanes = std::min<uint32_t>(c.lanes, (uint32_t)gsp_context::kMaxLanes);
+  if (c.pool_paths) out->pool_paths = std::max<uint64_t>(1ull << 16, c.pool_paths);
+  if (c.ring_bytes) out->ring_bytes = std::max<uint64_t>(1ull << 24, c.ring_bytes);
+  if (c.memory_share > 0.0) out->memory_share = std::min(0.9, std::max(0.01, c.memory_share));
+  if (c.primary_memo) out->primary_memo = c.primary_memo == 2 ? 2u : 1u;
+  if (c.finish_paths) out->finish_paths = c.finish_paths;
+  if (c.reinsert_rounds) out->reinsert_rounds = std::min<uint32_t>(c.reinsert_rounds, 65u);
+  if (c.gather_route <= GSP_GATHER_COPY) out->gather_route = c.gather_route;
+}
+
+extern "C" {
+
+int gsp_ctx_create(int device, gsp_context** out) { return gsp_ctx_create_ex(device, nullptr, out); }
+
+int gsp_ctx_create_ex(int device, const gsp_ctx_options* options, gsp_context** out) {
   if (!out) return GSP_ERR_INVALID;
   *out = nullptr;
+  if (options && options->struct_size < 8) {
+    set_create_error("gsp_ctx_options.struct_size is not set");
+    return GSP_ERR_INVALID;
+  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -867,9 +921,11 @@ int gsp_ctx_create(int device, gsp_context** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  c->finish_paths = getenv("GSP_FINISH_PATHS") ? (uint32_t)strtoul(getenv("GSP_FINISH_PATHS"), nullptr, 10) : kFinishPaths;
-  if (const char* pm = getenv("GSP_PRIMARY_MEMO")) c->primary_memo = atoi(pm) != 0;
-  if (const char* nl = getenv("GSP_LANES")) c->num_lanes = (uint32_t)std::min(std::max(atoi(nl), 1), (int)gsp_context::kMaxLanes);
+  gsp_internal_resolve_options(options, &c->opt);
+  c->finish_paths = c->opt.finish_paths == 0xffffffffu ? 0u : c->opt.finish_paths;
+  c->primary_memo = c->opt.primary_memo != 2;
+  c->num_lanes = c->opt.lanes;
+  c->memory_share = c->opt.memory_share;
   for (uint32_t l = 0; l < c->num_lanes && e == hipSuccess; ++l) {
     gsp_context::Lane& L = c->lanes[l];
     L.index = l;
@@ -907,6 +963,122 @@ void gsp_ctx_destroy(gsp_context* ctx) {
   delete ctx;
 }
 
+// ---- scene upload and per-frame edits -----------------------------------------------------------------------------------
+// gsp_upload_scene = validate -> tables (BSDF arrays + lights) -> resident geometry + instance table -> bake + BVH build;
+// gsp_update_tables / gsp_update_instances / gsp_update_camera redo only their own part (PathTracer.cpp:58-93 re-reads all
+// of it every frame; only the BLAS of a mesh is kept there, Renderer.cpp:122-131).
+
+static int check_instances(gsp_context* ctx, const gsp_instance* inst, uint32_t n, const uint32_t* num_bsdfs, uint64_t num_vertices,
+                           uint64_t* total_tris) {
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const gsp_instance& in = inst[i];
+    if (in.vertex_count % 3 != 0 || (uint64_t)in.first_vertex + in.vertex_count > num_vertices) {
+      ctx->err = "instance " + std::to_string(i) + ": vertex range outside the position/normal arrays";
+      return GSP_ERR_SCENE;
+    }
+    const uint32_t type = in.bsdf >> 16, idx = in.bsdf & 0xffffu;
+    if (type >= GSP_BSDF_TYPE_COUNT || idx >= num_bsdfs[type]) {
+      ctx->err = "instance " + std::to_string(i) + ": BSDF handle out of range";
+      return GSP_ERR_SCENE;
+    }
+    total += in.vertex_count / 3;
+  }
+  if (total_tris) *total_tris = total;
+  return GSP_OK;
+}
+
+// has_texture words against `num_textures` entries (0 textures: the words are ignored, as the reference's shaders ignore them)
+static int check_texture_words(gsp_context* ctx, const gsp_scene_desc* sc, uint32_t num_textures) {
+  if (num_textures == 0) return GSP_OK;
+  auto bad = [&](int32_t h) { return h < 0 || (uint32_t)h > num_textures; };
+  bool oob = false;
+  for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_DIFFUSE] && sc->diffuse_bsdfs; ++k) oob |= bad(sc->diffuse_bsdfs[k].has_texture);
+  for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_ROUGH_CONDUCTOR] && sc->rough_conductor_bsdfs; ++k)
+    oob |= bad(sc->rough_conductor_bsdfs[k].has_texture);
+  for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_ROUGH_PLASTIC] && sc->rough_plastic_bsdfs; ++k)
+    oob |= bad(sc->rough_plastic_bsdfs[k].has_texture);
+  if (oob) {
+    ctx->err = "has_texture must be 0 or 1 + the index of an entry of `textures`";
+    return GSP_ERR_SCENE;
+  }
+  return GSP_OK;
+}
+
+// the eight BSDF arrays + the lights of `sc` into the context's table allocation (queued on the context's stream)
+static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
+  const void* src[9] = {sc->diffuse_bsdfs, sc->smooth_dielectric_bsdfs, sc->smooth_conductor_bsdfs, sc->smooth_plastic_bsdfs,
+                        sc->rough_conductor_bsdfs, sc->smooth_floor_bsdfs, sc->rough_floor_bsdfs, sc->rough_plastic_bsdfs, sc->lights};
+  const size_t rec[9] = {sizeof(gsp_diffuse_bsdf), sizeof(gsp_smooth_dielectric_bsdf), sizeof(gsp_smooth_conductor_bsdf),
+                         sizeof(gsp_smooth_plastic_bsdf), sizeof(gsp_rough_conductor_bsdf), sizeof(gsp_smooth_floor_bsdf),
+                         sizeof(gsp_rough_floor_bsdf), sizeof(gsp_rough_plastic_bsdf), sizeof(gsp_triangle_light)};
+  size_t bytes[9], off[9], total = 0;
+  for (int k = 0; k < 9; ++k) {
+    bytes[k] = rec[k] * (k < 8 ? sc->num_bsdfs[k] : sc->num_lights);
+    if (bytes[k] && !src[k]) {
+      ctx->err = "null array with non-zero count";
+      return GSP_ERR_SCENE;
+    }
+    off[k] = total;
+    total += (bytes[k] + 15) & ~(size_t)15;
+  }
+  CTX_TRY(ctx, ctx->tables.ensure(std::max<size_t>(total, 16), &ctx->bytes));
+  for (int k = 0; k < 9; ++k) {
+    ctx->table_off[k] = off[k];
+    if (bytes[k]) CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p + off[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream));
+  }
+  ctx->tables_bytes = total;
+  ctx->num_lights = sc->num_lights;
+  for (int k = 0; k < GSP_BSDF_TYPE_COUNT; ++k) ctx->num_bsdfs[k] = sc->num_bsdfs[k];
+  return GSP_OK;
+}
+
+// instance table (ctx->h_inst) -> device, transformInvT per instance, world-space bake + BVH build from the RESIDENT vertex
+// arrays, per-slot uv gather of a textured scene, traversal spill region
+static int bake_and_build(gsp_context* ctx) {
+  hipStream_t st = ctx->stream;
+  const uint32_t ni = (uint32_t)ctx->h_inst.size();
+  // ---- PathTracer::prepareScene (PathTracer.cpp:58-93): per-instance table ----
+  std::vector<float> inv_t(16ull * ni);
+  std::vector<uint32_t> tri_first(ni + 1ull);
+  uint32_t acc = 0;
+  for (uint32_t i = 0; i < ni; ++i) {
+    const gsp_instance& in = ctx->h_inst[i];
+    float tr[16];
+    transpose4(in.transform, tr);
+    inverse4(tr, &inv_t[16ull * i]);
+    tri_first[i] = acc;
+    acc += in.vertex_count / 3;
+  }
+  tri_first[ni] = acc;
+  CTX_TRY(ctx, ctx->d_inst.upload(ctx->h_inst.data(), ni, st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->d_invt.upload(inv_t.data(), inv_t.size(), st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->d_first.upload(tri_first.data(), tri_first.size(), st, &ctx->bytes));
+  BuildInput bi;
+  bi.instances = ctx->d_inst.p;
+  bi.inv_t = ctx->d_invt.p;
+  bi.tri_first = ctx->d_first.p;
+  bi.num_instances = ni;
+  bi.positions = ctx->d_pos.p;
+  bi.normals = ctx->d_nrm.p;
+  bi.num_tris = (uint32_t)ctx->total_tris;
+  bi.reinsert_rounds = (int)ctx->opt.reinsert_rounds - 1;
+  ctx->bytes -= ctx->bvh.bytes;
+  int rc = build_bvh(st, bi, ctx->bvh, ctx->err);  // (synchronises the stream: inv_t / tri_first may go out of scope)
+  if (rc != GSP_OK) return rc;
+  ctx->bytes += ctx->bvh.bytes;
+  if (ctx->num_textures) {  // the collapse defines the slot order: the per-slot uv follow it
+    CTX_TRY(ctx, ctx->tri_uv.ensure(8ull * (ctx->total_tris + ctx->bvh.first_slot + kWide), &ctx->bytes));
+    if (ctx->total_tris) {
+      hipLaunchKernelGGL(k_gather_uv, dim3((uint32_t)((ctx->total_tris + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (uint32_t)ctx->total_tris,
+                         ctx->bvh.first_slot, ctx->bvh.slot_to_global, ctx->d_first.p, ni, ctx->d_inst.p, ctx->d_uv.p, ctx->tri_uv.p);
+      CTX_TRY(ctx, hipGetLastError());
+    }
+  }
+  CTX_TRY(ctx, hipStreamSynchronize(st));
+  return ctx->ensure_spill();
+}
+
 int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   if (!ctx || !sc) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
@@ -923,21 +1095,14 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
     return GSP_ERR_SCENE;
   }
   uint64_t total_tris = 0;
-  for (uint32_t i = 0; i < sc->num_instances; ++i) {
-    const gsp_instance& in = sc->instances[i];
-    if (in.vertex_count % 3 != 0 || (uint64_t)in.first_vertex + in.vertex_count > sc->num_vertices) {
-      ctx->err = "instance " + std::to_string(i) + ": vertex range outside the position/normal arrays";
-      return GSP_ERR_SCENE;
-    }
-    const uint32_t type = in.bsdf >> 16, idx = in.bsdf & 0xffffu;
-    if (type >= GSP_BSDF_TYPE_COUNT || idx >= sc->num_bsdfs[type]) {
-      ctx->err = "instance " + std::to_string(i) + ": BSDF handle out of range";
-      return GSP_ERR_SCENE;
-    }
-    total_tris += in.vertex_count / 3;
+  {
+    int rc_ = check_instances(ctx, sc->instances, sc->num_instances, sc->num_bsdfs, sc->num_vertices, &total_tris);
+    if (rc_ != GSP_OK) return rc_;
   }
-  if (total_tris >= (1ull << 28) - 16) {
-    ctx->err = "too many triangles (limit 2^28)";
+  // the wide tree of n triangles has fewer than n nodes and the traversal's stack entry holds node indices below kMaxNodes
+  // (pt_trace.h): checked here, before any device work
+  if (total_tris >= (uint64_t)kMaxNodes) {
+    ctx->err = "too many triangles: " + std::to_string(total_tris) + " (limit 2^25 - 1 = 33 554 431)";
     return GSP_ERR_SCENE;
   }
   // dormant-feature extension: textures / environment map
@@ -956,19 +1121,8 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
         return GSP_ERR_SCENE;
       }
     }
-  }
-  if (want_tex) {  // (without a textures array the words are ignored, as the reference's shaders ignore them)
-    auto bad = [&](int32_t h) { return h < 0 || (uint32_t)h > sc->num_textures; };
-    bool oob = false;
-    for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_DIFFUSE] && sc->diffuse_bsdfs; ++k) oob |= bad(sc->diffuse_bsdfs[k].has_texture);
-    for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_ROUGH_CONDUCTOR] && sc->rough_conductor_bsdfs; ++k)
-      oob |= bad(sc->rough_conductor_bsdfs[k].has_texture);
-    for (uint32_t k = 0; k < sc->num_bsdfs[GSP_BSDF_ROUGH_PLASTIC] && sc->rough_plastic_bsdfs; ++k)
-      oob |= bad(sc->rough_plastic_bsdfs[k].has_texture);
-    if (oob) {
-      ctx->err = "has_texture must be 0 or 1 + the index of an entry of `textures`";
-      return GSP_ERR_SCENE;
-    }
+    int rc_ = check_texture_words(ctx, sc, sc->num_textures);
+    if (rc_ != GSP_OK) return rc_;
   }
   if (want_env && (sc->envmap.width == 0 || sc->envmap.height == 0 || sc->envmap.width > (1u << 15) || sc->envmap.height > (1u << 15))) {
     ctx->err = "environment map: size 0 or above 32768";
@@ -976,94 +1130,116 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   }
   auto t0 = std::chrono::steady_clock::now();
   hipStream_t st = ctx->stream;
-  // ---- PathTracer::prepareScene (PathTracer.cpp:58-93): per-instance table ----
-  std::vector<float> inv_t(16ull * sc->num_instances);
-  std::vector<uint32_t> tri_first(sc->num_instances + 1ull);
-  uint32_t acc = 0;
-  for (uint32_t i = 0; i < sc->num_instances; ++i) {
-    const gsp_instance& in = sc->instances[i];
-    float tr[16];
-    transpose4(in.transform, tr);
-    inverse4(tr, &inv_t[16ull * i]);
-    tri_first[i] = acc;
-    acc += in.vertex_count / 3;
-  }
-  tri_first[sc->num_instances] = acc;
   {
-    const void* src[9] = {sc->diffuse_bsdfs, sc->smooth_dielectric_bsdfs, sc->smooth_conductor_bsdfs, sc->smooth_plastic_bsdfs,
-                          sc->rough_conductor_bsdfs, sc->smooth_floor_bsdfs, sc->rough_floor_bsdfs, sc->rough_plastic_bsdfs, sc->lights};
-    const size_t rec[9] = {sizeof(gsp_diffuse_bsdf), sizeof(gsp_smooth_dielectric_bsdf), sizeof(gsp_smooth_conductor_bsdf),
-                           sizeof(gsp_smooth_plastic_bsdf), sizeof(gsp_rough_conductor_bsdf), sizeof(gsp_smooth_floor_bsdf),
-                           sizeof(gsp_rough_floor_bsdf), sizeof(gsp_rough_plastic_bsdf), sizeof(gsp_triangle_light)};
-    size_t bytes[9], total = 0;
-    for (int k = 0; k < 9; ++k) {
-      bytes[k] = rec[k] * (k < 8 ? sc->num_bsdfs[k] : sc->num_lights);
-      if (bytes[k] && !src[k]) {
-        ctx->err = "null array with non-zero count";
-        return GSP_ERR_SCENE;
-      }
-      ctx->table_off[k] = total;
-      total += (bytes[k] + 15) & ~(size_t)15;
-    }
-    ctx->tables_bytes = total;
-    CTX_TRY(ctx, ctx->tables.ensure(std::max<size_t>(total, 16), &ctx->bytes));
-    for (int k = 0; k < 9; ++k)
-      if (bytes[k]) CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p + ctx->table_off[k], src[k], bytes[k], hipMemcpyHostToDevice, st));
+    int rc_ = upload_tables(ctx, sc);
+    if (rc_ != GSP_OK) return rc_;
   }
-  ctx->num_lights = sc->num_lights;
   ctx->camera = sc->camera;
-
-  // ---- geometry staging + device BVH build ----
-  DevBuf<gsp_instance> d_inst;
-  DevBuf<float> d_invt, d_pos, d_nrm;
-  DevBuf<uint32_t> d_first;
-  CTX_TRY(ctx, d_inst.upload(sc->instances, sc->num_instances, st, nullptr));
-  CTX_TRY(ctx, d_invt.upload(inv_t.data(), inv_t.size(), st, nullptr));
-  CTX_TRY(ctx, d_first.upload(tri_first.data(), tri_first.size(), st, nullptr));
-  CTX_TRY(ctx, d_pos.upload(sc->positions, 3ull * sc->num_vertices, st, nullptr));
-  CTX_TRY(ctx, d_nrm.upload(sc->normals, 3ull * sc->num_vertices, st, nullptr));
-  BuildInput bi;
-  bi.instances = d_inst.p;
-  bi.inv_t = d_invt.p;
-  bi.tri_first = d_first.p;
-  bi.num_instances = sc->num_instances;
-  bi.positions = d_pos.p;
-  bi.normals = d_nrm.p;
-  bi.num_tris = (uint32_t)total_tris;
-  ctx->bytes -= ctx->bvh.bytes;
-  int rc = build_bvh(st, bi, ctx->bvh, ctx->err);
-  if (rc != GSP_OK) return rc;
-  ctx->bytes += ctx->bvh.bytes;
-  // ---- dormant-feature extension: per-slot uv, texel arrays, environment map ----
+  // ---- resident geometry (the "BLAS inputs": object-space vertices; Mesh.cpp:7-51) ----
+  CTX_TRY(ctx, ctx->d_pos.upload(sc->positions, 3ull * sc->num_vertices, st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->d_nrm.upload(sc->normals, 3ull * sc->num_vertices, st, &ctx->bytes));
+  ctx->num_vertices = sc->num_vertices;
+  ctx->total_tris = total_tris;
+  ctx->h_inst.assign(sc->instances, sc->instances + sc->num_instances);
+  // ---- dormant-feature extension: texel arrays, uv, environment map ----
   ctx->textured = want_tex || want_env;
   ctx->num_textures = want_tex ? sc->num_textures : 0;
   ctx->env_width = want_env ? sc->envmap.width : 0;
   ctx->env_height = want_env ? sc->envmap.height : 0;
-  DevBuf<float> d_uv;
   if (want_tex) {
     float decode[256];
     for (int b = 0; b < 256; ++b) decode[b] = sc->texel_decode ? sc->texel_decode[b] : (float)b / 255.0f;
     CTX_TRY(ctx, ctx->texel_decode.upload(decode, 256, st, &ctx->bytes));
     CTX_TRY(ctx, ctx->textures.upload(sc->textures, sc->num_textures, st, &ctx->bytes));
     CTX_TRY(ctx, ctx->texels.upload(sc->texels, sc->num_texels, st, &ctx->bytes));
-    CTX_TRY(ctx, ctx->tri_uv.ensure(8ull * (total_tris + ctx->bvh.first_slot + 1), &ctx->bytes));
-    if (total_tris) {
-      CTX_TRY(ctx, d_uv.upload(sc->uvs, 2ull * sc->num_vertices, st, nullptr));
-      hipLaunchKernelGGL(k_gather_uv, dim3((uint32_t)((total_tris + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (uint32_t)total_tris,
-                         ctx->bvh.first_slot, ctx->bvh.slot_to_global, d_first.p, sc->num_instances, d_inst.p, d_uv.p, ctx->tri_uv.p);
-      CTX_TRY(ctx, hipGetLastError());
-    }
+    CTX_TRY(ctx, ctx->d_uv.upload(sc->uvs, 2ull * sc->num_vertices, st, &ctx->bytes));
     CTX_TRY(ctx, hipStreamSynchronize(st));  // `decode` is a stack array
   }
   if (want_env) {
     CTX_TRY(ctx, ctx->env_texels.upload(sc->envmap.texels, 4ull * sc->envmap.width * sc->envmap.height, st, &ctx->bytes));
     for (int k = 0; k < 16; ++k) ctx->env_to_local[k] = sc->envmap.to_local[k];
   }
-  CTX_TRY(ctx, hipStreamSynchronize(st));
-  ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  rc = ctx->ensure_spill();
+  // ---- bake + device BVH build ----
+  int rc = bake_and_build(ctx);
   if (rc != GSP_OK) return rc;
+  ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->stats.scene_updates = 0;
   ctx->have_scene = true;
+  return GSP_OK;
+}
+
+// common head of the gsp_update_* calls: the samples already queued belong to the scene as it was
+static int begin_update(gsp_context* ctx, const char* what) {
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_scene) {
+    ctx->err = std::string(what) + " needs gsp_upload_scene first";
+    return GSP_ERR_INVALID;
+  }
+  return pipeline_drain(ctx);
+}
+
+int gsp_update_camera(gsp_context* ctx, const gsp_camera* camera) {
+  if (!ctx || !camera) return GSP_ERR_INVALID;
+  int rc = begin_update(ctx, "gsp_update_camera");
+  if (rc != GSP_OK) return rc;
+  if (std::memcmp(&ctx->camera, camera, sizeof(gsp_camera)) == 0) return GSP_OK;
+  ctx->camera = *camera;  // (render_consts reads it at the next gsp_render)
+  for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;  // the memo holds the hits of the OLD camera rays
+  ++ctx->stats.scene_updates;
+  return GSP_OK;
+}
+
+int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32_t num_instances) {
+  if (!ctx || (!instances && num_instances)) return GSP_ERR_INVALID;
+  int rc = begin_update(ctx, "gsp_update_instances");
+  if (rc != GSP_OK) return rc;
+  if (num_instances != ctx->h_inst.size()) {
+    ctx->err = "gsp_update_instances: " + std::to_string(num_instances) + " instances, the uploaded scene has " +
+               std::to_string(ctx->h_inst.size()) + " (a different object list needs gsp_upload_scene)";
+    return GSP_ERR_SCENE;
+  }
+  for (uint32_t i = 0; i < num_instances; ++i)
+    if (instances[i].first_vertex != ctx->h_inst[i].first_vertex || instances[i].vertex_count != ctx->h_inst[i].vertex_count) {
+      ctx->err = "gsp_update_instances: instance " + std::to_string(i) + " names another vertex range than the uploaded one (a different mesh needs gsp_upload_scene)";
+      return GSP_ERR_SCENE;
+    }
+  rc = check_instances(ctx, instances, num_instances, ctx->num_bsdfs, ctx->num_vertices, nullptr);
+  if (rc != GSP_OK) return rc;
+  if (num_instances == 0 || std::memcmp(ctx->h_inst.data(), instances, num_instances * sizeof(gsp_instance)) == 0) return GSP_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  ctx->have_scene = false;  // (a failed rebuild leaves no half-built tree in use)
+  for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
+  ctx->h_inst.assign(instances, instances + num_instances);
+  rc = bake_and_build(ctx);
+  if (rc != GSP_OK) return rc;
+  ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->have_scene = true;
+  ++ctx->stats.scene_updates;
+  return GSP_OK;
+}
+
+int gsp_update_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
+  if (!ctx || !sc) return GSP_ERR_INVALID;
+  int rc = begin_update(ctx, "gsp_update_tables");
+  if (rc != GSP_OK) return rc;
+  if (sc->num_lights && !sc->lights) {
+    ctx->err = "null array with non-zero count";
+    return GSP_ERR_SCENE;
+  }
+  rc = check_instances(ctx, ctx->h_inst.data(), (uint32_t)ctx->h_inst.size(), sc->num_bsdfs, ctx->num_vertices, nullptr);
+  if (rc != GSP_OK) {
+    ctx->err = "gsp_update_tables: the new tables leave a resident " + ctx->err;
+    return rc;
+  }
+  rc = check_texture_words(ctx, sc, ctx->num_textures);
+  if (rc != GSP_OK) return rc;
+  rc = upload_tables(ctx, sc);  // (k_shade stages the tables per launch: nothing else holds a copy)
+  if (rc != GSP_OK) {
+    ctx->have_scene = false;
+    return rc;
+  }
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays are free again
+  ++ctx->stats.scene_updates;
   return GSP_OK;
 }
 
@@ -1148,6 +1324,7 @@ static RenderConsts render_consts(const gsp_context* ctx) {
   rcst.max_depth = rp->max_depth;
   rcst.rr_start_depth = rp->rr_start_depth;
   rcst.clamp = rp->clamp;
+  rcst.nee = rp->nee != 0 ? 1u : 0u;
   // raygen.rgen:22, tan() evaluated once on the host
   rcst.zplane = (std::max((float)ctx->width, (float)ctx->height) / 2.0f) / tanf(ctx->camera.fov / 2.0f);
   for (int i = 0; i < 16; ++i) rcst.cam_to_world[i] = ctx->camera.to_world[i];
@@ -1351,7 +1528,7 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
       ctx->stats.shade_kernel_ms += s_ms;
       CTX_TRY(ctx, hipEventElapsedTime(&ms, ev[2], ev[3]));
       ctx->stats.connect_kernel_ms += ms;
-      if (getenv("GSP_TRACE_BOUNCES"))
+      if (ctx->pipe_params.collect_kernel_times >= 2)  // (test tools: one line per iteration)
         fprintf(stderr, "lane %u iter %3u: n %9llu shadow %9u injected %9llu inflight %2zu | extend %8.3f ms shade %8.3f ms connect %8.3f ms\n",
                 L.index, bounce, (unsigned long long)n_traced, tails[T_SHADOW], (unsigned long long)I.injected, P.inflight.size(), e_ms, s_ms, ms);
     }
@@ -1468,7 +1645,8 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   // (paths in flight carry no copy of them); otherwise it is drained first.
   if (ctx->pipe_active &&
       (ctx->pipe_params.max_depth != rp->max_depth || ctx->pipe_params.rr_start_depth != rp->rr_start_depth ||
-       ctx->pipe_params.clamp != rp->clamp || ctx->pipe_params.timestamps_in_flight != rp->timestamps_in_flight)) {
+       ctx->pipe_params.clamp != rp->clamp || ctx->pipe_params.timestamps_in_flight != rp->timestamps_in_flight ||
+       (ctx->pipe_params.nee != 0) != (rp->nee != 0))) {
     int rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
   }
@@ -1482,8 +1660,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     // size -- r01 bench scan: 8 M 5.35, 12 M 5.76, 24 M 6.11, 48 M 6.16, 96 M 6.25 Grays/s; r02 (final kernels): 32 M 7.48,
     // 48 M 7.63, 64 M 7.64 (profiles/r02_ab_pool_size.txt); r03 (faster kernels, so the fixed cost per launch weighs more): 32 M 7.84,
     // 48 M 7.98, 64 M 8.09, 96 M 8.24, 128 M 8.21 (profiles/r03_ab_pool_size.txt).  96 M paths: 43 GB of queues (capacity 2 x the target)
-    uint64_t total_target = 96ull << 20;
-    if (const char* e = getenv("GSP_POOL_PATHS")) total_target = std::max<uint64_t>(1ull << 16, strtoull(e, nullptr, 10));
+    const uint64_t total_target = ctx->opt.pool_paths;  // (default 96 Mi)
     for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
       gsp_context::Lane& L = ctx->lanes[l];
       gsp_context::Pipeline& P = L.pipe;
@@ -1499,11 +1676,10 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       // (at most 192 samples per pixel in flight: tiny frames do not allocate gigabytes; a 1/8 tile share of a
       // 1080p frame, 259 k pixels, still fills the whole pool)
       P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 192 * npix), 2 * P.batch_paths);
-      uint64_t ring_bytes = 16ull << 30;
-      if (const char* e = getenv("GSP_RING_BYTES")) ring_bytes = std::max<uint64_t>(1ull << 24, strtoull(e, nullptr, 10));
+      uint64_t ring_bytes = ctx->opt.ring_bytes;  // (default 16 GiB)
       {
         // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline
-        // takes at most 40 % of the memory that is free now (plus what the lane already holds).  224 B of queues per
+        // takes at most gsp_ctx_options.memory_share (default 40 %) of the memory that is free now (plus what the lane already holds).  224 B of queues per
         // path of capacity (2 x 64-B path records, 2 x 16-B hit, 64-B shadow record), capacity = 2 x the pool target.
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -1521,7 +1697,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       // Slots of the sample-result ring: a batch holds its slot until its last path has ended, so with paths of
       // ~3 bounces on average and a tail of 52 the alive share of the batches in flight is only a few percent and
       // the ring must hold ~24 x the pool for the pool to fill (coffee: 4.2 rays per sample).  16 B per entry, most
-      // of it never touched on scenes with long paths; bounded by GSP_RING_BYTES (default 16 GiB of the 288).
+      // of it never touched on scenes with long paths; bounded by gsp_ctx_options.ring_bytes (default 16 GiB of the 288).
       const uint64_t want_slots = 24 * ((P.pool_target + P.batch_paths - 1) / P.batch_paths);
       const uint64_t fit_slots = ring_bytes / ctx->num_lanes / (P.batch_paths * sizeof(q4));
       P.num_slots = (uint32_t)std::min<uint64_t>(kMaxSlots, std::max<uint64_t>(4, std::min(want_slots, fit_slots)));
@@ -1633,9 +1809,6 @@ int gsp::gsp_internal_accum(gsp_context* ctx, void** accum, uint64_t* num_pixels
   if (stream) *stream = ctx->stream;
   return GSP_OK;
 }
-void gsp::gsp_internal_set_memory_share(gsp_context* ctx, double fraction) {
-  if (ctx) ctx->memory_share = std::min(0.4, std::max(0.01, fraction));
-}
 
 extern "C" {
 
@@ -1689,7 +1862,9 @@ int gsp_reset_stats(gsp_context* ctx) {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
+  const uint64_t updates = ctx->stats.scene_updates;  // (counts since the last gsp_upload_scene, not since the last reset)
   ctx->stats = gsp_stats{};
+  ctx->stats.scene_updates = updates;
   if (ctx->dstats.p) {
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
     CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));

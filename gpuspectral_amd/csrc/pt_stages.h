@@ -30,6 +30,7 @@ struct RenderConsts {
   uint32_t width, height;
   uint32_t max_depth, rr_start_depth;
   float clamp;
+  uint32_t nee;        // RenderParams.nee (PathTracer.h:36-41); the shipped shader hard-wires 1 (`#define NEE true`, rchit:656)
   float zplane;        // (max(W,H)/2) / tan(fov/2), raygen.rgen:22 (tan evaluated on the host)
   float cam_origin[3]; // camera.eye = toWorld[3]
   float cam_to_world[16];
@@ -163,8 +164,9 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
 
   const bool transmits = bsdf_transmits(bsdf);
   const float NdotV = dot(N, -rayDir);
-  // :735-736 gate; `lightPdf != 0` (:750) is known before tracing
-  const bool want_shadow = !bs.delta && ((NdotV > 0.0f && dot(N, L) > 0.0f) || transmits) && (lightPdf != 0.0f);
+  // :733-736 gate (`if (NEE)` first); `lightPdf != 0` (:750) is known before tracing
+  const bool nee_on = rc.nee != 0u;
+  const bool want_shadow = nee_on && !bs.delta && ((NdotV > 0.0f && dot(N, L) > 0.0f) || transmits) && (lightPdf != 0.0f);
   f3 nee = splat(0.0f);
   if (want_shadow) {
     const float w = power_heuristic(lightPdf, bs.pdf);                    // :751
@@ -175,8 +177,8 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   const uint32_t countEmitted = (in.flags >> 9) & 1u;
   const float lightFlag = NdotV > 0.0f ? 1.0f : 0.0f;                     // :760
   f3 emis = splat(0.0f);
-  if (countEmitted == 0 && wasDelta == 0) emis = emis + ((in.directWeight * emission) * lightFlag) * in.weight;  // :763-765
-  if (countEmitted == 1 || wasDelta == 1) emis = emis + (emission * lightFlag) * in.weight;                      // :766-768
+  if (nee_on && countEmitted == 0 && wasDelta == 0) emis = emis + ((in.directWeight * emission) * lightFlag) * in.weight;  // :763-765
+  if (!nee_on || countEmitted == 1 || wasDelta == 1) emis = emis + (emission * lightFlag) * in.weight;                      // :766-768
 
   bool done = false;
   if (dot(wi, N) <= 0.0f && !transmits) done = true;                      // :770-773

@@ -8,13 +8,14 @@
 // r03: the tree is a wide BVH with CONTIGUOUS CHILDREN traversed in a STATIC per-octant order, so that a node step
 // has no sort network and pushes at most ONE stack entry (the rest of the node's hit children: a "node group"):
 //   * the inner children of a node are consecutive nodes, its leaf children are consecutive triangle slots (one
-//     triangle per leaf child), so a group of children is {base, which ones, in which order} in 32 bits (4-wide) /
-//     64 bits (8-wide) instead of one pointer per child;
+//     triangle per leaf child), so a group of children is {base, which ones, in which order} in 32 bits instead of one
+//     pointer per child;
 //   * the visiting order of a node's children is fixed at build time for each of the 8 sign octants of the ray
 //     direction (children sorted by the projection of their box centre, in units of the node's extent, on the
 //     octant's diagonal).  Measured on the CPU (scripts/experiments/wide_bvh_probe.cpp, 200 k-triangle interior,
 //     quantised boxes): 10.46 node visits per ray against 10.46 with an exact distance sort per node.
-// GSP_WIDE selects the node width: 4 (default) or 8 (A/B variant).
+// The node width is 4.  (An 8-wide variant after Ylitie, Karras, Laine 2017 was built and measured in r03 -- slower on
+// every scene, LAB_NOTES.md -- and lives on in scripts/experiments/ and in the history, not here.)
 //
 // HBM layout (all records are whole float4s so one lane moves 16 B per load):
 //   4-wide node, "W4T" (64 B):
@@ -32,16 +33,6 @@
 //           inner positions: any-hit rays, for which the order hardly matters (scripts/experiments/
 //           wide_bvh_probe.cpp: 7.64 vs 7.74 node visits) but the latency of a step does, take the hit children in
 //           position order straight from the miss mask instead of through the table.
-//   8-wide node, "W8X" (80 B), after Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs through
-//   compressed wide BVHs" (HPG 2017):
-//                  q0 = {origin.xyz, bits(scale.x[31:16] | scale.y[31:16] >> 16)}     (powers of two: the upper half is all of them)
-//                  q1 = {bits(scale.z[31:16] | imask << 8 | lmask), bits(child_base), bits(tri_base), -}
-//                  q2 = {qlo.x[0..3], qlo.x[4..7], qlo.y[0..3], qlo.y[4..7]}
-//                  q3 = {qlo.z[0..3], qlo.z[4..7], qhi.x[0..3], qhi.x[4..7]}
-//                  q4 = {qhi.y[0..3], qhi.y[4..7], qhi.z[0..3], qhi.z[4..7]}
-//           a child sits in the slot whose octant its centre lies in (greedy assignment on centre . diagonal); a ray
-//           of sign octant `oct` visits the hit slots in increasing slot ^ oct.  imask / lmask: slots holding inner
-//           nodes / triangles; inner child in slot s = node child_base + popcount(imask below s), leaf likewise.
 //   child boxes are quantised outward (floor / ceil, verified against the decode), so they contain the exact
 //   boxes: culling stays conservative and results do not change.
 //   triangle packet (48 B, in the order the collapse emits leaf children):
@@ -52,10 +43,6 @@
 //   the result does not depend on the BVH topology or traversal order.
 #pragma once
 #include "pt_math.h"
-
-#ifndef GSP_WIDE
-#define GSP_WIDE 4
-#endif
 
 namespace gsp {
 
@@ -68,18 +55,24 @@ struct HitRec {
   int32_t slot;  // triangle slot in BVH leaf order; -1 = miss
 };
 
-constexpr int kWide = GSP_WIDE;
-constexpr uint32_t kNodeQuads = kWide == 8 ? 5u : 4u;  // 16-B quads per node
+constexpr int kWide = 4;
+constexpr uint32_t kNodeQuads = 4u;  // 16-B quads per node
 constexpr uint32_t kNodeBytes = 16u * kNodeQuads;
 // The first kTopNodes records of the node array (the tree is emitted level by level: the root and the levels under it)
 // are staged into LDS by every block of k_trace; the node buffer is allocated at least that long.
 #ifndef GSP_TOP_NODES
-#define GSP_TOP_NODES (GSP_WIDE == 8 ? 0 : 64)  // (the 8-wide A/B variant spends its LDS on two-word stack entries)
+#define GSP_TOP_NODES 64
 #endif
 constexpr uint32_t kTopNodes = GSP_TOP_NODES;
 constexpr size_t kNodeAllocMin = (size_t)(kTopNodes > 0 ? kTopNodes : 1) * kNodeBytes;
-// child_base travels through the packed 32-bit stack entries of the 4-wide traversal in 23 bits
-constexpr uint32_t kMaxNodes = kWide == 8 ? (1u << 25) : (1u << 23);
+// A stack entry is (child_base << kGroupBits) | group: the group that is PUSHED has already lost the child being
+// descended into (group_next runs first), so it names at most three children -- a marker bit over 3 x 2 bits for a
+// closest-hit ray, a 4-bit mask for an any-hit ray -- and 7 bits hold it; child_base gets the other 25.  The wide tree of
+// n triangles has fewer than n nodes, so every scene gsp_upload_scene accepts (n < kMaxNodes) fits: no late rejection.
+constexpr uint32_t kGroupBits = 7;
+constexpr uint32_t kGroupMask = (1u << kGroupBits) - 1u;
+constexpr uint32_t kMaxNodes = 1u << (32 - kGroupBits);
+GSP_HD uint32_t pack_group(uint32_t gb, uint32_t gs) { return (gb << kGroupBits) | gs; }
 
 // Watertight ray/triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle
 // Intersection", JCGT 2013), no back-face culling: the ray is sheared so that it
@@ -285,25 +278,8 @@ struct SeqTable4 {
       }
   }
 };
-// 8-wide: FirstTable8[oct][mask] = the slot s of `mask` with the smallest s ^ oct (2 KB); mask 0 -> 0.
-struct FirstTable8 {
-  uint8_t v[8 * 256];
-  constexpr FirstTable8() : v() {
-    for (int o = 0; o < 8; ++o)
-      for (int m = 0; m < 256; ++m) {
-        int best = 0, bk = 8;
-        for (int s = 0; s < 8; ++s)
-          if (((m >> s) & 1) && (s ^ o) < bk) bk = s ^ o, best = s;
-        v[o * 256 + m] = (uint8_t)best;
-      }
-  }
-};
-constexpr uint32_t kStepTableBytes = 2048;  // either table
-#if GSP_WIDE == 8
-constexpr FirstTable8 kStepTable{};
-#else
+constexpr uint32_t kStepTableBytes = 2048;
 constexpr SeqTable4 kStepTable{};
-#endif
 
 // ---- node encoder (device BVH build, pt_bvh.hip; host test harness, tests/emu) --------------------------------------
 struct WideChild {
@@ -384,66 +360,14 @@ GSP_HD void encode_node_w4(q4* __restrict__ o, const WideChild* e, int ni, int n
   o[3] = make_q4(u2f(order[0]), u2f(order[1]), scale[1], scale[2]);
 }
 
-// 8-wide node: children in any order; kind[k] != 0: inner.  Returns through slot_of[k] the slot each child was given
-// (the caller numbers the inner / leaf children in SLOT order: rank = popcount of the mask below the slot).
-GSP_HD void assign_slots_w8(const WideChild* e, int cnt, int* slot_of) {
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int k = 0; k < cnt; ++k) {
-    lo[0] = fmin_(lo[0], e[k].lo.x); lo[1] = fmin_(lo[1], e[k].lo.y); lo[2] = fmin_(lo[2], e[k].lo.z);
-    hi[0] = fmax_(hi[0], e[k].hi.x); hi[1] = fmax_(hi[1], e[k].hi.y); hi[2] = fmax_(hi[2], e[k].hi.z);
-  }
-  const float c0[3] = {lo[0] + hi[0], lo[1] + hi[1], lo[2] + hi[2]};  // 2 * centre
-  float cost[8][8];
-  for (int k = 0; k < cnt; ++k) {
-    const float d[3] = {(e[k].lo.x + e[k].hi.x) - c0[0], (e[k].lo.y + e[k].hi.y) - c0[1], (e[k].lo.z + e[k].hi.z) - c0[2]};
-    for (int s = 0; s < 8; ++s) cost[k][s] = ((s & 1 ? d[0] : -d[0]) + (s & 2 ? d[1] : -d[1])) + (s & 4 ? d[2] : -d[2]);
-  }
-  bool cu[8] = {false, false, false, false, false, false, false, false}, su[8] = {false, false, false, false, false, false, false, false};
-  for (int it = 0; it < cnt; ++it) {
-    float best = -3.0e38f;
-    int bk = 0, bs = 0;
-    bool any = false;
-    for (int k = 0; k < cnt; ++k)
-      if (!cu[k])
-        for (int s = 0; s < 8; ++s)
-          if (!su[s] && (!any || cost[k][s] > best)) best = cost[k][s], bk = k, bs = s, any = true;
-    cu[bk] = su[bs] = true;
-    slot_of[bk] = bs;
-  }
-}
-// e[s] = the child in slot s (s in 0..7) for the slots set in imask | lmask
-GSP_HD void encode_node_w8(q4* __restrict__ o, const WideChild* e, uint32_t imask, uint32_t lmask, uint32_t child_base, uint32_t tri_base) {
-  WideChild packed[8];
-  int where[8], cnt = 0;
-  for (int s = 0; s < 8; ++s)
-    if (((imask | lmask) >> s) & 1u) packed[cnt] = e[s], where[cnt++] = s;
-  float lo[3], scale[3];
-  uint8_t qp[6][8], q[6][8];
-  quantise_children(packed, cnt, lo, scale, qp);
-  for (int p = 0; p < 6; ++p)
-    for (int s = 0; s < 8; ++s) q[p][s] = p < 3 ? 255 : 0;
-  for (int k = 0; k < cnt; ++k)
-    for (int p = 0; p < 6; ++p) q[p][where[k]] = qp[p][k];
-  const uint32_t sx = f2u(scale[0]), sy = f2u(scale[1]), sz = f2u(scale[2]);  // powers of two: mantissa 0
-  o[0] = make_q4(lo[0], lo[1], lo[2], u2f((sx & 0xffff0000u) | (sy >> 16)));
-  o[1] = make_q4(u2f((sz & 0xffff0000u) | (imask << 8) | lmask), u2f(child_base), u2f(tri_base), 0.0f);
-  o[2] = make_q4(u2f(pack4(q[0])), u2f(pack4(q[0] + 4)), u2f(pack4(q[1])), u2f(pack4(q[1] + 4)));
-  o[3] = make_q4(u2f(pack4(q[2])), u2f(pack4(q[2] + 4)), u2f(pack4(q[3])), u2f(pack4(q[3] + 4)));
-  o[4] = make_q4(u2f(pack4(q[4])), u2f(pack4(q[4] + 4)), u2f(pack4(q[5])), u2f(pack4(q[5] + 4)));
-}
-
 // ---- the node step ------------------------------------------------------------------------------------------------
 // Per-ray constants of the step.
 struct RayBox {
   f3 o, inv;               // origin, 1 / direction
   f3 invc;                 // inv clamped to +-2^64 (box tests only; the triangle test uses the exact ray)
   bool negx, negy, negz;   // sign of 1/d per axis: which plane of a slab is the near one
-#if GSP_WIDE == 8
-  uint32_t octrow;         // 256 * sign octant: row of FirstTable8
-#else
   bool octhi;              // sign octant >= 4: the node's order_hi word
   uint32_t octshift;       // 7 * (octant & 3): position of the octant's order code in that word
-#endif
 };
 GSP_HD RayBox make_raybox(f3 o, f3 d) {
   RayBox r;
@@ -454,12 +378,8 @@ GSP_HD RayBox make_raybox(f3 o, f3 d) {
   r.negz = r.inv.z < 0.0f;
   const float big = 18446744073709551616.0f;  // 2^64
   r.invc = mk3(fmin_(fmax_(r.inv.x, -big), big), fmin_(fmax_(r.inv.y, -big), big), fmin_(fmax_(r.inv.z, -big), big));
-#if GSP_WIDE == 8
-  r.octrow = ((r.negx ? 1u : 0u) | (r.negy ? 2u : 0u) | (r.negz ? 4u : 0u)) * 256u;
-#else
   r.octhi = r.negz;
   r.octshift = (r.negx ? 7u : 0u) + (r.negy ? 14u : 0u);
-#endif
   return r;
 }
 
@@ -503,30 +423,6 @@ GSP_HD uint32_t shift_in_sign(uint32_t m, float x) {
     M = shift_in_sign(M, __builtin_fmaf(hi, 1.000001f, -lo));                                       \
   }
 
-#if GSP_WIDE == 8
-// bit s of the result = the child in slot s is MISSED
-GSP_HD uint32_t node_test(const q4* n, const RayBox& rb, float tmin, float tfar) {
-  const uint32_t w0 = f2u(n[0].w);
-  const float sx = u2f(w0 & 0xffff0000u) * rb.invc.x, sy = u2f(w0 << 16) * rb.invc.y, sz = u2f(f2u(n[1].x) & 0xffff0000u) * rb.invc.z;
-  const float dx = (n[0].x - rb.o.x) * rb.invc.x, dy = (n[0].y - rb.o.y) * rb.invc.y, dz = (n[0].z - rb.o.z) * rb.invc.z;
-  const uint32_t lx0 = f2u(n[2].x), lx1 = f2u(n[2].y), ly0 = f2u(n[2].z), ly1 = f2u(n[2].w);
-  const uint32_t lz0 = f2u(n[3].x), lz1 = f2u(n[3].y), hx0 = f2u(n[3].z), hx1 = f2u(n[3].w);
-  const uint32_t hy0 = f2u(n[4].x), hy1 = f2u(n[4].y), hz0 = f2u(n[4].z), hz1 = f2u(n[4].w);
-  const uint32_t nx0 = rb.negx ? hx0 : lx0, nx1 = rb.negx ? hx1 : lx1, fx0 = rb.negx ? lx0 : hx0, fx1 = rb.negx ? lx1 : hx1;
-  const uint32_t ny0 = rb.negy ? hy0 : ly0, ny1 = rb.negy ? hy1 : ly1, fy0 = rb.negy ? ly0 : hy0, fy1 = rb.negy ? ly1 : hy1;
-  const uint32_t nz0 = rb.negz ? hz0 : lz0, nz1 = rb.negz ? hz1 : lz1, fz0 = rb.negz ? lz0 : hz0, fz1 = rb.negz ? lz1 : hz1;
-  uint32_t m = 0;  // slot 7 first, so that slot s ends at bit s
-  GSP_CHILD(m, GSP_UB3, nx1, fx1, ny1, fy1, nz1, fz1)
-  GSP_CHILD(m, GSP_UB2, nx1, fx1, ny1, fy1, nz1, fz1)
-  GSP_CHILD(m, GSP_UB1, nx1, fx1, ny1, fy1, nz1, fz1)
-  GSP_CHILD(m, GSP_UB0, nx1, fx1, ny1, fy1, nz1, fz1)
-  GSP_CHILD(m, GSP_UB3, nx0, fx0, ny0, fy0, nz0, fz0)
-  GSP_CHILD(m, GSP_UB2, nx0, fx0, ny0, fy0, nz0, fz0)
-  GSP_CHILD(m, GSP_UB1, nx0, fx0, ny0, fy0, nz0, fz0)
-  GSP_CHILD(m, GSP_UB0, nx0, fx0, ny0, fy0, nz0, fz0)
-  return m;
-}
-#else
 // bit k of the result = child k is MISSED
 GSP_HD uint32_t node_test(const q4* n, const RayBox& rb, float tmin, float tfar) {
   // per-node constants of the decode: scale / d and (origin - o) / d per axis (6 multiplies), then ONE fma per plane
@@ -543,7 +439,6 @@ GSP_HD uint32_t node_test(const q4* n, const RayBox& rb, float tmin, float tfar)
   GSP_CHILD(m, GSP_UB0, qnx, qfx, qny, qfy, qnz, qfz)
   return m;
 }
-#endif
 #undef GSP_CHILD
 #undef GSP_UB0
 #undef GSP_UB1
@@ -551,50 +446,12 @@ GSP_HD uint32_t node_test(const q4* n, const RayBox& rb, float tmin, float tfar)
 #undef GSP_UB3
 
 // A node group = the children of ONE node that a ray still has to visit: {gb, gs}.
-//   4-wide, closest hit: gb = child_base, gs = their positions in visiting order (2 bits each under a marker bit;
-//                        kSeqEmpty: none)
-//   4-wide, any hit:     gb = child_base, gs = mask of their positions (taken in position order)
-//   8-wide:              gb = child_base, gs = hit inner slots | imask << 8
-// A triangle group = the hit leaf children of one node: {tb, tm}.
-//   4-wide: tb = tri_base - ni, tm = hit leaf positions (bit p = slot tb + p)
-//   8-wide: tb = tri_base, tm = hit leaf slots | lmask << 8
+//   closest hit: gb = child_base, gs = their positions in visiting order (2 bits each under a marker bit;
+//                kSeqEmpty: none)
+//   any hit:     gb = child_base, gs = mask of their positions (taken in position order)
+// A triangle group = the hit leaf children of one node: {tb, tm}: tb = tri_base - ni, tm = hit leaf positions
+// (bit p = slot tb + p).
 // `TAB(byte offset)` reads the step table (LDS copy on the device, kStepTable on the host).
-#if GSP_WIDE == 8
-template <bool ANY>
-GSP_HD bool group_empty(uint32_t gs) { return (gs & 0xffu) == 0u; }
-GSP_HD bool tris_empty(uint32_t tm) { return (tm & 0xffu) == 0u; }
-template <bool ANY>
-constexpr uint32_t root_group() { return 0x101u; }  // node 0 as "slot 0 of a node whose only inner slot is 0"
-template <bool ANY>
-constexpr uint32_t no_group() { return 0u; }
-template <bool ANY, class TAB>
-GSP_HD void node_step(const q4* n, const RayBox& rb, float tmin, float tfar, const TAB& tab, uint32_t& gb, uint32_t& gs, uint32_t& tb,
-                      uint32_t& tm) {
-  const uint32_t miss = node_test(n, rb, tmin, tfar);
-  const uint32_t w = f2u(n[1].x);
-  const uint32_t imask = (w >> 8) & 0xffu, lmask = w & 0xffu;
-  gs = (imask & ~miss) | (imask << 8);
-  tm = (lmask & ~miss) | (lmask << 8);
-  gb = f2u(n[1].y);
-  tb = f2u(n[1].z);
-}
-// takes the nearest child out of a non-empty group; returns the BYTE offset of its node
-template <bool ANY, class TAB>
-GSP_HD uint32_t group_next(uint32_t gb, uint32_t& gs, const RayBox& rb, const TAB& tab) {
-  const uint32_t slot = tab(rb.octrow + (gs & 0xffu));
-  const uint32_t bit = 1u << slot;
-  gs ^= bit;
-  const uint32_t rank = (uint32_t)__builtin_popcount((gs >> 8) & (bit - 1u));
-  return (gb + rank) * kNodeBytes;
-}
-// takes one triangle out of a non-empty triangle group; returns its slot
-GSP_HD uint32_t tris_next(uint32_t tb, uint32_t& tm) {
-  const uint32_t slot = (uint32_t)__builtin_ctz(tm);
-  const uint32_t bit = 1u << slot;
-  tm ^= bit;
-  return tb + (uint32_t)__builtin_popcount((tm >> 8) & (bit - 1u));
-}
-#else
 template <bool ANY>
 GSP_HD bool group_empty(uint32_t gs) { return ANY ? gs == 0u : gs <= kSeqEmpty; }
 GSP_HD bool tris_empty(uint32_t tm) { return tm == 0u; }
@@ -637,18 +494,11 @@ GSP_HD uint32_t tris_next(uint32_t tb, uint32_t& tm) {
   tm &= tm - 1u;
   return tb + p;
 }
-#endif
 
 // host / k_finish view of the step table
 struct StepTableRef {
   const void* base;
-  GSP_HD uint32_t operator()(uint32_t byte_off) const {
-#if GSP_WIDE == 8
-    return ((const uint8_t*)base)[byte_off];
-#else
-    return ((const uint16_t*)base)[byte_off >> 1];
-#endif
-  }
+  GSP_HD uint32_t operator()(uint32_t byte_off) const { return ((const uint16_t*)base)[byte_off >> 1]; }
 };
 
 // One ray against the wide BVH on one thread, start to finish: the traversal of k_finish (which runs the last few
@@ -656,7 +506,7 @@ struct StepTableRef {
 // step, same triangle test and the same min-t / min-id rule as the wave kernel (pt_wavetrace.h), so the hit is the
 // same; the visiting order is not (and need not be).  ANY = true: return at the first accepted triangle
 // (TerminateOnFirstHit | SkipClosestHitShader).  aux = BSDF type of the accepted triangle (low 3 bits of p0.w).
-// STACK: push(uint32_t) / pop() of 32-bit words; at most one group (1 word 4-wide, 2 words 8-wide) per tree level.
+// STACK: push(uint32_t) / pop() of 32-bit words; at most one group (one word) per tree level.
 template <bool ANY, class STACK, class TAB>
 GSP_HD bool trace_ray(const q4* __restrict__ nodes, const q4* __restrict__ tris, f3 o, f3 d, float tmin, float tmax, HitRec& h,
                       uint32_t& aux, STACK& stk, const TAB& tab) {
@@ -674,14 +524,9 @@ GSP_HD bool trace_ray(const q4* __restrict__ nodes, const q4* __restrict__ tris,
     if (group_empty<ANY>(gs)) {
       if (depth == 0) break;
       --depth;
-#if GSP_WIDE == 8
-      gs = stk.pop();
-      gb = stk.pop();
-#else
       const uint32_t e = stk.pop();
-      gb = e >> 9;
-      gs = e & 511u;
-#endif
+      gb = e >> kGroupBits;
+      gs = e & kGroupMask;
       continue;
     }
     const q4* nd = (const q4*)((const char*)nodes + group_next<ANY>(gb, gs, rb, tab));
@@ -713,12 +558,7 @@ GSP_HD bool trace_ray(const q4* __restrict__ nodes, const q4* __restrict__ tris,
     }
     if (!group_empty<ANY>(ngs)) {
       if (!group_empty<ANY>(gs)) {
-#if GSP_WIDE == 8
-        stk.push(gb);
-        stk.push(gs);
-#else
-        stk.push((gb << 9) | gs);
-#endif
+        stk.push(pack_group(gb, gs));
         ++depth;
       }
       gb = ngb;

@@ -34,7 +34,7 @@ namespace gsp {
 
 constexpr int kTraceBlock = 256;
 #ifndef GSP_LDS_LEVELS
-#define GSP_LDS_LEVELS (GSP_WIDE == 8 ? 10 : (GSP_TOP_NODES > 0 ? 16 : 20))
+#define GSP_LDS_LEVELS 16
 #endif
 #ifndef GSP_TRACE_WAVES
 #define GSP_TRACE_WAVES 7  // waves per SIMD the register allocator must allow (<= 72 VGPRs; 8 would spill)
@@ -42,7 +42,7 @@ constexpr int kTraceBlock = 256;
 #ifndef GSP_TRACE_WAVES_ANY
 #define GSP_TRACE_WAVES_ANY GSP_TRACE_WAVES  // ... of the any-hit instantiations (they keep no u, v, tie-break id)
 #endif
-constexpr int kStackWords = GSP_WIDE == 8 ? 2 : 1;   // 32-bit words per stack entry (one node group)
+constexpr int kStackWords = 1;                       // 32-bit words per stack entry (one node group, pt_trace.h pack_group)
 constexpr int kLdsStackDepth = GSP_LDS_LEVELS;       // LDS levels (entries) per lane
 #ifndef GSP_REFILL_LANES
 #define GSP_REFILL_LANES 16
@@ -89,13 +89,7 @@ typedef __attribute__((address_space(3))) v4f_t lds_v4f;
 // the step table (pt_trace.h) in LDS
 struct LdsStepTable {
   const __attribute__((address_space(3))) char* base;
-  __device__ __forceinline__ uint32_t operator()(uint32_t byte_off) const {
-#if GSP_WIDE == 8
-    return *(const lds_u8*)(base + byte_off);
-#else
-    return *(const lds_u16*)(base + byte_off);
-#endif
-  }
+  __device__ __forceinline__ uint32_t operator()(uint32_t byte_off) const { return *(const lds_u16*)(base + byte_off); }
 };
 __device__ __forceinline__ void stage_step_table(uint32_t* lds_words, uint32_t tid, uint32_t threads) {
   const uint32_t* src = (const uint32_t*)&kStepTable;
@@ -130,40 +124,17 @@ struct WaveStack {
   // Hot path: the LDS-or-spill decision is taken once per wave (a ballot and a scalar branch);
   // almost always every lane is inside the LDS levels and the access is a bare ds_read / ds_write.
   __device__ __forceinline__ void push_group(uint32_t gb, uint32_t gs) {
-    if (__builtin_expect(__ballot(sp + kEntryBytes > kLdsBytes) == 0, 1)) {
-#if GSP_WIDE == 8
-      at(sp)[0] = gb;
-      at(sp)[kTraceBlock] = gs;
-#else
-      at(sp)[0] = (gb << 9) | gs;
-#endif
-    } else {
-#if GSP_WIDE == 8
-      store_at(sp, gb);
-      store_at(sp + kWordBytes, gs);
-#else
-      store_at(sp, (gb << 9) | gs);
-#endif
-    }
+    if (__builtin_expect(__ballot(sp + kEntryBytes > kLdsBytes) == 0, 1)) at(sp)[0] = pack_group(gb, gs);
+    else store_at(sp, pack_group(gb, gs));
     sp += kEntryBytes;
   }
   __device__ __forceinline__ void pop_group(uint32_t& gb, uint32_t& gs) {
     sp -= kEntryBytes;
-#if GSP_WIDE == 8
-    if (__builtin_expect(__ballot(sp + kEntryBytes > kLdsBytes) == 0, 1)) {
-      gb = at(sp)[0];
-      gs = at(sp)[kTraceBlock];
-    } else {
-      gb = load_at(sp);
-      gs = load_at(sp + kWordBytes);
-    }
-#else
     uint32_t e;
     if (__builtin_expect(__ballot(sp >= kLdsBytes) == 0, 1)) e = at(sp)[0];
     else e = load_at(sp);
-    gb = e >> 9;
-    gs = e & 511u;
-#endif
+    gb = e >> kGroupBits;
+    gs = e & kGroupMask;
   }
 };
 

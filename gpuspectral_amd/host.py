@@ -45,6 +45,18 @@ def load():
     L.gsph_scene_warning.argtypes = [vp, u32]
     L.gsph_scene_num_materials.restype = u32
     L.gsph_scene_num_materials.argtypes = [vp]
+    L.gsph_scene_num_objects.restype = u32
+    L.gsph_scene_num_objects.argtypes = [vp]
+    L.gsph_scene_set_camera.argtypes = [vp, vp, C.c_float]
+    L.gsph_scene_set_transform.argtypes = [vp, u32, vp]
+    L.gsph_scene_set_object_material.argtypes = [vp, u32, vp, C.c_int]
+    L.gsph_scene_set_diffuse_reflectance.argtypes = [vp, u32, vp]
+    L.gsph_scene_make_object_rough_conductor.argtypes = [vp, u32, vp, vp, C.c_float]
+    L.gsph_scene_reflatten.argtypes = [vp]
+    L.gsph_pathtracer_render_files_same_slot.argtypes = [vp, C.POINTER(C.c_char_p), C.c_char_p, u32, u32, vp, vp]
+    L.gsph_tracker_remember.argtypes = [vp]
+    L.gsph_tracker_diff.argtypes = [vp]
+    L.gsph_tracker_probe.argtypes = [vp, vp]
     L.gsph_pathtracer_create.restype = vp
     L.gsph_pathtracer_create.argtypes = [u32, u32, C.c_int, vp, u64]
     L.gsph_pathtracer_free.argtypes = [vp]
@@ -108,8 +120,40 @@ class Scene:
     def num_materials(self):
         return self._L.gsph_scene_num_materials(self._h)
 
+    # ---- edits between frames (a host application mutates its Scene; PathTracer::prepareScene compares by value) ----
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise GspError("%s: %s" % (what, _err(self._L)))
+
+    @property
+    def num_objects(self):
+        return self._L.gsph_scene_num_objects(self._h)
+
+    def set_camera(self, to_world, fov):
+        m = np.ascontiguousarray(to_world, np.float32).reshape(16)
+        self._ok(self._L.gsph_scene_set_camera(self._h, m.ctypes.data, float(fov)), "set_camera")
+
+    def set_transform(self, obj, matrix16):
+        m = np.ascontiguousarray(matrix16, np.float32).reshape(16)
+        self._ok(self._L.gsph_scene_set_transform(self._h, obj, m.ctypes.data), "set_transform")
+
+    def set_object_material(self, obj, emission=None, twofaced=None):
+        e = np.ascontiguousarray(emission, np.float32).reshape(3) if emission is not None else None
+        self._ok(self._L.gsph_scene_set_object_material(self._h, obj, e.ctypes.data if e is not None else None,
+                                                        -1 if twofaced is None else int(bool(twofaced))), "set_object_material")
+
+    def set_diffuse_reflectance(self, index, rgb):
+        c = np.ascontiguousarray(rgb, np.float32).reshape(3)
+        self._ok(self._L.gsph_scene_set_diffuse_reflectance(self._h, index, c.ctypes.data), "set_diffuse_reflectance")
+
+    def make_object_rough_conductor(self, obj, eta, k, alpha):
+        e, kk = np.ascontiguousarray(eta, np.float32).reshape(3), np.ascontiguousarray(k, np.float32).reshape(3)
+        self._ok(self._L.gsph_scene_make_object_rough_conductor(self._h, obj, e.ctypes.data, kk.ctypes.data, float(alpha)),
+                 "make_object_rough_conductor")
+
     def arrays(self):
-        """Copy of the flattened scene (what crosses the C ABI) as abi.SceneArrays."""
+        """Copy of the flattened scene AS IT IS NOW (what crosses the C ABI) as abi.SceneArrays."""
+        self._ok(self._L.gsph_scene_reflatten(self._h), "flattenScene")
         d = self._L.gsph_scene_desc(self._h).contents
         sc = abi.SceneArrays()
         sc.instances = _view(d.instances, d.num_instances, abi.INSTANCE_DT)
@@ -190,6 +234,17 @@ class PathTracer:
 
     def render(self, scene, spp):
         self._check(self._L.gsph_pathtracer_render(self._h, scene._h, spp), "render")
+
+    def render_files_same_slot(self, paths, spp, asset_dir=None):
+        """Loads each file into a Scene in ONE stack slot (a C++ loop-local), renders `spp` samples from timestamp 0 and
+        downloads: (images [n, H, W, 4], addresses of the n Scene objects)."""
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        out = np.zeros((len(paths), self.height, self.width, 4), np.float32)
+        addr = np.zeros(len(paths), np.uint64)
+        self._check(self._L.gsph_pathtracer_render_files_same_slot(self._h, arr, asset_dir.encode() if asset_dir else None,
+                                                                   len(paths), spp, out.ctypes.data, addr.ctypes.data),
+                    "render_files_same_slot")
+        return out, addr
 
     def set_params(self, params):
         self._check(self._L.gsph_pathtracer_set_params(self._h, C.byref(params)), "set_params")

@@ -704,22 +704,18 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg, const L
   return outScene;
 }
 
-void flattenScene(const Scene& scene, FlatScene& out) {
-  out = FlatScene{};
+void flattenInstances(const Scene& scene, std::vector<gsp_instance>& out) {
+  out.clear();
+  out.reserve(scene.renderObjects.size());
   std::unordered_map<const Mesh*, std::pair<uint32_t, uint32_t>> placed;
+  uint32_t next = 0;
   for (const RenderObject& obj : scene.renderObjects) {
     const Mesh* m = obj.mesh.get();
     auto it = placed.find(m);
     if (it == placed.end()) {
-      const auto& vs = m->getVertices();
-      uint32_t first = (uint32_t)(out.positions.size() / 3);
-      uint32_t count = (uint32_t)(vs.size() / 3 * 3);
-      for (uint32_t i = 0; i < count; ++i) {
-        out.positions.insert(out.positions.end(), {vs[i].pos.x, vs[i].pos.y, vs[i].pos.z});
-        out.normals.insert(out.normals.end(), {vs[i].normal.x, vs[i].normal.y, vs[i].normal.z});
-        if (!scene.textures.empty()) out.uvs.insert(out.uvs.end(), {vs[i].uv.x, vs[i].uv.y});
-      }
-      it = placed.emplace(m, std::make_pair(first, count)).first;
+      const uint32_t count = (uint32_t)(m->getVertices().size() / 3 * 3);
+      it = placed.emplace(m, std::make_pair(next, count)).first;
+      next += count;
     }
     const Material& material = scene.getMaterial(obj.material);
     gsp_instance in{};
@@ -731,14 +727,11 @@ void flattenScene(const Scene& scene, FlatScene& out) {
     in.twofaced = material.twofaced ? 1u : 0u;
     in.first_vertex = it->second.first;
     in.vertex_count = it->second.second;
-    out.instances.push_back(in);
+    out.push_back(in);
   }
-  gsp_scene_desc& d = out.desc;
-  d.instances = out.instances.data();
-  d.num_instances = (uint32_t)out.instances.size();
-  d.positions = out.positions.data();
-  d.normals = out.normals.data();
-  d.num_vertices = out.positions.size() / 3;
+}
+
+void describeTables(const Scene& scene, gsp_scene_desc& d) {
   d.diffuse_bsdfs = scene.diffuseBSDFs.data();
   d.smooth_dielectric_bsdfs = scene.smoothDielectricBSDFs.data();
   d.smooth_conductor_bsdfs = scene.smoothConductorBSDFs.data();
@@ -759,6 +752,30 @@ void flattenScene(const Scene& scene, FlatScene& out) {
   d.num_lights = (uint32_t)scene.triangleLights.size();
   std::memcpy(d.camera.to_world, scene.camera.getToWorld().data(), sizeof(d.camera.to_world));
   d.camera.fov = scene.camera.getFov();
+}
+
+void flattenScene(const Scene& scene, FlatScene& out) {
+  out = FlatScene{};
+  flattenInstances(scene, out.instances);  // (vertex ranges in order of first use, as below)
+  std::unordered_map<const Mesh*, bool> placed;
+  for (const RenderObject& obj : scene.renderObjects) {
+    const Mesh* m = obj.mesh.get();
+    if (!placed.emplace(m, true).second) continue;
+    const auto& vs = m->getVertices();
+    const uint32_t count = (uint32_t)(vs.size() / 3 * 3);
+    for (uint32_t i = 0; i < count; ++i) {
+      out.positions.insert(out.positions.end(), {vs[i].pos.x, vs[i].pos.y, vs[i].pos.z});
+      out.normals.insert(out.normals.end(), {vs[i].normal.x, vs[i].normal.y, vs[i].normal.z});
+      if (!scene.textures.empty()) out.uvs.insert(out.uvs.end(), {vs[i].uv.x, vs[i].uv.y});
+    }
+  }
+  gsp_scene_desc& d = out.desc;
+  d.instances = out.instances.data();
+  d.num_instances = (uint32_t)out.instances.size();
+  d.positions = out.positions.data();
+  d.normals = out.normals.data();
+  d.num_vertices = out.positions.size() / 3;
+  describeTables(scene, d);
   // ---- dormant features ----
   if (!scene.textures.empty()) {
     for (const Texture& t : scene.textures) {

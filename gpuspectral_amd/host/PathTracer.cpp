@@ -3,13 +3,95 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 
 namespace GPUSpectral {
 
-PathTracer::PathTracer(uint32_t width, uint32_t height, int device, const std::vector<uint32_t>& pixelIds)
+// ---- SceneTracker -----------------------------------------------------------------------------------------------------
+namespace {
+template <class T>
+void appendBytes(std::vector<unsigned char>& out, const std::vector<T>& v) {
+  const uint64_t n = v.size();
+  const unsigned char* c = reinterpret_cast<const unsigned char*>(&n);
+  out.insert(out.end(), c, c + sizeof(n));
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(v.data());
+  out.insert(out.end(), p, p + n * sizeof(T));
+}
+// the bytes PathTracer.cpp:74-87 uploads every frame: BSDF.inc's eight arrays, then the lights
+void tableBytes(const Scene& s, std::vector<unsigned char>& out) {
+  out.clear();
+  appendBytes(out, s.diffuseBSDFs);
+  appendBytes(out, s.smoothDielectricBSDFs);
+  appendBytes(out, s.smoothConductorBSDFs);
+  appendBytes(out, s.smoothPlasticBSDFs);
+  appendBytes(out, s.roughConductorBSDFs);
+  appendBytes(out, s.smoothFloorBSDFs);
+  appendBytes(out, s.roughFloorBSDFs);
+  appendBytes(out, s.roughPlasticBSDFs);
+  appendBytes(out, s.triangleLights);
+}
+void assetKey(const Scene& s, std::vector<uint64_t>& out) {
+  out.clear();
+  out.push_back(s.textures.size());
+  for (const Texture& t : s.textures) out.push_back(((uint64_t)t.width << 32) | t.height), out.push_back(t.texels.size());
+  out.push_back(s.srgbTextures ? 1 : 0);
+  out.push_back(s.hasEnvMap ? 1 : 0);
+  if (s.hasEnvMap) {
+    out.push_back(((uint64_t)s.envMap.width << 32) | s.envMap.height);
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) {
+        uint32_t bits;
+        std::memcpy(&bits, &s.envMap.transform[c][r], 4);
+        out.push_back(bits);
+      }
+  }
+}
+gsp_camera cameraOf(const Scene& s) {
+  gsp_camera c{};
+  std::memcpy(c.to_world, s.camera.getToWorld().data(), sizeof(c.to_world));
+  c.fov = s.camera.getFov();
+  return c;
+}
+}  // namespace
+
+unsigned SceneTracker::diff(const Scene& scene, std::vector<gsp_instance>& inst) const {
+  flattenInstances(scene, inst);
+  if (!valid || scene.renderObjects.size() != meshes.size()) return Everything;
+  for (size_t i = 0; i < meshes.size(); ++i)
+    if (scene.renderObjects[i].mesh != meshes[i]) return Everything;  // another mesh = another BLAS (Renderer.cpp:122-131)
+  std::vector<uint64_t> a;
+  assetKey(scene, a);
+  if (a != assets) return Everything;
+  unsigned change = None;
+  // (same meshes in the same order => same vertex ranges; what may differ is transform / emission / bsdf / twofaced)
+  if (inst.size() != instances.size() ||
+      (!inst.empty() && std::memcmp(inst.data(), instances.data(), inst.size() * sizeof(gsp_instance)) != 0))
+    change |= InstancesChanged;
+  std::vector<unsigned char> t;
+  tableBytes(scene, t);
+  if (t != tables) change |= TablesChanged;
+  const gsp_camera cam = cameraOf(scene);
+  if (std::memcmp(&cam, &camera, sizeof(cam)) != 0) change |= CameraChanged;
+  return change;
+}
+
+void SceneTracker::remember(const Scene& scene, const std::vector<gsp_instance>& inst) {
+  meshes.clear();
+  for (const RenderObject& o : scene.renderObjects) meshes.push_back(o.mesh);
+  instances = inst;
+  tableBytes(scene, tables);
+  assetKey(scene, assets);
+  camera = cameraOf(scene);
+  valid = true;
+}
+
+PathTracer::PathTracer(uint32_t width, uint32_t height, int device, const std::vector<uint32_t>& pixelIds,
+                       const gsp_ctx_options* opt)
     : width(width), height(height), device(device), pixelIds(pixelIds) {
   gsp_default_render_params(&params);
+  gsp_default_ctx_options(&options);
+  if (opt) options = *opt;
   setup();
 }
 
@@ -21,8 +103,8 @@ void PathTracer::check(int rc, const char* what) {
 
 // PathTracer.cpp:5-7
 void PathTracer::setup() {
-  int rc = gsp_ctx_create(device, &ctx);
-  if (rc != GSP_OK) throw std::runtime_error(std::string("gsp_ctx_create: ") + gsp_last_error(nullptr));
+  int rc = gsp_ctx_create_ex(device, &options, &ctx);
+  if (rc != GSP_OK) throw std::runtime_error(std::string("gsp_ctx_create_ex: ") + gsp_last_error(nullptr));
   check(gsp_frame_begin(ctx, width, height, pixelIds.empty() ? nullptr : pixelIds.data(), pixelIds.size()),
         "gsp_frame_begin");
 }
@@ -33,16 +115,43 @@ void PathTracer::reset() {
         "gsp_frame_begin");
 }
 
-// PathTracer.cpp:58-93.  The reference rebuilds the TLAS and re-uploads every table each
-// frame; the scene is immutable between frames in every caller, so this uploads once per
-// Scene object (identity + object count) and keeps the BVH resident.
+// PathTracer.cpp:10-19,58-93.  The reference rebuilds the TLAS and re-uploads every table, the instance records and the
+// camera each frame; here the scene is compared BY VALUE with what the device holds (SceneTracker) and only what changed
+// is sent: nothing in the common case, the camera alone for a moved camera, the tables for an edited BSDF or light, a
+// re-bake + BVH rebuild from the resident meshes for an edited transform or material, everything for another object list.
+// Tables go before instances: an instance may name a BSDF the new tables add.
 void PathTracer::prepareScene(const Scene& scene) {
-  if (uploaded == &scene && uploadedObjects == scene.renderObjects.size()) return;
-  FlatScene flat;
-  flattenScene(scene, flat);
-  check(gsp_upload_scene(ctx, &flat.desc), "gsp_upload_scene");
-  uploaded = &scene;
-  uploadedObjects = scene.renderObjects.size();
+  std::vector<gsp_instance> inst;
+  const unsigned change = tracker.diff(scene, inst);
+  if (change == SceneTracker::None) return;
+  tracker.forget();  // (a failed call below leaves nothing remembered: the next pass uploads everything)
+  if (change & SceneTracker::Everything) {
+    FlatScene flat;
+    flattenScene(scene, flat);
+    check(gsp_upload_scene(ctx, &flat.desc), "gsp_upload_scene");
+  } else {
+    gsp_scene_desc d{};
+    describeTables(scene, d);
+    // an instance edit that names a BSDF the OLD tables lack needs the new tables first, and tables that drop a record an
+    // OLD instance names need the new instances first: send the pair in the order that keeps every handle in range, or
+    // (both directions at once) fall back to the full upload
+    const bool both = (change & SceneTracker::TablesChanged) && (change & SceneTracker::InstancesChanged);
+    int rcT = GSP_OK;
+    if (change & SceneTracker::TablesChanged) rcT = gsp_update_tables(ctx, &d);
+    if (rcT != GSP_OK && !both) check(rcT, "gsp_update_tables");
+    if (change & SceneTracker::InstancesChanged) {
+      int rcI = gsp_update_instances(ctx, inst.data(), (uint32_t)inst.size());
+      if (rcI != GSP_OK && rcT == GSP_OK) check(rcI, "gsp_update_instances");
+      if (rcI == GSP_OK && rcT != GSP_OK) check(gsp_update_tables(ctx, &d), "gsp_update_tables");
+      if (rcI != GSP_OK && rcT != GSP_OK) {
+        FlatScene flat;
+        flattenScene(scene, flat);
+        check(gsp_upload_scene(ctx, &flat.desc), "gsp_upload_scene");
+      }
+    }
+    if (change & SceneTracker::CameraChanged) check(gsp_update_camera(ctx, &d.camera), "gsp_update_camera");
+  }
+  tracker.remember(scene, inst);
 }
 
 void PathTracer::render(const Scene& scene, uint32_t spp) {
@@ -76,11 +185,11 @@ gsp_stats PathTracer::stats() {
 }
 
 // ---- several GPUs ---------------------------------------------------------------------------------------------
-MultiGpuPathTracer::MultiGpuPathTracer(uint32_t width, uint32_t height, const std::vector<int>& devices)
+MultiGpuPathTracer::MultiGpuPathTracer(uint32_t width, uint32_t height, const std::vector<int>& devices, const gsp_ctx_options* opt)
     : width(width), height(height), devices(devices) {
   gsp_default_render_params(&params);
-  int rc = gsp_multi_create(devices.data(), (int)devices.size(), &multi);
-  if (rc != GSP_OK) throw std::runtime_error(std::string("gsp_multi_create: ") + gsp_multi_last_error(nullptr));
+  int rc = gsp_multi_create_ex(devices.data(), (int)devices.size(), opt, &multi);
+  if (rc != GSP_OK) throw std::runtime_error(std::string("gsp_multi_create_ex: ") + gsp_multi_last_error(nullptr));
   check(gsp_multi_frame_begin(multi, width, height), "gsp_multi_frame_begin");
 }
 
@@ -96,12 +205,27 @@ void MultiGpuPathTracer::reset() {
 }
 
 void MultiGpuPathTracer::prepareScene(const Scene& scene) {
-  if (uploaded == &scene && uploadedObjects == scene.renderObjects.size()) return;
-  FlatScene flat;
-  flattenScene(scene, flat);
-  check(gsp_multi_upload_scene(multi, &flat.desc), "gsp_multi_upload_scene");
-  uploaded = &scene;
-  uploadedObjects = scene.renderObjects.size();
+  std::vector<gsp_instance> inst;
+  const unsigned change = tracker.diff(scene, inst);
+  if (change == SceneTracker::None) return;
+  tracker.forget();
+  // (same order as PathTracer::prepareScene; the handle-range corner cases take the full upload here)
+  bool full = (change & SceneTracker::Everything) != 0;
+  if (!full) {
+    gsp_scene_desc d{};
+    describeTables(scene, d);
+    if ((change & SceneTracker::TablesChanged) && gsp_multi_update_tables(multi, &d) != GSP_OK) full = true;
+    if (!full && (change & SceneTracker::InstancesChanged) &&
+        gsp_multi_update_instances(multi, inst.data(), (uint32_t)inst.size()) != GSP_OK)
+      full = true;
+    if (!full && (change & SceneTracker::CameraChanged)) check(gsp_multi_update_camera(multi, &d.camera), "gsp_multi_update_camera");
+  }
+  if (full) {
+    FlatScene flat;
+    flattenScene(scene, flat);
+    check(gsp_multi_upload_scene(multi, &flat.desc), "gsp_multi_upload_scene");
+  }
+  tracker.remember(scene, inst);
 }
 
 void MultiGpuPathTracer::render(const Scene& scene, uint32_t spp) {

@@ -21,6 +21,29 @@
 
 namespace GPUSpectral {
 
+// What a pass last handed to the device, BY VALUE.  The reference's createRenderPass(fg, scene) re-reads the camera, every
+// object's transform and material, the eight BSDF tables and the lights on every call and keeps only the BLAS of a mesh,
+// cached by mesh id (S/renderer/PathTracer.cpp:10-19,58-93; Renderer.cpp:122-131).  Its Scene is a plain struct with
+// public vectors, so no mutator could keep a revision counter honest; the tracker therefore compares VALUES each frame
+// (~100 B per object + the tables: microseconds) and answers with the cheapest C-ABI call that brings the device up to
+// date.  Mesh identity is the MeshPtr itself, HELD here: while the tracker holds it no other Mesh can be constructed at
+// that address, so a different scene built in the same stack slot can never be mistaken for the uploaded one.
+struct SceneTracker {
+  enum Change : unsigned { None = 0, CameraChanged = 1, TablesChanged = 2, InstancesChanged = 4, Everything = 8 };
+  // what differs between `scene` and the snapshot (Everything: other meshes / object list / textures: a full upload)
+  unsigned diff(const Scene& scene, std::vector<gsp_instance>& instances) const;
+  void remember(const Scene& scene, const std::vector<gsp_instance>& instances);
+  void forget() { valid = false; meshes.clear(); }
+
+ private:
+  bool valid = false;
+  std::vector<MeshPtr> meshes;          // per render object
+  std::vector<gsp_instance> instances;  // transform, emission, bsdf, twofaced, vertex range per object
+  std::vector<unsigned char> tables;    // counts + the eight BSDF arrays + the lights, back to back
+  gsp_camera camera{};
+  std::vector<uint64_t> assets;         // dormant features: texture / environment-map sizes, flags, envmap transform
+};
+
 // The plugin interface of the reference (Renderer.h:22-25) without the Vulkan FrameGraph.
 class RenderPassCreator {
  public:
@@ -31,7 +54,9 @@ class RenderPassCreator {
 class PathTracer : public RenderPassCreator {
  public:
   // `pixelIds` optionally restricts this tracer to a subset of the frame (multi-GPU tiles).
-  PathTracer(uint32_t width, uint32_t height, int device = 0, const std::vector<uint32_t>& pixelIds = {});
+  // `options` (optional): per-context resources, gsp_ctx_options of include/gpuspectral_pt.h (path-pool size, memory share, ...)
+  PathTracer(uint32_t width, uint32_t height, int device = 0, const std::vector<uint32_t>& pixelIds = {},
+             const gsp_ctx_options* options = nullptr);
   ~PathTracer() override;
   PathTracer(const PathTracer&) = delete;
   PathTracer& operator=(const PathTracer&) = delete;
@@ -39,7 +64,12 @@ class PathTracer : public RenderPassCreator {
   void setup();
   void createRenderPass(const Scene& scene) override;  // +1 spp
   void render(const Scene& scene, uint32_t spp);       // +spp samples
-  void prepareScene(const Scene& scene);               // flatten + upload + BVH build (cached per Scene object)
+  // Brings the device up to date with `scene` as it is NOW (the reference re-reads it every frame): nothing when nothing
+  // changed, gsp_update_camera / _tables / _instances for edits, a full flatten + upload + BVH build for another object list.
+  void prepareScene(const Scene& scene);
+  // Forget what was uploaded: the next pass uploads everything.  Needed only after texel CONTENTS of a texture or
+  // environment map were rewritten in place (dormant features; sizes and flags are tracked, contents are not).
+  void invalidateScene() { tracker.forget(); }
 
   // RGBA32F, row-major, width*height*4 floats (running mean, alpha 1)
   std::vector<float> download();
@@ -57,8 +87,8 @@ class PathTracer : public RenderPassCreator {
   uint32_t width, height;
   int device;
   std::vector<uint32_t> pixelIds;
-  const Scene* uploaded = nullptr;
-  size_t uploadedObjects = 0;
+  gsp_ctx_options options{};
+  SceneTracker tracker;
   int timestamp{0};
 };
 
@@ -69,14 +99,15 @@ class PathTracer : public RenderPassCreator {
 // PathTracer on one GPU.
 class MultiGpuPathTracer : public RenderPassCreator {
  public:
-  MultiGpuPathTracer(uint32_t width, uint32_t height, const std::vector<int>& devices);
+  MultiGpuPathTracer(uint32_t width, uint32_t height, const std::vector<int>& devices, const gsp_ctx_options* options = nullptr);
   ~MultiGpuPathTracer() override;
   MultiGpuPathTracer(const MultiGpuPathTracer&) = delete;
   MultiGpuPathTracer& operator=(const MultiGpuPathTracer&) = delete;
 
   void createRenderPass(const Scene& scene) override;  // +1 spp on every GPU's share
   void render(const Scene& scene, uint32_t spp);
-  void prepareScene(const Scene& scene);
+  void prepareScene(const Scene& scene);  // as PathTracer::prepareScene, on every share
+  void invalidateScene() { tracker.forget(); }
   std::vector<float> download();  // RGBA32F, row-major, width*height*4 floats
   void reset();
   int getTimestamp() const { return timestamp; }
@@ -89,8 +120,7 @@ class MultiGpuPathTracer : public RenderPassCreator {
   gsp_multi* multi = nullptr;
   uint32_t width, height;
   std::vector<int> devices;
-  const Scene* uploaded = nullptr;
-  size_t uploadedObjects = 0;
+  SceneTracker tracker;
   int timestamp{0};
 };
 

@@ -211,5 +211,10 @@ mat4 inverse(const mat4& m);
 // Host half of PathTracer::prepareScene (S/renderer/PathTracer.cpp:58-93): instance table in
 // renderObjects order, shared meshes stored once.
 void flattenScene(const Scene& scene, FlatScene& out);
+// The instance table alone (no vertex copies): what flattenScene would put in FlatScene::instances.  This is the part of
+// the scene the reference rebuilds on every createRenderPass (PathTracer.cpp:10-19,58-70).
+void flattenInstances(const Scene& scene, std::vector<gsp_instance>& out);
+// The table part of a gsp_scene_desc (eight BSDF arrays + lights, pointing INTO `scene`) and its camera.
+void describeTables(const Scene& scene, gsp_scene_desc& d);
 
 }  // namespace GPUSpectral

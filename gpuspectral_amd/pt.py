@@ -20,8 +20,13 @@ EXPORTS = (
     "gsp_build_info",
     "gsp_device_count",
     "gsp_ctx_create",
+    "gsp_default_ctx_options",
+    "gsp_ctx_create_ex",
     "gsp_ctx_destroy",
     "gsp_upload_scene",
+    "gsp_update_camera",
+    "gsp_update_instances",
+    "gsp_update_tables",
     "gsp_frame_begin",
     "gsp_render",
     "gsp_sync",
@@ -36,9 +41,13 @@ EXPORTS = (
     "gsp_last_error",
     "gsp_tile_partition",
     "gsp_multi_create",
+    "gsp_multi_create_ex",
     "gsp_multi_destroy",
     "gsp_multi_num_shares",
     "gsp_multi_upload_scene",
+    "gsp_multi_update_camera",
+    "gsp_multi_update_instances",
+    "gsp_multi_update_tables",
     "gsp_multi_frame_begin",
     "gsp_multi_render",
     "gsp_multi_sync",
@@ -56,7 +65,7 @@ class GspError(RuntimeError):
 
 
 def lib_path():
-    # GSP_LIB_PATH: developer override used to A/B kernel build variants
+    # GSP_LIB_PATH: developer override used to A/B kernel build variants (same ABI version only)
     return os.environ.get("GSP_LIB_PATH") or os.path.join(_HERE, "lib", "libgpuspectral_pt.so")
 
 
@@ -79,6 +88,12 @@ def load():
     L.gsp_build_info.restype = C.c_char_p
     L.gsp_device_count.restype = C.c_int
     L.gsp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.gsp_default_ctx_options.argtypes = [C.POINTER(abi.CtxOptions)]
+    L.gsp_default_ctx_options.restype = None
+    L.gsp_ctx_create_ex.argtypes = [C.c_int, C.POINTER(abi.CtxOptions), C.POINTER(vp)]
+    L.gsp_update_camera.argtypes = [vp, C.POINTER(abi.Camera)]
+    L.gsp_update_instances.argtypes = [vp, vp, u32]
+    L.gsp_update_tables.argtypes = [vp, C.POINTER(abi.SceneDesc)]
     L.gsp_ctx_destroy.argtypes = [vp]
     L.gsp_ctx_destroy.restype = None
     L.gsp_upload_scene.argtypes = [vp, C.POINTER(abi.SceneDesc)]
@@ -98,6 +113,10 @@ def load():
     L.gsp_tile_partition.argtypes = [u32, u32, u32, u32, u32, vp]
     L.gsp_tile_partition.restype = u64
     L.gsp_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.gsp_multi_create_ex.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(abi.CtxOptions), C.POINTER(vp)]
+    L.gsp_multi_update_camera.argtypes = [vp, C.POINTER(abi.Camera)]
+    L.gsp_multi_update_instances.argtypes = [vp, vp, u32]
+    L.gsp_multi_update_tables.argtypes = [vp, C.POINTER(abi.SceneDesc)]
     L.gsp_multi_destroy.argtypes = [vp]
     L.gsp_multi_destroy.restype = None
     L.gsp_multi_num_shares.argtypes = [vp]
@@ -109,15 +128,13 @@ def load():
     L.gsp_multi_download.argtypes = [vp, vp]
     L.gsp_multi_get_stats.argtypes = [vp, C.POINTER(abi.Stats), C.POINTER(abi.Stats)]
     L.gsp_multi_reset_stats.argtypes = [vp]
-    if hasattr(L, "gsp_multi_gather_route"):  # (absent from an ABI-3 build variant)
-        L.gsp_multi_gather_route.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.gsp_multi_gather_route.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.gsp_multi_last_error.argtypes = [vp]
     L.gsp_multi_last_error.restype = C.c_char_p
     v = L.gsp_abi_version()
-    # (a GSP_LIB_PATH build variant of an earlier round -- the same-box baseline of an A/B -- may be one version behind:
-    # version 4 only appended fields to gsp_stats, which such a library leaves zero in the caller's struct)
-    if v != abi.GSP_ABI_VERSION and not (os.environ.get("GSP_LIB_PATH") and v == abi.GSP_ABI_VERSION - 1):
-        raise GspError("ABI version mismatch between abi.py and %s" % path)
+    # (exact match: an older library fills arrays of gsp_stats at ITS struct size and knows nothing of gsp_render_params.nee)
+    if v != abi.GSP_ABI_VERSION:
+        raise GspError("ABI version mismatch: abi.py is %d, %s is %d" % (abi.GSP_ABI_VERSION, path, v))
     _LIB = L
     return L
 
@@ -154,15 +171,29 @@ def source_digest():
 HIT_DT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<i4")])
 
 
-class Context:
-    """One HIP device + stream + scene + accumulate buffer (gsp_context)."""
+def _options(options, kw):
+    """abi.CtxOptions from an explicit struct, keyword fields, or -- test / A-B tooling only -- the GSP_* environment."""
+    if options is None:
+        options = abi.options_from_env()
+    for k, v in kw.items():
+        setattr(options, k, v)
+    return options
 
-    def __init__(self, device=0):
+
+class Context:
+    """One HIP device + stream + scene + accumulate buffer (gsp_context).
+
+    options: abi.CtxOptions (gsp_ctx_options); keyword arguments set single fields (pool_paths=..., primary_memo=2, ...).
+    Without either, this TEST binding maps the GSP_* variables of the A/B scripts onto the struct (abi.options_from_env);
+    the library itself never reads the environment."""
+
+    def __init__(self, device=0, options=None, **option_fields):
         self._L = load()
         h = C.c_void_p()
-        rc = self._L.gsp_ctx_create(device, C.byref(h))
+        self.options = _options(options, option_fields)
+        rc = self._L.gsp_ctx_create_ex(device, C.byref(self.options), C.byref(h))
         if rc != 0:
-            raise GspError("gsp_ctx_create: %s" % self._L.gsp_last_error(None).decode())
+            raise GspError("gsp_ctx_create_ex: %s" % self._L.gsp_last_error(None).decode())
         self._h = h
         self._scene = None
         self.width = self.height = 0
@@ -194,6 +225,24 @@ class Context:
         d = scene.desc()
         self._scene = scene
         self._check(self._L.gsp_upload_scene(self._h, C.byref(d)), "gsp_upload_scene")
+
+    def update_camera(self, to_world, fov):
+        """gsp_update_camera: to_world = 16 floats in glm memory order, fov in radians."""
+        cam = abi.Camera()
+        for i, v in enumerate(np.asarray(to_world, np.float32).reshape(16)):
+            cam.to_world[i] = float(v)
+        cam.fov = float(fov)
+        self._check(self._L.gsp_update_camera(self._h, C.byref(cam)), "gsp_update_camera")
+
+    def update_instances(self, instances):
+        """gsp_update_instances: abi.INSTANCE_DT records (same count and vertex ranges as the uploaded scene)."""
+        inst = np.ascontiguousarray(instances, abi.INSTANCE_DT)
+        self._check(self._L.gsp_update_instances(self._h, inst.ctypes.data if len(inst) else None, len(inst)), "gsp_update_instances")
+
+    def update_tables(self, scene):
+        """gsp_update_tables: the BSDF arrays and lights of `scene` (abi.SceneArrays) replace the resident ones."""
+        d = scene.desc()
+        self._check(self._L.gsp_update_tables(self._h, C.byref(d)), "gsp_update_tables")
 
     def frame_begin(self, width, height, pixel_ids=None):
         if pixel_ids is not None:
@@ -270,13 +319,14 @@ class MultiContext:
     """One frame over several GPUs of one node in ONE process (gsp_multi): tile partition, one host thread per share,
     device-to-device gather into the first device.  `devices` may repeat an index (several shares on one GPU)."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, options=None, **option_fields):
         self._L = load()
         devs = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
-        rc = self._L.gsp_multi_create(devs, len(devices), C.byref(h))
+        self.options = _options(options, option_fields)
+        rc = self._L.gsp_multi_create_ex(devs, len(devices), C.byref(self.options), C.byref(h))
         if rc != 0:
-            raise GspError("gsp_multi_create: %s" % self._L.gsp_multi_last_error(None).decode())
+            raise GspError("gsp_multi_create_ex: %s" % self._L.gsp_multi_last_error(None).decode())
         self._h = h
         self._scene = None
         self.width = self.height = 0
@@ -307,6 +357,22 @@ class MultiContext:
         d = scene.desc()
         self._scene = scene
         self._check(self._L.gsp_multi_upload_scene(self._h, C.byref(d)), "gsp_multi_upload_scene")
+
+    def update_camera(self, to_world, fov):
+        cam = abi.Camera()
+        for i, v in enumerate(np.asarray(to_world, np.float32).reshape(16)):
+            cam.to_world[i] = float(v)
+        cam.fov = float(fov)
+        self._check(self._L.gsp_multi_update_camera(self._h, C.byref(cam)), "gsp_multi_update_camera")
+
+    def update_instances(self, instances):
+        inst = np.ascontiguousarray(instances, abi.INSTANCE_DT)
+        self._check(self._L.gsp_multi_update_instances(self._h, inst.ctypes.data if len(inst) else None, len(inst)),
+                    "gsp_multi_update_instances")
+
+    def update_tables(self, scene):
+        d = scene.desc()
+        self._check(self._L.gsp_multi_update_tables(self._h, C.byref(d)), "gsp_multi_update_tables")
 
     def frame_begin(self, width, height):
         self._check(self._L.gsp_multi_frame_begin(self._h, width, height), "gsp_multi_frame_begin")

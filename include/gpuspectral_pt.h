@@ -16,6 +16,15 @@
  *        arrays, light array)                                  S/renderer/PathTracer.cpp:58-93
  *        Renderer::getOrCreateBLAS / HwDriver::createTLAS      S/renderer/Renderer.cpp:122-131, PathTracer.cpp:10-19
  *        (vkCmdBuildAccelerationStructuresKHR)                 S/backend/vulkan/VulkanRays.cpp:6-86,91-181
+ *   gsp_update_camera / gsp_update_instances / gsp_update_tables   (ABI 5)
+ *        what the reference re-reads on EVERY createRenderPass while the BLAS of a mesh stays cached by mesh id:
+ *        renderState.camera                                     S/renderer/PathTracer.cpp:88-90
+ *        the TLAS over obj.transform + the per-object Instance
+ *        records (transformInvT, emission, bsdf, twofaced)     S/renderer/PathTracer.cpp:10-19,58-70
+ *        the eight BSDF tables and the triangle lights          S/renderer/PathTracer.cpp:74-87
+ *   gsp_ctx_create_ex / gsp_ctx_options
+ *        the knobs of the device objects PathTracer borrows     S/renderer/Renderer.cpp:19-45 (none are per-pass there;
+ *        here: path-pool size, result ring, memory share, ...)
  *   gsp_frame_begin
  *        accumulateBuffer = createTexture(RGBA32F, W, H)       S/renderer/PathTracer.cpp:5-7
  *   gsp_render
@@ -48,7 +57,9 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 4 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth */
+#define GSP_ABI_VERSION 5 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth;
+                             5: gsp_update_camera / _instances / _tables (+ gsp_multi_*), gsp_ctx_options + gsp_ctx_create_ex /
+                                gsp_multi_create_ex, gsp_render_params.nee, gsp_stats.scene_updates */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -231,7 +242,12 @@ typedef struct gsp_render_params {
   float clamp;
   uint32_t timestamps_in_flight; /* samples traced concurrently; 0 = auto */
   uint32_t collect_traversal_stats; /* 1: count BVH nodes / triangles per ray (slower) */
-  uint32_t collect_kernel_times;    /* 1: HIP-event time every extend/shade/connect launch  */
+  uint32_t collect_kernel_times;    /* 1: HIP-event time every extend/shade/connect launch (2: and print one line per iteration to stderr) */
+  uint32_t nee;             /* (ABI 5) RenderParams.nee (S/renderer/PathTracer.h:36-41), which the shipped shader replaces by
+                               `#define NEE true` (rayhit.rchit:656).  1 (default) = the reference as shipped.  0 = the other side
+                               of its `if (NEE)` branches (rayhit.rchit:733,763-768): no shadow ray, every emitter met counts
+                               with full weight, directWeight stays 1; the light sample is still DRAWN (rayhit.rchit:720 is
+                               outside the branch), so the random streams of the two settings coincide */
 } gsp_render_params;
 
 typedef struct gsp_stats {
@@ -262,12 +278,14 @@ typedef struct gsp_stats {
      camera rays of a frame are traced once (memo_build_rays) and later samples copy the hit.  extension_rays keeps
      counting PATH SEGMENTS (what the reference traces: it equals the oracle's count); memoised_rays of them were
      answered from the memo.  Rays actually traced = extension_rays - memoised_rays + memo_build_rays + shadow_rays.
-     GSP_PRIMARY_MEMO=0 turns the memo off. */
+     gsp_ctx_options.primary_memo = 2 turns the memo off. */
   uint64_t memoised_rays;
   uint64_t memo_build_rays;
   uint64_t bvh_depth;        /* (ABI 4) levels of the wide BVH: a traversal stacks at most one entry per level; beyond the 20
                                 levels a lane keeps in LDS the stack continues in HBM, beyond 34 the tail of a drain is left
                                 to the wavefront kernels */
+  uint64_t scene_updates;    /* (ABI 5) gsp_update_camera / _instances / _tables calls that changed something since the last
+                                gsp_upload_scene (a test hook: which path did the host layer take?) */
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;
@@ -291,9 +309,59 @@ int gsp_device_count(void);
 int gsp_ctx_create(int device, gsp_context** out);
 void gsp_ctx_destroy(gsp_context* ctx);
 
+/*
+ * (ABI 5) Per-context resources and scheduling choices.  None of them changes a result: images, ray counts and sample
+ * order are the same for every setting (the GPU suite runs the non-default ones).  gsp_default_ctx_options fills in the
+ * defaults; a field left 0 also means "default", so a zero-initialised struct with struct_size set is valid.
+ * The library never reads the environment: a host application sets these per context.  (The Python test binding,
+ * gpuspectral_amd/pt.py, maps the GSP_* variables the A/B scripts of earlier rounds used onto this struct.)
+ */
+#define GSP_GATHER_AUTO 0 /* RCCL when the shares sit on distinct devices and the communicator comes up, else copies */
+#define GSP_GATHER_RCCL 1 /* ncclSend / ncclRecv group; creation fails if RCCL cannot be initialised               */
+#define GSP_GATHER_COPY 2 /* hipMemcpyPeerAsync into the gathering device                                         */
+typedef struct gsp_ctx_options {
+  uint32_t struct_size;      /* sizeof(gsp_ctx_options) of the caller's header                                        */
+  uint32_t lanes;            /* independent pipelines per context, 1 (default) or 2                                   */
+  uint64_t pool_paths;       /* paths in flight the pool aims at (default 96 Mi; at most 192 per owned pixel)         */
+  uint64_t ring_bytes;       /* upper bound of the sample-result ring (default 16 GiB)                                */
+  double memory_share;       /* share of the device memory that is FREE when a render starts which path pool + ring
+                                may take, 0.01 .. 0.9 (default 0.4): what to lower when several contexts share a GPU  */
+  uint32_t primary_memo;     /* 0 default (on), 1 on, 2 off: trace the camera ray of a pixel once per frame           */
+  uint32_t finish_paths;     /* k_finish takes over a drain below this many live paths; 0 default (262144),
+                                0xffffffff = never                                                                    */
+  uint32_t reinsert_rounds;  /* BVH build: parallel-reinsertion rounds + 1 (0 default = 6 rounds, 1 = none, ...)      */
+  uint32_t gather_route;     /* gsp_multi_create_ex only: GSP_GATHER_*                                                */
+} gsp_ctx_options;
+void gsp_default_ctx_options(gsp_ctx_options* o);
+int gsp_ctx_create_ex(int device, const gsp_ctx_options* options, gsp_context** out);
+
 /* Copy the scene to the device, bake world-space triangles and build the BVH
- * on the device.  The caller keeps ownership of every array in `scene`. */
+ * on the device.  The caller keeps ownership of every array in `scene`.  Limit: fewer than 2^25 (33.5 M) triangles -- the
+ * traversal's packed stack entry holds node indices below 2^25 and a tree has fewer nodes than triangles -- checked here,
+ * before any device work (GSP_ERR_SCENE). */
 int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
+
+/*
+ * (ABI 5) Per-frame scene edits.  The reference re-reads camera, object transforms, materials, BSDF tables and lights on
+ * every createRenderPass (S/renderer/PathTracer.cpp:10-19,58-93) and only keeps the BLAS of a mesh (Renderer.cpp:122-131);
+ * a host that mirrors it calls these between gsp_render calls instead of uploading the whole scene again.  Each call first
+ * completes the samples already queued (they belong to the old scene), leaves the accumulate buffer and the timestamps
+ * alone -- like the reference, where an edit simply shows up in the next frame's sample; call gsp_frame_begin to restart the
+ * running mean -- and invalidates the primary-hit memo.  All need a prior gsp_upload_scene.
+ *   gsp_update_camera     new camera; no geometry work.
+ *   gsp_update_instances  new transform / emission / bsdf / twofaced per instance.  `num_instances` and every
+ *                         first_vertex / vertex_count must equal the uploaded ones (the meshes stay: they are resident on
+ *                         the device); BSDF handles are checked against the resident tables.  Re-bakes the world-space
+ *                         packets and rebuilds the BVH on the device (26-37 ms for a million triangles), as the reference
+ *                         rebuilds its TLAS.
+ *   gsp_update_tables     the eight BSDF arrays + num_bsdfs and the lights + num_lights of `scene` replace the resident
+ *                         ones (all other fields of `scene` are ignored); every resident instance's handle must stay in
+ *                         range.  No geometry work.  Textured scenes (dormant-feature extension): has_texture values are
+ *                         checked against the resident textures.
+ */
+int gsp_update_camera(gsp_context* ctx, const gsp_camera* camera);
+int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32_t num_instances);
+int gsp_update_tables(gsp_context* ctx, const gsp_scene_desc* scene);
 
 /*
  * Allocate (and zero) the accumulate buffer for a width x height frame.
@@ -365,18 +433,27 @@ typedef struct gsp_multi gsp_multi;
 /* One context per entry of `devices` (HIP device indices; an index may repeat: several shares on one GPU).  The
  * first device gathers.  Same error convention as gsp_ctx_create (gsp_multi_last_error(NULL) after a failure). */
 int gsp_multi_create(const int* devices, int n, gsp_multi** out);
+/* (ABI 5) the same with options: every share's context is created with `options` (memory_share is divided among the shares
+ * of one device), options->gather_route picks the gather (GSP_GATHER_*). */
+int gsp_multi_create_ex(const int* devices, int n, const gsp_ctx_options* options, gsp_multi** out);
 void gsp_multi_destroy(gsp_multi* m);
 int gsp_multi_num_shares(const gsp_multi* m);
 /* gsp_upload_scene / gsp_frame_begin (32x32 tiles) / gsp_render / gsp_sync on every share, one host thread each. */
 int gsp_multi_upload_scene(gsp_multi* m, const gsp_scene_desc* scene);
+/* (ABI 5) gsp_update_camera / _instances / _tables on every share */
+int gsp_multi_update_camera(gsp_multi* m, const gsp_camera* camera);
+int gsp_multi_update_instances(gsp_multi* m, const gsp_instance* instances, uint32_t num_instances);
+int gsp_multi_update_tables(gsp_multi* m, const gsp_scene_desc* scene);
 int gsp_multi_frame_begin(gsp_multi* m, uint32_t width, uint32_t height);
 int gsp_multi_render(gsp_multi* m, const gsp_render_params* params);
 int gsp_multi_sync(gsp_multi* m);
 /* The one exchange of a render: completes the queued samples, brings every share's HDR tiles into devices[0] and
  * assembles the frame there.  With one share per device the gather is ONE RCCL group over xGMI (every share
  * ncclSend()s its tiles, devices[0] ncclRecv()s them); a device list with repeats (several shares on one GPU, for
- * tests) uses peer copies instead -- RCCL wants one rank per device.  GSP_MULTI_GATHER=rccl | copy forces a route
- * (rccl with ONE share performs a self send / recv: the RCCL smoke test of a one-GPU box).
+ * tests) uses peer copies instead -- RCCL wants one rank per device -- and so does a node on which librccl cannot be
+ * loaded or the communicator does not come up (GSP_GATHER_AUTO; the reason is kept in gsp_multi_last_error).
+ * gsp_ctx_options.gather_route forces a route (GSP_GATHER_RCCL with ONE share performs a self send / recv: the RCCL smoke
+ * test of a one-GPU box).
  * *device_frame (optional) = the RGBA32F frame on devices[0] (NULL for a single share without RCCL, whose frame is its
  * context's accumulate buffer). */
 int gsp_multi_gather(gsp_multi* m, void** device_frame);

@@ -418,8 +418,10 @@ static inline bool isvalid(float x) { return !gisnan(x) && !gisinf(x); }
 static inline bool isvalid3(vec3 x) { return isvalid(x.x) && isvalid(x.y) && isvalid(x.z); }
 
 // rayhit.rchit:666-797
+// NEE: RenderParams.nee (PathTracer.h:36-41), which the shipped shader replaces by `#define NEE true` (:656); false = the
+// other side of its `if (NEE)` / `!NEE ||` branches (:733, :763, :766)
 static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit, vec3 rayOrigin, Counters& C,
-                             bool collect) {
+                             bool collect, bool NEE = true) {
   Rng rng{prd.seed};                                                      // :668
   const uint32_t instId = S.accel.tri_instance[hit.prim];
   const gsp_instance& instance = S.sc.instances[instId];                  // :672
@@ -481,6 +483,7 @@ static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit,
 
   bool neeDone = false;
   const uint32_t btype = instance.bsdf >> 16;
+  if (NEE)                                                                 // :733
   if (!bsdfRes.isDelta) {                                                  // :735
     if ((dot(N, -rayDir) > 0.0f && dot(N, L) > 0.0f) || isTransimissionBSDF(btype)) {  // :736
       C.shadow_rays++;
@@ -494,10 +497,10 @@ static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit,
   }
   prd.seed = rng.state;                                                    // :759
   float lightFlag = dot(N, -rayDir) > 0.0f ? 1.0f : 0.0f;                  // :760
-  if (prd.countEmitted == 0 && prd.wasDelta == 0) {                        // :763-765
+  if (NEE && prd.countEmitted == 0 && prd.wasDelta == 0) {                 // :763-765
     prd.emitted = prd.emitted + ((prd.directWeight * emission) * lightFlag) * prd.weight;
   }
-  if (prd.countEmitted == 1 || prd.wasDelta == 1) {                        // :766-768
+  if (!NEE || prd.countEmitted == 1 || prd.wasDelta == 1) {                // :766-768
     prd.emitted = prd.emitted + (emission * lightFlag) * prd.weight;
   }
   if (dot(wi, N) <= 0.0f && !isTransimissionBSDF(btype)) {                 // :770-773
@@ -528,6 +531,7 @@ struct RenderCfg {
   uint32_t width, height;
   uint32_t max_depth, rr_start_depth;
   float clamp;
+  bool nee = true;
 };
 
 // raygen.rgen:20-25 with z hoisted (it does not depend on the pixel)
@@ -571,7 +575,7 @@ static vec3 samplePixel(const SceneCtx& S, const RenderCfg& cfg, uint32_t px, ui
     Hit h = closestHit(S.accel, prd.origin, prd.direction, 0.0f, 1e10f, collect ? &C.trav : nullptr);  // :53-58
     if (h.prim >= 0) {
       C.shaded_vertices++;
-      closestHitShader(S, prd, h, prd.origin, C, collect);
+      closestHitShader(S, prd, h, prd.origin, C, collect, cfg.nee);
     } else {
       prd.done = 1;                                                        // miss.rmiss:15-18
       // dormant-feature extension: the escaping path sees the environment map
@@ -707,7 +711,7 @@ int oracle_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixe
                   const gsp_render_params* rp, float* accum, int threads, int collect_trav, oracle_stats* out) {
   Oracle* o = (Oracle*)h;
   if (!o || !rp || !accum) return 1;
-  RenderCfg cfg{width, height, rp->max_depth, rp->rr_start_depth, rp->clamp};
+  RenderCfg cfg{width, height, rp->max_depth, rp->rr_start_depth, rp->clamp, rp->nee != 0};
   const uint64_t npix = pixel_ids ? num_pixels : (uint64_t)width * height;
   // raygen.rgen:22  z = (max(size.x,size.y)/2) / tan(fov/2); tan() evaluated on the host
   const float zplane = (gmax((float)width, (float)height) / 2.0f) / tanf(o->S.fov / 2.0f);

@@ -6,5 +6,4 @@ sc = scenes.interior(1_000_000)
 with g.Context(0) as ctx:
     ctx.upload_scene(sc); ctx.frame_begin(1920,1080)
     ctx.render(spp=4)
-    os.environ["GSP_TRACE_BOUNCES"]="1"
-    ctx.render(spp=16, first_timestamp=4, collect_kernel_times=1)
+    ctx.render(spp=16, first_timestamp=4, collect_kernel_times=2)  # 2: one line per iteration on stderr

@@ -96,17 +96,17 @@ class Emu:
     """ctypes handle on tests/emu/libpt_emu.so: the product's per-path stage headers compiled
     for the host (a test harness -- see tests/emu/pt_emu.cpp; never a product path)."""
 
-    def __init__(self, wide=4):
+    def __init__(self):
         from gpuspectral_amd import abi
 
         d = os.path.join(ROOT, "tests", "emu")
-        so = os.path.join(d, "libpt_emu.so" if wide == 4 else "libpt_emu_w%d.so" % wide)
+        so = os.path.join(d, "libpt_emu.so")
         src = os.path.join(d, "pt_emu.cpp")
         hdrs = [os.path.join(ROOT, "gpuspectral_amd", "csrc", h) for h in os.listdir(os.path.join(ROOT, "gpuspectral_amd", "csrc")) if h.endswith(".h")]
         newest = max(os.path.getmtime(p) for p in [src] + hdrs)
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
             subprocess.check_call(
-                ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma", "-mavx2", "-DGSP_WIDE=%d" % wide, "-shared", "-o", so, src]
+                ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-mfma", "-mavx2", "-shared", "-o", so, src]
             )
         L = C.CDLL(so)
         L.emu_create.restype = C.c_void_p
@@ -180,10 +180,10 @@ class EmuScene:
             pass
 
 
-@pytest.fixture(scope="session", params=[4, 8], ids=["wide4", "wide8"])
-def emu(request):
-    """The product's stage headers on the host, once per node width the traversal supports (GSP_WIDE)."""
-    return Emu(request.param)
+@pytest.fixture(scope="session")
+def emu():
+    """The product's stage headers on the host."""
+    return Emu()
 
 
 def rmse(a, b):

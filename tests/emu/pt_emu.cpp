@@ -9,7 +9,7 @@
 // or anything shipped: the product renders on the GPU only.
 //
 // The BVH here is a plain median-split wide tree (kWide children per node, contiguous children) written with the
-// product's own node encoder (encode_node_w4 / _w8, pt_trace.h) and walked with the product's own per-ray
+// product's own node encoder (encode_node_w4, pt_trace.h) and walked with the product's own per-ray
 // traversal (trace_ray: the node step node_step + intersect_tri that k_trace and k_finish run, with the product's
 // step table); closest-hit results do not depend on the BVH topology (pt_trace.h).
 #include <algorithm>
@@ -169,24 +169,6 @@ struct Emu {
       nodes.resize(nodes.size() + kNodeQuads);
       q4* out = &nodes[(size_t)kNodeQuads * qi];
       if (n == 0) ch.clear();
-#if GSP_WIDE == 8
-      WideChild wc[8], by_slot[8];
-      int slot_of[8];
-      for (size_t k = 0; k < ch.size(); ++k) range_box(ch[k].first, ch[k].count, wc[k]);
-      assign_slots_w8(wc, (int)ch.size(), slot_of);
-      uint32_t imask = 0, lmask = 0;
-      Range in_slot[8];
-      for (size_t k = 0; k < ch.size(); ++k) {
-        by_slot[slot_of[k]] = wc[k];
-        in_slot[slot_of[k]] = ch[k];
-        (ch[k].count >= 2 ? imask : lmask) |= 1u << slot_of[k];
-      }
-      for (int sl = 0; sl < 8; ++sl) {  // ranks in slot order
-        if ((imask >> sl) & 1u) queue.push_back(in_slot[sl]);
-        else if ((lmask >> sl) & 1u) slots.push_back(order[in_slot[sl].first]);
-      }
-      encode_node_w8(out, by_slot, imask, lmask, child_base, tri_base);
-#else
       WideChild wc[4];
       int ni = 0, nl = 0;
       for (const Range& r : ch)
@@ -200,11 +182,10 @@ struct Emu {
           slots.push_back(order[r.first]);
         }
       encode_node_w4(out, wc, ni, nl, child_base, tri_base);
-#endif
     }
-    isect.assign(3ull * (n + 1), mkq(0, 0, 0, 0));  // slot n: the all-zero triangle (det == 0: never hit)
-    shade.assign(4ull * (n + 1), mkq(0, 0, 0, 0));
-    slot_to_global.assign(n + 1, 0);
+    isect.assign(3ull * (n + kWide), mkq(0, 0, 0, 0));  // slots n..: all-zero triangles (det == 0: never hit), as build_bvh appends
+    shade.assign(4ull * (n + kWide), mkq(0, 0, 0, 0));
+    slot_to_global.assign(n + kWide, 0);
     for (uint32_t s = 0; s < n; ++s) {
       uint32_t gg = slots[s];
       slot_to_global[s] = gg;
@@ -212,7 +193,7 @@ struct Emu {
       for (int k = 0; k < 4; ++k) shade[4ull * s + k] = gs[4ull * gg + k];
     }
     if (!guv.empty()) {
-      tri_uv.assign(8ull * (n + 1), 0.0f);
+      tri_uv.assign(8ull * (n + kWide), 0.0f);
       for (uint32_t s = 0; s < n; ++s)
         for (int k = 0; k < 8; ++k) tri_uv[8ull * s + k] = guv[8ull * slots[s] + k];
     }
@@ -316,6 +297,7 @@ int emu_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixel_i
   rc.max_depth = rp->max_depth;
   rc.rr_start_depth = rp->rr_start_depth;
   rc.clamp = rp->clamp;
+  rc.nee = rp->nee != 0 ? 1u : 0u;
   rc.zplane = (std::max((float)width, (float)height) / 2.0f) / tanf(e->sc.camera.fov / 2.0f);
   for (int i = 0; i < 16; ++i) rc.cam_to_world[i] = e->sc.camera.to_world[i];
   for (int i = 0; i < 3; ++i) rc.cam_origin[i] = e->sc.camera.to_world[12 + i];

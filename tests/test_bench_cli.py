@@ -89,3 +89,31 @@ def test_gpus_defaults_to_world_size(monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     args = b.parse()
     assert args.gpus is None
+
+
+def test_nccl_ranks_beyond_the_visible_gpus_are_refused(monkeypatch, capsys):
+    """`--gpus N` over the nccl backend with fewer than N visible GPUs exits with 2 before torch, a
+    process group or a device context exists (RCCL wants one GPU per rank; a hung init would cost the driver its limit)."""
+    import gpuspectral_amd as g
+
+    b = _load_bench()
+    n = g.device_count() + 2
+    monkeypatch.setenv("WORLD_SIZE", str(n))
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(n)])
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert e.value.code == 2
+    assert "visible GPUs" in capsys.readouterr().err
+
+
+def test_a_failing_rank_exits_with_its_rank_in_the_message():
+    """An exception in a rank is printed with the rank and ends the process with status 1 (os._exit, no re-exec), so the
+    launcher tears the job down instead of leaving the other ranks in a barrier."""
+    code = ("import sys, os; sys.argv = ['bench.py', '--scene', 'interior', '--tris', '-5']; os.environ['RANK'] = '3'; os.environ['WORLD_SIZE'] = '1';"
+            "import importlib.util as u; s = u.spec_from_file_location('b', %r); m = u.module_from_spec(s); s.loader.exec_module(m);"
+            "m.parse = lambda: (_ for _ in ()).throw(RuntimeError('boom')); m.main()" % os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 1
+    assert "rank 3 of 1 failed: RuntimeError: boom" in r.stderr

@@ -20,6 +20,27 @@ def test_emu_render_full_bsdf_set_bit_exact(emu, oracle_mod, materials_scene):
     assert np.isfinite(img).all()
 
 
+def test_emu_nee_off_bit_exact(emu, oracle_mod, materials_scene, cornell):
+    """RenderParams.nee = 0 (PathTracer.h:36-41; the `if (NEE)` / `!NEE ||` branches of rayhit.rchit:733,763-768): the
+    product's shade_vertex against the oracle's closestHitShader, on the CPU.  No shadow ray is traced, every emitter met
+    counts with full weight, and the light sample is still drawn -- so the paths are those of nee = 1 and only the
+    estimator differs: same ray-segment count, no shadow rays, a different (noisier) image of the same scene."""
+    from gpuspectral_amd import abi
+
+    for sc, w, h, spp in ((materials_scene, 48, 48, 6), (cornell, 64, 64, 4)):
+        p = abi.default_render_params()
+        p.nee = 0
+        img = emu.scene(sc).render(w, h, spp=spp, params=p)
+        ref, st = oracle_mod.Oracle(sc).render(w, h, spp=spp, params=p)
+        assert np.array_equal(img, ref)
+        on, st_on = oracle_mod.Oracle(sc).render(w, h, spp=spp)
+        assert st["shadow_rays"] == 0 and st_on["shadow_rays"] > 0
+        assert st["extension_rays"] == st_on["extension_rays"]  # the random streams coincide (rchit:720 is outside the branch)
+        assert not np.array_equal(ref, on)
+        # both estimators are of the same radiance: the frame means agree to Monte-Carlo accuracy
+        assert abs(ref[:, :3].mean() - on[:, :3].mean()) < 0.35 * on[:, :3].mean()
+
+
 @pytest.mark.parametrize("what", ["textures", "envmap", "both-srgb"])
 def test_emu_dormant_features_bit_exact(emu, oracle_mod, what):
     """shade_vertex<true>, sample_texture, sample_envmap, det_atan2f of the product headers against the oracle's

@@ -130,11 +130,24 @@ def test_rccl_gather_route_with_one_device(monkeypatch, materials_scene):
         assert m.gather_route()[0] == "copy"
 
 
-def test_library_links_rccl():
-    """The C++ product itself carries the RCCL gather (ldd shows librccl), not only the torch path of bench.py."""
+def test_rccl_is_resolved_at_run_time_with_a_fallback(materials_scene):
+    """The C++ product carries the RCCL gather without LINKING librccl (a hard -lrccl made a single-GPU dlopen
+    fail where RCCL is absent): `readelf -d` shows no librccl, the forced RCCL route above still works (dlopen found it),
+    GSP_GATHER_RCCL with a repeated device is refused with a message, and GSP_GATHER_AUTO on a repeated device list takes
+    the copy route and says why."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi, pt
+
     lib = os.path.join(ROOT, "gpuspectral_amd", "lib", "libgpuspectral_pt.so")
-    out = subprocess.run(["ldd", lib], capture_output=True, text=True).stdout
-    assert "librccl" in out, out
+    out = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "librccl" not in out, out
+    with pytest.raises(g.GspError, match="one rank per device"):
+        pt.MultiContext([0, 0], options=abi.CtxOptions(gather_route=abi.GATHER_RCCL))
+    with pt.MultiContext([0, 0], options=abi.CtxOptions(gather_route=abi.GATHER_AUTO)) as m:
+        assert m.gather_route()[0] == "copy"
+        assert "repeats" in m._L.gsp_multi_last_error(m._h).decode()
+    with pt.MultiContext([0], options=abi.CtxOptions(gather_route=abi.GATHER_RCCL)) as m:
+        assert m.gather_route()[0] == "rccl" and "RCCL" in m._L.gsp_multi_last_error(m._h).decode()
 
 
 def test_bench_one_rank_through_nccl(tmp_path):
@@ -184,24 +197,28 @@ def test_cpp_host_multi_gpu_tracer_via_cli(tmp_path):
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_bench_two_ranks_on_one_gpu(tmp_path):
-    """bench.py's N > 1 path end to end on hardware: two processes (torch.distributed.run, gloo instead of RCCL because
-    both ranks sit on the one GPU), the real GPU renderer, C++ tile partition, gather, assembly -- against bench.py's
-    own single-rank frame."""
-    env = dict(os.environ)
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_ranks_on_one_gpu(tmp_path, ranks):
+    """bench.py's N > 1 path end to end on hardware: N processes (torch.distributed.run, gloo instead of RCCL because
+    the ranks share the one GPU), the real GPU renderer, C++ tile partition, gather, assembly, the per-rank record --
+    against bench.py's own single-rank frame.  N = 8 is the shape of the driver's scaling run (scripts/ranks8_one_gpu.sh)."""
+    env = dict(os.environ, GSP_POOL_PATHS="2000000")  # (the test binding maps it onto gsp_ctx_options: 8 pools share one GPU)
     common = ["--steps", "1", "--warmup", "1", "--spp-per-step", "4", "--tris", "60000", "--width", "416", "--height", "240",
               "--no-cpu-baseline"]
     f1, f2 = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump", f1] + common, env=env,
                         capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-3000:]
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dump", f2] + common,
-                        env=env, capture_output=True, text=True, timeout=900)
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                         "--master-port", str(29613 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--dump", f2] + common,
+                        env=env, capture_output=True, text=True, timeout=1200)
     assert r2.returncode == 0, r2.stderr[-3000:]
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
-    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == ranks
+    pr = j2["config"]["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(ranks)) and sum(p["pixels"] for p in pr) == 416 * 240
+    assert sum(p["samples"] for p in pr) == j2["config"]["spp_timed"] * 416 * 240 and all(p["elapsed_s"] > 0 and p["device_bytes"] > 0 for p in pr)
     # path segments are a property of the samples; how many of the camera-ray segments were copied from the primary-hit
     # memo instead of traced is not (a rank whose few remaining paths go to k_finish traces them from the camera)
     assert j1["config"]["path_segments"] == j2["config"]["path_segments"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]

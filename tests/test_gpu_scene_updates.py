@@ -1,0 +1,316 @@
+"""Per-frame scene semantics of the drop-in boundary (ABI 5): the reference's createRenderPass re-reads the camera, every
+object's transform and material, the eight BSDF tables and the lights on EVERY call and only keeps the BLAS of a mesh
+(S/renderer/PathTracer.cpp:10-19,58-93; Renderer.cpp:122-131).  The C++ PathTracer compares the scene by value each
+frame (SceneTracker) and sends gsp_update_camera / _tables / _instances; every test compares the GPU frame bit for bit
+with the oracle rendering the scene AS IT IS at that frame."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CORNELL_XML
+
+pytestmark = pytest.mark.gpu
+
+
+def moved(to_world, dx=0.0, dy=0.0, dz=0.0):
+    m = np.array(to_world, np.float32).copy()
+    m[12] += np.float32(dx)
+    m[13] += np.float32(dy)
+    m[14] += np.float32(dz)
+    return m
+
+
+def test_host_pathtracer_follows_a_moving_camera(oracle_mod):
+    """(a) the camera moves between createRenderPass calls.  No reset: like the reference, the running mean simply goes on
+    (timestamps 0-2 through the first camera, 3-5 through the second); the oracle is driven the same way."""
+    from gpuspectral_amd import host
+
+    W = H = 64
+    scene = host.Scene(CORNELL_XML)
+    pt = host.PathTracer(W, H)
+    a0 = scene.arrays()
+    pt.render(scene, 3)
+    ref, _ = oracle_mod.Oracle(a0).render(W, H, spp=3)
+    assert np.array_equal(pt.download().reshape(-1, 4), ref)
+    assert pt.stats()["scene_updates"] == 0
+    build_ms = pt.stats()["bvh_build_ms"]
+    scene.set_camera(moved(a0.to_world, dx=0.35, dy=-0.2), float(a0.fov) * 1.2)
+    a1 = scene.arrays()
+    for _ in range(3):
+        pt.create_render_pass(scene)  # +1 spp each, timestamps 3, 4, 5
+    ref, _ = oracle_mod.Oracle(a1).render(W, H, spp=3, first_timestamp=3, accum=ref)
+    img = pt.download().reshape(-1, 4)
+    assert np.array_equal(img, ref)
+    st = pt.stats()
+    assert st["scene_updates"] == 1 and st["bvh_build_ms"] == build_ms  # the camera path: no rebuild
+    # and from a clean accumulate buffer: the frame IS the new view (a stale primary-hit memo would show the old one)
+    pt.reset()
+    pt.render(scene, 4)
+    ref1, _ = oracle_mod.Oracle(a1).render(W, H, spp=4)
+    ref0, _ = oracle_mod.Oracle(a0).render(W, H, spp=4)
+    img = pt.download().reshape(-1, 4)
+    assert np.array_equal(img, ref1) and not np.array_equal(img, ref0)
+    pt.close()
+
+
+def test_host_pathtracer_follows_transform_and_material_edits(oracle_mod):
+    """(b) an object moves, a BSDF record changes colour, a box becomes a (new) rough conductor, the light dims: each frame
+    equals the oracle on the scene as edited so far."""
+    from gpuspectral_amd import host
+
+    W = H = 72
+    scene = host.Scene(CORNELL_XML)
+    pt = host.PathTracer(W, H)
+
+    def check(expect_updates):
+        pt.reset()
+        pt.render(scene, 3)
+        ref, ost = oracle_mod.Oracle(scene.arrays()).render(W, H, spp=3)
+        img = pt.download().reshape(-1, 4)
+        assert np.array_equal(img, ref)
+        st = pt.stats()
+        assert st["scene_updates"] == expect_updates
+        return img
+
+    base = check(0)
+    a = scene.arrays()
+    # the tall box (object 6) slides and turns: gsp_update_instances (re-bake + BVH rebuild from the resident meshes)
+    m = a.instances["transform"][6].copy()
+    m[12] += 0.3
+    m[14] += 0.2
+    scene.set_transform(6, m)
+    img1 = check(1)
+    assert not np.array_equal(img1, base)
+    # the left wall's BSDF record turns blue: gsp_update_tables only
+    scene.set_diffuse_reflectance(0, [0.05, 0.1, 0.7])
+    img2 = check(2)
+    assert not np.array_equal(img2, img1)
+    # the short box gets a BSDF that did not exist before: tables AND instances
+    scene.make_object_rough_conductor(5, [0.2, 0.92, 1.1], [3.9, 2.45, 2.14], 0.14)
+    img3 = check(4)
+    assert not np.array_equal(img3, img2)
+    # an edit that changes nothing sends nothing
+    scene.set_diffuse_reflectance(0, [0.05, 0.1, 0.7])
+    assert np.array_equal(check(4), img3)
+    pt.close()
+
+
+def test_two_scenes_in_the_same_stack_slot(oracle_mod, tmp_path):
+    """(c) VERDICT r03 weak 6: a loop over scene files with a stack `Scene` puts different scenes of equal object count at
+    the SAME address.  Each frame must be its own scene's."""
+    from gpuspectral_amd import host
+    from oracle import mitsuba_loader as ml
+
+    xml = open(CORNELL_XML).read()
+    other = xml.replace('value="0.63, 0.065, 0.05"', 'value="0.1, 0.2, 0.8"').replace(
+        '<matrix value="-1 0 0 0 0 1 0 1 0 0 -1 6.8 0 0 0 1"/>', '<matrix value="-1 0 0 0.3 0 1 0 1.1 0 0 -1 6.2 0 0 0 1"/>').replace(
+        'value="17, 12, 4"', 'value="6, 9, 14"')
+    assert other != xml
+    p2 = tmp_path / "cornell_variant.xml"
+    p2.write_text(other)
+    W = H = 56
+    pt = host.PathTracer(W, H)
+    paths = [CORNELL_XML, str(p2), CORNELL_XML, str(p2)]
+    imgs, addr = pt.render_files_same_slot(paths, 3)
+    assert len(set(addr.tolist())) == 1, "the test did not reproduce the hazard: the Scene objects did not share a slot"
+    refs = [oracle_mod.Oracle(ml.load_scene(p)).render(W, H, spp=3)[0] for p in paths[:2]]
+    assert not np.array_equal(refs[0], refs[1])
+    for i, img in enumerate(imgs):
+        assert np.array_equal(img.reshape(-1, 4), refs[i % 2]), "frame %d shows another scene" % i
+    pt.close()
+
+
+def test_c_abi_updates_equal_a_fresh_upload(oracle_mod):
+    """gsp_update_camera / _instances / _tables through the C ABI on a scene of tens of thousands of triangles: the frame of
+    an updated context == the frame of a fresh context that uploaded the edited scene == the oracle; and the error
+    contract (another object list, a handle out of range, before any upload)."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import scenes
+
+    W, H, SPP = 96, 54, 3
+    sc = scenes.interior(40_000)
+    with g.Context(0) as ctx:
+        with pytest.raises(g.GspError, match="needs gsp_upload_scene first"):
+            ctx.update_camera(sc.to_world, sc.fov)
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=SPP)
+        before = ctx.download().copy()
+        # edits
+        sc.to_world = moved(sc.to_world, dx=0.4, dz=-0.3)
+        inst = sc.instances.copy()
+        k = int(np.argmax(inst["vertex_count"]))  # move the largest object a little, make another one glow
+        t = inst["transform"][k].copy()
+        t[13] += 0.05
+        inst["transform"][k] = t
+        j = int(np.argmin(inst["vertex_count"]))
+        sc.instances = inst
+        bs = [b.copy() for b in sc.bsdfs]
+        if len(bs[0]):
+            bs[0]["reflectance"][0] = (0.9, 0.1, 0.1)
+        sc.bsdfs = bs
+        lights = sc.lights.copy()
+        lights["radiance"][:, :3] *= np.float32(0.5)
+        sc.lights = lights
+        ctx.update_camera(sc.to_world, sc.fov)
+        ctx.update_instances(sc.instances)
+        ctx.update_tables(sc)
+        assert ctx.stats()["scene_updates"] == 3
+        ctx.frame_begin(W, H)
+        ctx.render(spp=SPP)
+        upd = ctx.download().copy()
+        assert not np.array_equal(upd, before)
+        # pipelined: an update between two gsp_render calls without a sync in between drains the old samples first
+        ctx.frame_begin(W, H)
+        ctx.render(spp=2)
+        ctx.update_camera(moved(sc.to_world, dy=0.1), sc.fov)
+        ctx.render(spp=1, first_timestamp=2)
+        mixed = ctx.download().reshape(-1, 4).copy()
+        # errors leave the scene usable
+        with pytest.raises(g.GspError, match="instances, the uploaded scene has"):
+            ctx.update_instances(sc.instances[:-1])
+        bad = sc.instances.copy()
+        bad["bsdf"][0] = (7 << 16) | 0xFFFF
+        with pytest.raises(g.GspError, match="BSDF handle out of range"):
+            ctx.update_instances(bad)
+        other = sc.instances.copy()
+        other["first_vertex"][j] += 3
+        with pytest.raises(g.GspError, match="another vertex range"):
+            ctx.update_instances(other)
+        ctx.update_camera(sc.to_world, sc.fov)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=SPP)
+        assert np.array_equal(ctx.download(), upd)
+    with g.Context(0) as fresh:
+        fresh.upload_scene(sc)
+        fresh.frame_begin(W, H)
+        fresh.render(spp=SPP)
+        assert np.array_equal(fresh.download(), upd)
+    o = oracle_mod.Oracle(sc)
+    ref, _ = o.render(W, H, spp=SPP)
+    assert np.array_equal(upd.reshape(-1, 4), ref)
+    # the pipelined sequence: 2 samples through the first camera, the third through the moved one
+    acc, _ = o.render(W, H, spp=2)
+    cam2 = moved(sc.to_world, dy=0.1)
+    keep = sc.to_world
+    sc.to_world = cam2
+    acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=2, accum=acc)
+    sc.to_world = keep
+    assert np.array_equal(mixed, acc)
+
+
+def test_multi_updates_reach_every_share(oracle_mod, cornell):
+    """gsp_multi_update_*: three shares on the one GPU, camera + tables + instances edited, frame == oracle."""
+    import copy
+
+    import gpuspectral_amd as g
+
+    W = H = 80
+    sc = copy.deepcopy(cornell)
+    with g.MultiContext([0, 0, 0]) as m:
+        m.upload_scene(sc)
+        m.frame_begin(W, H)
+        m.render(spp=2)
+        first = m.download().copy()
+        sc.to_world = moved(sc.to_world, dx=-0.3)
+        inst = sc.instances.copy()
+        t = inst["transform"][5].copy()
+        t[12] -= 0.2
+        inst["transform"][5] = t
+        sc.instances = inst
+        bs = [b.copy() for b in sc.bsdfs]
+        bs[0]["reflectance"][1] = (0.2, 0.2, 0.9)
+        sc.bsdfs = bs
+        m.update_camera(sc.to_world, sc.fov)
+        m.update_tables(sc)
+        m.update_instances(sc.instances)
+        m.frame_begin(W, H)
+        m.render(spp=2)
+        img = m.download()
+        tot, each = m.stats(per_share=True)
+        assert all(e["scene_updates"] == 3 for e in each)
+    ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=2)
+    assert np.array_equal(img.reshape(-1, 4), ref) and not np.array_equal(img, first)
+
+
+@pytest.mark.parametrize("which", ["materials", "cornell", "interior"])
+def test_nee_off_matches_the_oracle(oracle_mod, cornell, materials_scene, which):
+    """gsp_render_params.nee = 0 (RenderParams.nee, PathTracer.h:36-41; rayhit.rchit:733,763-768) on the GPU, with and
+    without k_finish: bit-equal to the oracle, no shadow ray traced, same path segments as nee = 1."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi, scenes
+
+    sc = {"materials": materials_scene, "cornell": cornell}.get(which) or scenes.interior(20_000)
+    W, H, SPP = 80, 60, 5
+    p = abi.default_render_params()
+    p.nee = 0
+    ref, ost = oracle_mod.Oracle(sc).render(W, H, spp=SPP, params=p)
+    for finish in (0, 0xFFFFFFFF):
+        with g.Context(0, finish_paths=finish) as ctx:
+            ctx.upload_scene(sc)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=SPP, params=p)
+            img = ctx.download().reshape(-1, 4)
+            st = ctx.stats()
+            assert np.array_equal(img, ref)
+            assert st["shadow_rays"] == 0 == ost["shadow_rays"]
+            assert st["extension_rays"] == ost["extension_rays"] and st["shaded_vertices"] == ost["shaded_vertices"]
+            # switching the estimator between two calls drains the pipeline first (paths in flight carry no copy of it)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=2)
+            ctx.render(spp=3, first_timestamp=2, params=p)
+            mix = ctx.download().reshape(-1, 4)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=2)
+        p.spp, p.first_timestamp = 3, 2
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=3, first_timestamp=2, accum=acc, params=p)
+        assert np.array_equal(mix, acc)
+
+
+def test_ctx_options_change_no_result(oracle_mod, materials_scene):
+    """gsp_ctx_options: pool size, ring size, memory share, lanes, primary memo, k_finish threshold,
+    reinsertion rounds are resources and schedules -- every setting renders the same frame and traces the same rays."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi
+
+    W, H, SPP = 128, 96, 6
+    ref, ost = oracle_mod.Oracle(materials_scene).render(W, H, spp=SPP)
+    settings = [dict(), dict(pool_paths=1 << 16), dict(ring_bytes=1 << 24, pool_paths=1 << 18), dict(memory_share=0.02),
+                dict(lanes=2), dict(primary_memo=2), dict(finish_paths=0xFFFFFFFF), dict(finish_paths=1 << 12),
+                dict(reinsert_rounds=1), dict(reinsert_rounds=21), dict(lanes=2, primary_memo=2, pool_paths=1 << 17, finish_paths=0xFFFFFFFF)]
+    for kw in settings:
+        with g.Context(0, options=abi.CtxOptions(**kw)) as ctx:
+            ctx.upload_scene(materials_scene)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=4)
+            ctx.render(spp=SPP - 4, first_timestamp=4)
+            img = ctx.download().reshape(-1, 4)
+            st = ctx.stats()
+        assert np.array_equal(img, ref), kw
+        assert (st["extension_rays"], st["shadow_rays"]) == (ost["extension_rays"], ost["shadow_rays"]), kw
+        assert (st["memoised_rays"] == 0) == (kw.get("primary_memo") == 2), kw
+    bad = abi.CtxOptions()
+    bad.struct_size = 0
+    with pytest.raises(g.GspError, match="struct_size"):
+        g.Context(0, options=bad)
+
+
+def test_random_edits_fuzz(oracle_mod):
+    """tests/tools/fuzz_parity.py check_updates: random scenes edited twice through the update calls (random transforms incl.
+    mirrored ones, swapped material handles, twofaced flips, emission, rescaled tables and lights, moved cameras), and 10
+    seeds with nee = 0: every frame and every ray count equals the oracle's."""
+    import sys
+
+    import gpuspectral_amd as g
+    from conftest import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import fuzz_parity
+
+    with g.Context(0) as ctx:
+        for seed in range(7000, 7016):
+            ok, nbad, tris = fuzz_parity.check_updates(ctx, oracle_mod, seed)
+            assert ok, "seed %d: %d of 3 frames differ (%d triangles)" % (seed, nbad, tris)
+        for seed in range(7100, 7110):
+            ok, ndiff, tris = fuzz_parity.check(ctx, oracle_mod, seed, nee=0)
+            assert ok, "seed %d with nee = 0: %d pixels differ (%d triangles)" % (seed, ndiff, tris)

@@ -1,6 +1,9 @@
 """Randomised GPU-vs-oracle parity: small random scenes with every BSDF type at ordinary and extreme parameters
 (alpha -> 0, ior 1, zero / >1 reflectance, huge k), random transforms (mirrored, sheared scale), several lights,
-random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed] [dormant]
+random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed] [dormant|nee0|updates]
+`nee0`: gsp_render_params.nee = 0 (RenderParams.nee; the other side of rayhit.rchit's `if (NEE)` branches).
+`updates`: scene seed+1 is reached from scene seed's geometry by gsp_update_* calls where the object lists agree (else a
+fresh upload): exercises the per-frame edit path with random transforms / materials / tables / cameras.
 `dormant`: every scene also gets the dormant-feature extension (tests/textured.py: random uv, random textures on the
 texturable records, a random environment map; every third scene with an sRGB table, one wall removed so paths escape)."""
 import os, sys
@@ -47,7 +50,7 @@ def random_scene(seed):
     return b.build()
 
 
-def check(ctx, oracle_mod, seed, W=40, H=28, spp=3, dormant=False):
+def check(ctx, oracle_mod, seed, W=40, H=28, spp=3, dormant=False, nee=1):
     sc = random_scene(seed)
     if dormant:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -60,13 +63,91 @@ def check(ctx, oracle_mod, seed, W=40, H=28, spp=3, dormant=False):
     ctx.upload_scene(sc)
     ctx.frame_begin(W, H)
     ctx.reset_stats()
-    ctx.render(spp=spp)
+    p = abi.default_render_params()
+    p.nee = nee
+    ctx.render(spp=spp, params=p)
     st = ctx.stats()
     img = ctx.download().reshape(-1, 4)
-    ref, so = oracle_mod.Oracle(sc).render(W, H, spp=spp)
+    ref, so = oracle_mod.Oracle(sc).render(W, H, spp=spp, params=p)
     same = np.array_equal(img, ref, equal_nan=True)
     rays = st["extension_rays"] == so["extension_rays"] and st["shadow_rays"] == so["shadow_rays"]
     return same and rays, int((img != ref).any(1).sum()), sc.num_triangles
+
+
+def mutate(sc, seed):
+    """A random per-frame edit of `sc` that keeps its meshes: transforms (translation, mirrored / sheared scale), material
+    handles swapped among the objects, twofaced flips, emission changes, every BSDF table and the lights rescaled, a moved
+    camera.  Returns (edited copy, what changed)."""
+    import copy
+
+    rng = np.random.RandomState(seed * 7919 + 13)
+    sc2 = copy.deepcopy(sc)
+    inst = sc2.instances.copy()
+    n = len(inst)
+    changed = set()
+    for i in range(n):
+        if rng.rand() < 0.5:
+            t = inst["transform"][i].copy()
+            t[12:15] += rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+            if rng.rand() < 0.3:
+                t[0:3] *= np.float32(rng.choice([-1.0, 0.5, 1.7]))  # first column: mirror / non-uniform scale
+            inst["transform"][i] = t
+            changed.add("instances")
+        if rng.rand() < 0.25:
+            inst["bsdf"][i] = inst["bsdf"][rng.randint(n)]
+            changed.add("instances")
+        if rng.rand() < 0.15:
+            inst["twofaced"][i] ^= 1
+            changed.add("instances")
+        if rng.rand() < 0.1:
+            inst["emission"][i] = rng.choice([0.0, 0.5, 8.0], 3).astype(np.float32)
+            changed.add("instances")
+    sc2.instances = inst
+    if rng.rand() < 0.7:
+        bs = [b.copy() for b in sc2.bsdfs]
+        for b in bs:
+            for name in b.dtype.names or ():
+                if name != "has_texture" and len(b) and rng.rand() < 0.5:
+                    b[name] = (b[name] * np.float32(rng.choice([0.5, 0.9, 1.2]))).astype(np.float32)
+        sc2.bsdfs = bs
+        lights = sc2.lights.copy()
+        if len(lights):
+            lights["radiance"] = (lights["radiance"] * np.float32(rng.choice([0.3, 1.0, 2.0]))).astype(np.float32)
+        sc2.lights = lights
+        changed.add("tables")
+    if rng.rand() < 0.7:
+        m = np.array(sc2.to_world, np.float32).copy()
+        m[12:15] += rng.uniform(-0.2, 0.2, 3).astype(np.float32)
+        sc2.to_world = m
+        sc2.fov = np.float32(float(sc2.fov) * rng.choice([0.8, 1.0, 1.3]))
+        changed.add("camera")
+    return sc2, changed
+
+
+def check_updates(ctx, oracle_mod, seed, W=40, H=28, spp=3):
+    """random_scene(seed) is uploaded and rendered, then edited in place through gsp_update_camera / _tables / _instances
+    (two rounds of edits) -- every frame against the oracle on the scene as it stands."""
+    sc = random_scene(seed)
+    ctx.upload_scene(sc)
+    bad = 0
+    for step in range(3):
+        if step:
+            sc, what = mutate(sc, seed * 4 + step)
+            if "tables" in what:
+                ctx.update_tables(sc)
+            if "instances" in what:
+                ctx.update_instances(sc.instances)
+            if "camera" in what:
+                ctx.update_camera(sc.to_world, sc.fov)
+        ctx.frame_begin(W, H)
+        ctx.reset_stats()
+        ctx.render(spp=spp)
+        st = ctx.stats()
+        img = ctx.download().reshape(-1, 4)
+        ref, so = oracle_mod.Oracle(sc).render(W, H, spp=spp)
+        if not (np.array_equal(img, ref, equal_nan=True) and st["extension_rays"] == so["extension_rays"] and st["shadow_rays"] == so["shadow_rays"]):
+            bad += 1
+    return bad == 0, bad, sc.num_triangles
 
 
 if __name__ == "__main__":
@@ -75,11 +156,15 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     dormant = len(sys.argv) > 3 and sys.argv[3] == "dormant"
+    nee = 0 if len(sys.argv) > 3 and sys.argv[3] == "nee0" else 1
     bad = []
     with g.Context(0) as ctx:
         for seed in range(s0, s0 + n):
-            ok, ndiff, tris = check(ctx, O, seed, dormant=dormant)
+            if len(sys.argv) > 3 and sys.argv[3] == "updates":
+                ok, ndiff, tris = check_updates(ctx, O, seed)
+            else:
+                ok, ndiff, tris = check(ctx, O, seed, dormant=dormant, nee=nee)
             if not ok:
                 bad.append((seed, ndiff))
                 print("seed %d: MISMATCH (%d pixels, %d tris)" % (seed, ndiff, tris), flush=True)
-    print("%d scenes%s, %d mismatching: %s" % (n, " with the dormant-feature extension" if dormant else "", len(bad), bad))
+    print("%d scenes%s, %d mismatching: %s" % (n, " with the dormant-feature extension" if dormant else (" with nee = 0" if nee == 0 else ""), len(bad), bad))
