@@ -19,10 +19,16 @@ scene at 1920x1080, on 1/2/4/8 MI355X.
 * Scene upload and BVH build are outside the timed region (reported separately).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, k_trace<ExtendIO> (closest-hit BVH traversal),
-against the resource that binds it -- VALU instruction issue: wave64 VALU instructions per second
-(rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from the committed PMC passes over this same command line,
-profiles/pmc_bench_*.json) over this run's HIP-event kernel time, against 1024 SIMDs x 2.4 GHz / 2 cycles.  The
-memory side is reported next to it: counter HBM bytes per launch (`traffic`, FETCH_SIZE / WRITE_SIZE with the
+against the three ceilings it runs near, `bound` naming the one it is closest to:
+  valu_issue_weighted  wave64 VALU instructions per second (rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from the
+                       committed PMC passes over this same command line, profiles/pmc_bench_*.json, over this run's HIP-event
+                       kernel time) against 1024 SIMDs x 2.4 GHz / the kernel's mean issue cost (static class mix of the
+                       loaded library: full / half / quarter-rate instructions, lib/valu_mix.json); `fractions.valu_issue`
+                       is the same rate against 2 cycles per instruction;
+  l1_request           16-B lane loads per second (from the live statistics pass: 4 per node record not served from LDS,
+                       3 per triangle packet, 2 for the ray) against one per cycle and CU;
+  hbm                  counter bytes per second against 8 TB/s.
+The memory side in detail: counter HBM bytes per launch (`traffic`, FETCH_SIZE / WRITE_SIZE with the
 calibration of scripts/microbench/fetch_calib.hip) as a fraction of the 8 TB/s peak (`hbm_frac`), and the SURVEY 8(d)
 algorithmic bytes (every node / triangle record the traversal reads, mostly served by L2 / Infinity Cache) as
 `algorithmic_gbs` -- informational, not a fraction of anything.  `frac` is an issue-rate UTILISATION (a build that
@@ -45,6 +51,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# Vector-memory request path: one divergent 16-B lane load per cycle and CU (scripts/microbench/lane_fetch.hip measures 614 G/s
+# = 256 CUs x 2.4 GHz for the traversal's access pattern, profiles/r03_trace_bound.txt)
+L1_REQUEST_PEAK_G = 256 * 2.4
 # VALU issue peak: 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz max clock (same guide)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 PMC_GLOB = os.path.join(ROOT, "profiles", "pmc_bench_*.json")  # one file per profiled command line (steps / warmup)
@@ -268,22 +277,21 @@ def _main():
         sk.close()
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    import gpuspectral_amd as g
-    from gpuspectral_amd import multigpu, scenes  # noqa: F401
-
     if world > 1 or args.force_dist:
         from datetime import timedelta
 
-        # RCCL wants one GPU per rank: refuse an over-subscribed launch BEFORE any GPU call (gsp_device_count and
-        # torch.cuda.device_count only count devices; neither initialises one)
-        if args.backend == "nccl" and world > max(1, g.device_count()):
-            if rank == 0:
-                print("bench.py: --gpus %d over the nccl backend needs %d visible GPUs, this node shows %d "
-                      "(use --backend gloo for a dry run that shares GPUs)" % (world, world, g.device_count()), file=sys.stderr)
-            sys.exit(2)
+        # torch FIRST: the tracer's library then binds to the HIP runtime torch has loaded (the other order leaves torch's
+        # bundled runtime without a device: "No HIP GPUs are available")
         import torch
         import torch.distributed as dist
 
+        # RCCL wants one GPU per rank: refuse an over-subscribed launch BEFORE any GPU call (torch.cuda.device_count only
+        # counts devices, it initialises none)
+        if args.backend == "nccl" and world > max(1, torch.cuda.device_count()):
+            if rank == 0:
+                print("bench.py: --gpus %d over the nccl backend needs %d visible GPUs, this node shows %d "
+                      "(use --backend gloo for a dry run that shares GPUs)" % (world, world, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(2)
         # a rank that dies must not leave the others in a collective until the driver's limit: every wait of this group
         # gives up after --dist-timeout seconds
         tmo = timedelta(seconds=args.dist_timeout)
@@ -292,6 +300,9 @@ def _main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
         else:
             dist.init_process_group("gloo", timeout=tmo)
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import multigpu, scenes  # noqa: F401
 
     sc, scene_name = make_scene(args)
     W, H = args.width, args.height
@@ -329,6 +340,13 @@ def _main():
     st = ctx.stats()
     nodes_per_ray = st["nodes_visited"] / max(1, st["stat_rays"])
     tris_per_ray = st["tris_tested"] / max(1, st["stat_rays"])
+    # requests on the vector-memory path per ray ("lane loads": one lane's 16-B load = one request): a node record read from
+    # HBM / L2 is 4 of them, one read from the block's LDS copy of the top of the tree is none, a triangle packet 3, the
+    # ray's own record 2
+    lds_nodes_per_ray = st["nodes_from_lds"] / max(1, st["stat_rays"])
+    ext_lane_loads = 4.0 * (nodes_per_ray - lds_nodes_per_ray) + 3.0 * tris_per_ray + 2.0
+    sh_n = max(1, st["shadow_stat_rays"])
+    sh_lane_loads = 4.0 * (st["shadow_nodes_visited"] - st["shadow_nodes_from_lds"]) / sh_n + 3.0 * st["shadow_tris_tested"] / sh_n + 2.0 + 1.1
     ctx.reset_stats()
 
     local_t = None
@@ -414,10 +432,53 @@ def _main():
         shd["queue_bytes_per_vertex"] = shade_bytes / max(1.0, vertices)
         shd["queue_gbs"] = shade_bytes / (st["shade_kernel_ms"] * 1e-3) / 1e9 if st["shade_kernel_ms"] > 0 else None
         shd["queue_frac_of_hbm_peak"] = shd["queue_gbs"] / HBM_PEAK_GBS if shd["queue_gbs"] else None
+        # ---- the ceilings the traversal runs against, each as a fraction (DESIGN.md 5 defines them in one line each):
+        #   valu_issue           wave64 VALU instructions / s over 1024 SIMDs x 2.4 GHz / 2 cycles (every instruction full rate)
+        #   valu_issue_weighted  ... over 1024 x 2.4 GHz / the kernel's mean issue cost (static class mix: 2 / 4 / 8 cycles)
+        #   l1_request           lane loads / s over one per cycle and CU
+        #   hbm                  counter bytes / s over 8 TB/s
+        mixf = os.path.join(os.path.dirname(g.lib_path()), "valu_mix.json")
+        vmix = {}
+        try:
+            vm = json.load(open(mixf))
+            if vm.get("library_digest") == digest:
+                vmix = vm["kernels"]
+        except (OSError, ValueError):
+            pass
+
+        def ceilings(k, kname, lane_loads_per_ray, rays, ms):
+            """adds the request-path and class-weighted issue figures to a kernel_rates() dict"""
+            k["lane_loads_per_ray"] = lane_loads_per_ray
+            k["lane_loads_g_s"] = lane_loads_per_ray * rays / (ms * 1e-3) / 1e9 if ms > 0 else None
+            k["l1_request_frac"] = k["lane_loads_g_s"] / L1_REQUEST_PEAK_G if k["lane_loads_g_s"] else None
+            cyc = (vmix.get(kname) or {}).get("mean_issue_cycles")
+            k["valu_mean_issue_cycles"] = cyc
+            k["valu_weighted_peak_ginstr_s"] = 1024 * 2.4 / cyc if cyc else None
+            k["issue_frac_weighted"] = k["valu_ginstr_s"] / k["valu_weighted_peak_ginstr_s"] if (cyc and k["valu_ginstr_s"]) else None
+            fr = {"valu_issue_weighted": k["issue_frac_weighted"], "l1_request": k["l1_request_frac"], "hbm": k["hbm_frac"]}
+            fr = {a: b for a, b in fr.items() if b is not None}
+            k["bound"] = max(fr, key=fr.get) if fr else None
+            return k
+
+        ceilings(ext, "k_trace_extend", ext_lane_loads, ext_traced0, ext_ms)
+        ceilings(con, "k_trace_connect", sh_lane_loads, st["shadow_rays"], st["connect_kernel_ms"])
+        ceilings(shd, "k_shade", 9.0, vertices, st["shade_kernel_ms"])  # 5 coalesced record quads + the 4 quads of the shading packet
+        bound = ext["bound"] or "valu_issue"
+        pick = {"valu_issue_weighted": (ext["valu_ginstr_s"], ext["valu_weighted_peak_ginstr_s"], "G wave64 VALU instr/s", ext["issue_frac_weighted"]),
+                "l1_request": (ext["lane_loads_g_s"], L1_REQUEST_PEAK_G, "G lane loads/s", ext["l1_request_frac"]),
+                "hbm": (ext["hbm_gbs"], HBM_PEAK_GBS, "GB/s", ext["hbm_frac"]),
+                "valu_issue": (ext["valu_ginstr_s"], VALU_PEAK_GINST, "G wave64 VALU instr/s", ext["issue_frac"])}[bound]
         roof = {
             "kernel": "k_trace<ExtendIO> (closest-hit traversal of the wide BVH)",
-            "bound": "valu_issue",
-            "achieved": ext["valu_ginstr_s"], "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instr/s", "frac": ext["issue_frac"],
+            # the ceiling the kernel is CLOSEST to (largest fraction) of: class-weighted VALU issue, L1 request path, HBM
+            "bound": bound,
+            "achieved": pick[0], "peak": pick[1], "unit": pick[2], "frac": pick[3],
+            "fractions": {"valu_issue": ext["issue_frac"], "valu_issue_weighted": ext["issue_frac_weighted"],
+                          "l1_request": ext["l1_request_frac"], "hbm": ext["hbm_frac"]},
+            "valu_ginstr_s": ext["valu_ginstr_s"], "valu_peak_ginstr_s": VALU_PEAK_GINST,
+            "valu_weighted_peak_ginstr_s": ext["valu_weighted_peak_ginstr_s"], "valu_mean_issue_cycles": ext["valu_mean_issue_cycles"],
+            "lane_loads_per_ray": ext_lane_loads, "lds_nodes_per_ray": lds_nodes_per_ray, "lane_loads_g_s": ext["lane_loads_g_s"],
+            "l1_request_peak_g_s": L1_REQUEST_PEAK_G,
             "lanes_per_instr": ext["lanes_per_instr"],
             # work-normalised: a build that issues MORE instructions per ray scores higher on `frac`; these do not
             "effective": ext["effective"],

@@ -221,6 +221,10 @@ class Stats(C.Structure):
         ("memoised_rays", C.c_uint64),
         ("memo_build_rays", C.c_uint64),
         ("bvh_depth", C.c_uint64),
+        ("nodes_from_lds", C.c_uint64),
+        ("shadow_nodes_from_lds", C.c_uint64),
+        ("shadow_stat_occluded", C.c_uint64),
+        ("shadow_stat_occluded_nodes", C.c_uint64),
         ("scene_updates", C.c_uint64),
     ]
 

@@ -541,6 +541,10 @@ int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
       t.shadow_nodes_visited += s.shadow_nodes_visited;
       t.shadow_tris_tested += s.shadow_tris_tested;
       t.shadow_stat_rays += s.shadow_stat_rays;
+      t.nodes_from_lds += s.nodes_from_lds;
+      t.shadow_nodes_from_lds += s.shadow_nodes_from_lds;
+      t.shadow_stat_occluded += s.shadow_stat_occluded;
+      t.shadow_stat_occluded_nodes += s.shadow_stat_occluded_nodes;
       t.algorithmic_bytes += s.algorithmic_bytes;
       t.memoised_rays += s.memoised_rays;
       t.memo_build_rays += s.memo_build_rays;

@@ -81,7 +81,7 @@ enum { C_LIVE = 2 * kTailSet, C_READBACK = C_LIVE + kMaxSlots,
        C_WORK_EXT = ((C_READBACK + 31) / 32) * 32, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
        C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
 struct DevStats {
-  unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays;
+  unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays, sh_occluded, sh_occluded_nodes, lds_nodes, sh_lds_nodes;
 };
 
 __device__ __forceinline__ q4 mkq(float x, float y, float z, float w) {
@@ -269,6 +269,10 @@ constexpr int kShadeWaves = kShadeBlock / 64;
 #ifndef GSP_SHADE_MINWAVES
 #define GSP_SHADE_MINWAVES 4  // 128 VGPRs: 4 blocks of 256 threads per CU
 #endif
+// r04: a software-pipelined tile loop (the hit / P0 / P1 records of tile i + 1 brought into a second set of LDS buffers by
+// LDS-DMA, global_load_lds_dwordx4, while tile i is shaded; P2 / P3 gathered at the sorted index) was built, is bit-exact
+// and measured flat to 2 % SLOWER on five scenes (profiles/r04_ab_shade_pipeline_*.txt; the patch:
+// scripts/experiments/r04_shade_pipeline_lds_dma.patch): what the prefetch hides, the two extra gathers cost.
 // TEX: scene with textures / an environment map (dormant-feature extension): a second instantiation, so that the code
 // of the reference's path (TEX = false) is what it was
 template <bool TEX>
@@ -675,6 +679,7 @@ struct gsp_context {
   DevBuf<float> trace_rays;  // gsp_trace: grow-only staging, kept across calls
   DevBuf<q4> trace_hits;
   DevBuf<uint32_t> trace_work;
+  DevBuf<uint32_t> node_hist, tri_hist;  // collect_traversal_stats = 2 (gsp_debug_visit_histograms)
   uint32_t spill_stride = 0;
   gsp_stats stats{};
 
@@ -1064,6 +1069,9 @@ static int bake_and_build(gsp_context* ctx) {
   bi.num_tris = (uint32_t)ctx->total_tris;
   bi.reinsert_rounds = (int)ctx->opt.reinsert_rounds - 1;
   ctx->bytes -= ctx->bvh.bytes;
+  if (ctx->node_hist.p) ctx->bytes -= (ctx->node_hist.count + ctx->tri_hist.count) * sizeof(uint32_t);
+  ctx->node_hist.release();
+  ctx->tri_hist.release();
   int rc = build_bvh(st, bi, ctx->bvh, ctx->err);  // (synchronises the stream: inv_t / tri_first may go out of scope)
   if (rc != GSP_OK) return rc;
   ctx->bytes += ctx->bvh.bytes;
@@ -1369,8 +1377,20 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   PathQueue Q[2];
   for (int k = 0; k < 2; ++k) Q[k] = PathQueue{L.P0[k].p, L.P1[k].p, L.P2[k].p, L.P3[k].p};
   ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p};
-  const TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays};
-  const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays};
+  TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays, nullptr, nullptr, &ctx->dstats.p->lds_nodes};
+  const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays, &ctx->dstats.p->sh_occluded,
+                            &ctx->dstats.p->sh_occluded_nodes, &ctx->dstats.p->sh_lds_nodes};
+  if (rp->collect_traversal_stats >= 2) {  // per-record visit counts of the closest-hit rays (measurement hook)
+    const size_t nn = std::max<size_t>(ctx->bvh.num_nodes, 1), ns = (size_t)ctx->bvh.num_tris + ctx->bvh.first_slot + kWide;
+    if (ctx->node_hist.count < nn || ctx->tri_hist.count < ns) {
+      CTX_TRY(ctx, ctx->node_hist.ensure(nn, &ctx->bytes));
+      CTX_TRY(ctx, ctx->tri_hist.ensure(ns, &ctx->bytes));
+      CTX_TRY(ctx, hipMemsetAsync(ctx->node_hist.p, 0, ctx->node_hist.count * sizeof(uint32_t), st));
+      CTX_TRY(ctx, hipMemsetAsync(ctx->tri_hist.p, 0, ctx->tri_hist.count * sizeof(uint32_t), st));
+    }
+    so_ext.node_hist = ctx->node_hist.p;
+    so_ext.tri_hist = ctx->tri_hist.p;
+  }
   const uint64_t n = P.n;  // exact, or an upper bound of what this iteration traces
   const int cur = P.cur;
   gsp_context::Lane::Iter& I = L.it[t];
@@ -1842,6 +1862,10 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
     ctx->stats.shadow_nodes_visited = d.sh_nodes;
     ctx->stats.shadow_tris_tested = d.sh_tris;
     ctx->stats.shadow_stat_rays = d.sh_rays;
+    ctx->stats.nodes_from_lds = d.lds_nodes;
+    ctx->stats.shadow_nodes_from_lds = d.sh_lds_nodes;
+    ctx->stats.shadow_stat_occluded = d.sh_occluded;
+    ctx->stats.shadow_stat_occluded_nodes = d.sh_occluded_nodes;
   }
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
   ctx->stats.num_triangles = ctx->bvh.num_tris;
@@ -1869,6 +1893,25 @@ int gsp_reset_stats(gsp_context* ctx) {
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
     CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return GSP_OK;
+}
+
+int gsp_debug_visit_histograms(gsp_context* ctx, uint32_t* node_counts, uint64_t num_nodes, uint32_t* slot_counts, uint64_t num_slots) {
+  if (!ctx) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
+  if (!ctx->node_hist.p || !ctx->tri_hist.p) {
+    ctx->err = "gsp_debug_visit_histograms: no render with collect_traversal_stats = 2 since the last call";
+    return GSP_ERR_INVALID;
+  }
+  if (node_counts) CTX_TRY(ctx, hipMemcpy(node_counts, ctx->node_hist.p, std::min<uint64_t>(num_nodes, ctx->node_hist.count) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (slot_counts) CTX_TRY(ctx, hipMemcpy(slot_counts, ctx->tri_hist.p, std::min<uint64_t>(num_slots, ctx->tri_hist.count) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  ctx->bytes -= (ctx->node_hist.count + ctx->tri_hist.count) * sizeof(uint32_t);
+  ctx->node_hist.release();
+  ctx->tri_hist.release();
   return GSP_OK;
 }
 

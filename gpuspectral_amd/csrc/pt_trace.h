@@ -64,6 +64,11 @@ constexpr uint32_t kNodeBytes = 16u * kNodeQuads;
 #define GSP_TOP_NODES 64
 #endif
 constexpr uint32_t kTopNodes = GSP_TOP_NODES;
+// (r04: staging the first 64 triangle SLOTS as well -- the leaf children of the top of the tree, i.e. the scene's largest
+// triangles, which take 2.14 of the 3.93 triangle tests of a closest-hit ray on the bench scene -- was built, is bit-exact and
+// changes nothing: 90.4-91.2 vs 89.9-90.9 ms; neither does 32 / 96 / 128 instead of 64 nodes.  The kernel is bound by VALU
+// issue, not by the request path.  profiles/r04_lds_budget_probe.txt, r04_ab_lds_triangles.txt, r04_ab_top_nodes.txt;
+// scripts/experiments/r04_lds_triangle_packets.patch)
 constexpr size_t kNodeAllocMin = (size_t)(kTopNodes > 0 ? kTopNodes : 1) * kNodeBytes;
 // A stack entry is (child_base << kGroupBits) | group: the group that is PUSHED has already lost the child being
 // descended into (group_next runs first), so it names at most three children -- a marker bit over 3 x 2 bits for a

@@ -148,6 +148,11 @@ struct TraceStatsOut {
   unsigned long long* nodes;
   unsigned long long* tris;
   unsigned long long* rays;
+  unsigned long long* hits = nullptr;       // rays that ended with a hit (any-hit: occluded shadow rays)
+  unsigned long long* hit_nodes = nullptr;  // node records those rays read
+  unsigned long long* lds_nodes = nullptr;  // node records served by the block's LDS copy of the top of the tree
+  uint32_t* node_hist = nullptr;            // visits per node index / tests per triangle slot (collect_traversal_stats = 2):
+  uint32_t* tri_hist = nullptr;             // which records would an LDS copy have to hold?
 };
 
 // lanes set in a ballot, as a 32-bit scalar: comparing the 64-bit result of __popcll with a constant is compiled
@@ -185,6 +190,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   // the top of the tree: every ray starts there, and a fetch from LDS is not one of the divergent 16-B requests of which
   // the vector-memory path takes one per cycle and CU (scripts/microbench/lane_fetch.hip) -- the rate both traversal
   // kernels run at
+  // (r04: a quad-major copy -- quad k of node n at lds_top[k * kTopNodes + n], so that lanes reading the same quad of different
+  // nodes spread over all 32 banks instead of 2 of the 8 four-bank groups -- halves SQ_LDS_BANK_CONFLICT (1.89e8 -> 0.90e8 per
+  // closest-hit launch, 6.6e7 -> 1.2e7 any-hit) and changes the closest-hit kernel by nothing, the any-hit kernel by +2.5 %
+  // (one more address op per LDS node step): the replays are hidden behind the other six waves.  profiles/r04_ab_lds_layout.txt)
   __shared__ q4 lds_top[kTopNodes > 0 ? kTopNodes * kNodeQuads : 1];
   for (uint32_t i = threadIdx.x; i < kTopNodes * kNodeQuads; i += kTraceBlock) lds_top[i] = nodes[i];
   __syncthreads();
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   h.t = 0.0f;
   h.u = h.v = 0.0f;
   h.slot = -1;
-  uint32_t c_nodes = 0, c_tris = 0, c_rays = 0;
+  uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0, c_hit_nodes = 0, ray_nodes = 0, c_lds = 0;  // (STATS instantiations only)
 
 #ifdef GSP_WAVE_PROFILE
   unsigned long long wp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -242,6 +251,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           if (pending) {
             io.store(ri, h, best_id & 7u, pay);
             ri = 0xffffffffu;
+            if (STATS && h.slot >= 0) {
+              ++c_hits;
+              c_hit_nodes += ray_nodes;
+            }
           }
         }
       }
@@ -286,7 +299,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           gb = 0u;
           gs = root_group<ANY>();
           tm = tm2 = 0u;
-          if (STATS) ++c_rays;
+          if (STATS) {
+            ++c_rays;
+            ray_nodes = 0;
+          }
         }
         const uint32_t want = (uint32_t)__popcll(idle_m);
         pool_next += want < avail ? want : avail;
@@ -353,7 +369,12 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 #pragma unroll
             for (uint32_t k = 0; k < kNodeQuads; ++k) nq[k] = nd[k];
           }
-          if (STATS) ++c_nodes;
+          if (STATS) {
+            ++c_nodes;
+            ++ray_nodes;
+            if (kTopNodes > 0 && noff < kTopNodes * kNodeBytes) ++c_lds;
+            if (so.node_hist) atomicAdd(so.node_hist + noff / kNodeBytes, 1u);
+          }
           uint32_t ngb, ngs, ntb, ntm;
           node_step<ANY>(nq, rb, tmin, h.t, tab, ngb, ngs, ntb, ntm);
           if (!group_empty<ANY>(ngs)) {  // descend: the rest of the current group waits on the stack
@@ -404,7 +425,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
         aw = p0.w;
         hit = intersect_tri_rot(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u, v);
       }
-      if (STATS) c_tris += act ? 1u : 0u;
+      if (STATS) {
+        c_tris += act ? 1u : 0u;
+        if (act && so.tri_hist) atomicAdd(so.tri_hist + slot, 1u);
+      }
       if (ANY) {  // the first accepted triangle ends the ray
         h.t = hit ? t : h.t;
         h.slot = hit ? (int32_t)slot : h.slot;
@@ -434,10 +458,14 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 #endif
   if (STATS) {
     const unsigned long long a = wave_sum_u64(c_nodes), b = wave_sum_u64(c_tris), c = wave_sum_u64(c_rays);
+    const unsigned long long d = wave_sum_u64(c_hits), e = wave_sum_u64(c_hit_nodes), f = wave_sum_u64(c_lds);
     if (lane == 0) {
       atomicAdd(so.nodes, a);
       atomicAdd(so.tris, b);
       atomicAdd(so.rays, c);
+      if (so.lds_nodes) atomicAdd(so.lds_nodes, f);
+      if (so.hits) atomicAdd(so.hits, d);
+      if (so.hit_nodes) atomicAdd(so.hit_nodes, e);
     }
   }
 }

@@ -38,6 +38,7 @@ EXPORTS = (
     "gsp_get_stats",
     "gsp_reset_stats",
     "gsp_trace",
+    "gsp_debug_visit_histograms",
     "gsp_last_error",
     "gsp_tile_partition",
     "gsp_multi_create",
@@ -108,6 +109,7 @@ def load():
     L.gsp_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.gsp_reset_stats.argtypes = [vp]
     L.gsp_trace.argtypes = [vp, vp, u64, C.c_int, vp]
+    L.gsp_debug_visit_histograms.argtypes = [vp, vp, u64, vp, u64]
     L.gsp_last_error.argtypes = [vp]
     L.gsp_last_error.restype = C.c_char_p
     L.gsp_tile_partition.argtypes = [u32, u32, u32, u32, u32, vp]
@@ -296,6 +298,15 @@ class Context:
 
     def reset_stats(self):
         self._check(self._L.gsp_reset_stats(self._h), "gsp_reset_stats")
+
+    def visit_histograms(self):
+        """(visits per node index, tests per triangle slot) of the closest-hit rays traced with collect_traversal_stats=2."""
+        st = self.stats()
+        nodes = np.zeros(int(st["num_bvh_nodes"]), np.uint32)
+        slots = np.zeros(int(st["num_triangles"]) + 8, np.uint32)
+        self._check(self._L.gsp_debug_visit_histograms(self._h, nodes.ctypes.data, len(nodes), slots.ctypes.data, len(slots)),
+                    "gsp_debug_visit_histograms")
+        return nodes, slots
 
     def trace(self, rays, any_hit=False):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

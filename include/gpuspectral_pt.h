@@ -241,7 +241,8 @@ typedef struct gsp_render_params {
   uint32_t rr_start_depth;
   float clamp;
   uint32_t timestamps_in_flight; /* samples traced concurrently; 0 = auto */
-  uint32_t collect_traversal_stats; /* 1: count BVH nodes / triangles per ray (slower) */
+  uint32_t collect_traversal_stats; /* 1: count BVH nodes / triangles per ray (slower); 2: and per-record visit counts of the
+                                       closest-hit rays (gsp_debug_visit_histograms) */
   uint32_t collect_kernel_times;    /* 1: HIP-event time every extend/shade/connect launch (2: and print one line per iteration to stderr) */
   uint32_t nee;             /* (ABI 5) RenderParams.nee (S/renderer/PathTracer.h:36-41), which the shipped shader replaces by
                                `#define NEE true` (rayhit.rchit:656).  1 (default) = the reference as shipped.  0 = the other side
@@ -284,6 +285,10 @@ typedef struct gsp_stats {
   uint64_t bvh_depth;        /* (ABI 4) levels of the wide BVH: a traversal stacks at most one entry per level; beyond the 20
                                 levels a lane keeps in LDS the stack continues in HBM, beyond 34 the tail of a drain is left
                                 to the wavefront kernels */
+  uint64_t nodes_from_lds;             /* (ABI 5, stats mode) of nodes_visited / shadow_nodes_visited: node records the traversal read ... */
+  uint64_t shadow_nodes_from_lds;      /* ... from its LDS copy of the top of the tree (no request on the vector-memory path)         */
+  uint64_t shadow_stat_occluded;       /* (ABI 5, stats mode) shadow rays of shadow_stat_rays that were occluded ...          */
+  uint64_t shadow_stat_occluded_nodes; /* ... and the node records those read (the rest of shadow_nodes_visited: unoccluded) */
   uint64_t scene_updates;    /* (ABI 5) gsp_update_camera / _instances / _tables calls that changed something since the last
                                 gsp_upload_scene (a test hook: which path did the host layer take?) */
 } gsp_stats;
@@ -414,6 +419,11 @@ int gsp_reset_stats(gsp_context* ctx);
  * shadow-ray kernel (prim = 0 when occluded, -1 when not).
  */
 int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void* hits);
+
+/* Measurement hook: after renders with collect_traversal_stats = 2, how often the closest-hit rays read each node record
+ * (index = position in the level-ordered node array) and tested each triangle slot.  Copies min(count, available) words,
+ * then drops the counters.  It answers "which records would an LDS copy have to hold?" (DESIGN.md 4). */
+int gsp_debug_visit_histograms(gsp_context* ctx, uint32_t* node_counts, uint64_t num_nodes, uint32_t* slot_counts, uint64_t num_slots);
 
 /* Last error message of this context (or of the failed gsp_ctx_create when
  * ctx == NULL).  Never NULL. */

@@ -19,7 +19,7 @@ hipcc $F -c pt_multi.hip -o build/var_$1/pt_multi.o &
 wait
 printf 'extern "C" const char gsp_build_info_string[] = "arch=gfx950 digest=variant-%s flags=%s";\n' "$1" "$F" > build/var_$1/pt_buildinfo.cpp
 g++ -O2 -fPIC -c build/var_$1/pt_buildinfo.cpp -o build/var_$1/pt_buildinfo.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/gpuspectral_amd/lib/variants/$1.so" build/var_$1/pt_render.o build/var_$1/pt_bvh.o build/var_$1/pt_multi.o build/var_$1/pt_buildinfo.o $( grep -q rccl pt_multi.hip && echo -L/opt/rocm/lib -lrccl )
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/gpuspectral_amd/lib/variants/$1.so" build/var_$1/pt_render.o build/var_$1/pt_bvh.o build/var_$1/pt_multi.o build/var_$1/pt_buildinfo.o $( grep -q dlopen pt_multi.hip && echo -ldl || echo -L/opt/rocm/lib -lrccl )
 echo built $1
 rm -rf build/var_$1
 [ -n "$3" ] && rm -rf "$T" || true

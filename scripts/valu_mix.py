@@ -14,8 +14,8 @@ FULL = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_sub
 QUARTER = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32"}
 
 
-def main(path, sym):
-    text = open(path).read()
+def mix(text, sym):
+    """-> (symbol, Counter of VALU opcodes, n, full, half, quarter) of the first kernel whose mangled name contains `sym`."""
     m = re.search(r"^(%s[^\n:]*):" % ("_Z[^\n:]*" + re.escape(sym)), text, re.M)
     start = m.end()
     end = text.index("s_endpgm", start)
@@ -28,7 +28,32 @@ def main(path, sym):
     n = sum(ops.values())
     full = sum(c for o, c in ops.items() if o in FULL)
     quarter = sum(c for o, c in ops.items() if o in QUARTER)
-    half = n - full - quarter
+    return m.group(1), ops, n, full, n - full - quarter, quarter
+
+
+# the three render kernels as bench.py names them -> substring of the mangled symbol (non-STATS, non-TEX instantiations)
+RENDER_KERNELS = {"k_trace_extend": "k_traceILb0ELb0ENS_12_GLOBAL__N_18ExtendIO", "k_trace_connect": "k_traceILb1ELb0ENS_12_GLOBAL__N_19ConnectIO",
+                  "k_shade": "k_shadeILb0E"}
+
+
+def write_json(path, out, digest):
+    """csrc/Makefile: the static class mix of the render kernels next to the library, stamped with its source digest;
+    bench.py turns it into the class-weighted VALU issue ceiling of `roofline`."""
+    import json
+
+    text = open(path).read()
+    rec = {"library_digest": digest, "costs_cycles": {"full": 2, "half": 4, "quarter": 8}, "kernels": {}}
+    for name, sym in RENDER_KERNELS.items():
+        _, _, n, full, half, quarter = mix(text, sym)
+        arch = (2 * full + 4 * half + 8 * quarter) / n
+        rec["kernels"][name] = {"valu_instructions_static": n, "full": full, "half": half, "quarter": quarter, "mean_issue_cycles": arch}
+    json.dump(rec, open(out, "w"), indent=1)
+
+
+def main(path, sym):
+    text = open(path).read()
+    name, ops, n, full, half, quarter = mix(text, sym)
+    m = type("M", (), {"group": lambda self, i: name})()
     print("%s: %d VALU instructions: full-rate %d (%.1f %%), half-rate %d (%.1f %%), quarter-rate %d (%.1f %%)" % (
         m.group(1)[:60], n, full, 100.0 * full / n, half, 100.0 * half / n, quarter, 100.0 * quarter / n))
     arch = (2 * full + 4 * half + 8 * quarter) / n
@@ -40,4 +65,7 @@ def main(path, sym):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) == 5 and sys.argv[2] == "--json":
+        write_json(sys.argv[1], sys.argv[3], sys.argv[4])
+    else:
+        main(sys.argv[1], sys.argv[2])

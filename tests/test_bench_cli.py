@@ -94,10 +94,10 @@ def test_gpus_defaults_to_world_size(monkeypatch, capsys):
 def test_nccl_ranks_beyond_the_visible_gpus_are_refused(monkeypatch, capsys):
     """`--gpus N` over the nccl backend with fewer than N visible GPUs exits with 2 before torch, a
     process group or a device context exists (RCCL wants one GPU per rank; a hung init would cost the driver its limit)."""
-    import gpuspectral_amd as g
+    import torch
 
     b = _load_bench()
-    n = g.device_count() + 2
+    n = torch.cuda.device_count() + 2
     monkeypatch.setenv("WORLD_SIZE", str(n))
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")

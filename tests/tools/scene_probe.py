@@ -46,4 +46,9 @@ with g.Context(0) as ctx:
                               launches=st["extend_launches"],
                               nodes_per_ray=round(s0["nodes_visited"] / max(1, s0["stat_rays"]), 2), tris_per_ray=round(s0["tris_tested"] / max(1, s0["stat_rays"]), 2),
                               shadow_nodes_per_ray=round(s0["shadow_nodes_visited"] / max(1, s0["shadow_stat_rays"]), 2),
-                              shadow_tris_per_ray=round(s0["shadow_tris_tested"] / max(1, s0["shadow_stat_rays"]), 2))), flush=True)
+                              shadow_tris_per_ray=round(s0["shadow_tris_tested"] / max(1, s0["shadow_stat_rays"]), 2),
+                              # any-hit rays by verdict (is an occluder cache worth building?)
+                              shadow_occluded_share=round(s0["shadow_stat_occluded"] / max(1, s0["shadow_stat_rays"]), 3),
+                              occluded_nodes_per_ray=round(s0["shadow_stat_occluded_nodes"] / max(1, s0["shadow_stat_occluded"]), 2),
+                              unoccluded_nodes_per_ray=round((s0["shadow_nodes_visited"] - s0["shadow_stat_occluded_nodes"]) /
+                                                             max(1, s0["shadow_stat_rays"] - s0["shadow_stat_occluded"]), 2))), flush=True)
