@@ -585,9 +585,11 @@ __global__ __launch_bounds__(kBlock) void k_ri_validate(uint32_t n, int32_t root
   }
   const RiRec r = ri_load(nodes2, (int32_t)t), rp = ri_load(nodes2, pp);
   const int s = rp.code[0] == (int32_t)t ? 0 : 1;
-  const bool ok = rp.code[s] == (int32_t)t && rp.lo[s].x == fminf(r.lo[0].x, r.lo[1].x) && rp.lo[s].y == fminf(r.lo[0].y, r.lo[1].y) &&
-                  rp.lo[s].z == fminf(r.lo[0].z, r.lo[1].z) && rp.hi[s].x == fmaxf(r.hi[0].x, r.hi[1].x) &&
-                  rp.hi[s].y == fmaxf(r.hi[0].y, r.hi[1].y) && rp.hi[s].z == fmaxf(r.hi[0].z, r.hi[1].z);
+  // (bit patterns, not float ==: a box of NaN coordinates -- garbage in -- still equals itself)
+  auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b); };
+  const bool ok = rp.code[s] == (int32_t)t && same(rp.lo[s].x, fminf(r.lo[0].x, r.lo[1].x)) && same(rp.lo[s].y, fminf(r.lo[0].y, r.lo[1].y)) &&
+                  same(rp.lo[s].z, fminf(r.lo[0].z, r.lo[1].z)) && same(rp.hi[s].x, fmaxf(r.hi[0].x, r.hi[1].x)) &&
+                  same(rp.hi[s].y, fmaxf(r.hi[0].y, r.hi[1].y)) && same(rp.hi[s].z, fmaxf(r.hi[0].z, r.hi[1].z));
   if (!ok) atomicAdd(bad, 1u);
 }
 
@@ -745,7 +747,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
 
   Scratch S;
   q4 *isect_g, *shade_g, *lo_g, *hi_g, *leaf_lo, *leaf_hi, *int_lo, *int_hi, *nodes2, *isect_m, *shade_m;
-  uint32_t *bounds, *vals_in, *vals_out, *arrive, *d_depth, *flag, *idx4, *s2g_m;
+  uint32_t *bounds, *vals_in, *vals_out, *arrive, *flag, *idx4, *s2g_m;
   uint64_t *keys_in, *keys_out;
   int32_t *child_l, *child_r, *parent_int, *parent_leaf;
   GSP_HIP_TRY(S.alloc(&isect_g, 3ull * n));
@@ -765,7 +767,6 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(S.alloc(&vals_in, n));
   GSP_HIP_TRY(S.alloc(&vals_out, n));
   GSP_HIP_TRY(S.alloc(&arrive, n));
-  GSP_HIP_TRY(S.alloc(&d_depth, 1));
   GSP_HIP_TRY(S.alloc(&child_l, n));
   GSP_HIP_TRY(S.alloc(&child_r, n));
   GSP_HIP_TRY(S.alloc(&parent_int, n));
@@ -777,7 +778,6 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
   GSP_HIP_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
   GSP_HIP_TRY(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, stream));
-  GSP_HIP_TRY(hipMemsetAsync(d_depth, 0, sizeof(uint32_t), stream));
 
   hipLaunchKernelGGL(k_bake, dim3(blocks_for(n)), dim3(kBlock), 0, stream, in, isect_g, shade_g, lo_g, hi_g, bounds);
   hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, lo_g, hi_g, bounds, keys_in, vals_in);

@@ -80,7 +80,7 @@ def mutate(sc, seed):
     camera.  Returns (edited copy, what changed)."""
     import copy
 
-    rng = np.random.RandomState(seed * 7919 + 13)
+    rng = np.random.RandomState((seed * 7919 + 13) % (1 << 32))
     sc2 = copy.deepcopy(sc)
     inst = sc2.instances.copy()
     n = len(inst)
