@@ -65,6 +65,8 @@ def test_twenty_million_triangles_use_the_25_bit_node_index():
         st = ctx.stats()
         assert st["num_triangles"] == ntri + 2
         assert st["num_bvh_nodes"] > (1 << 23), st["num_bvh_nodes"]  # beyond the old index width: the point of the test
+        print("scale test: %d triangles, %d wide nodes (2^23 = %d), depth %d, upload + build %.0f ms, %.1f GB on the device"
+              % (st["num_triangles"], st["num_bvh_nodes"], 1 << 23, st["bvh_depth"], st["bvh_build_ms"], st["device_bytes"] / 1e9))
         rng = np.random.RandomState(3)
         k = 20000
         ci, cj = rng.randint(0, G, k), rng.randint(0, G, k)
