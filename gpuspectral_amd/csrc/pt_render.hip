@@ -1186,13 +1186,22 @@ static int begin_update(gsp_context* ctx, const char* what) {
   return pipeline_drain(ctx);
 }
 
+// No drain: a path in flight left the camera behind when its primary ray was generated (k_generate / the memo are the only
+// readers of it, and gsp_render returns only after every sample of the call has been generated), so the samples queued so far
+// finish as what they are -- samples through the old camera -- while the next gsp_render generates through the new one; they
+// are folded in timestamp order either way.  A viewer that moves its camera every frame keeps the path pool full
+// (profiles/r04_update_latency.txt: 500x500, one sample per frame).
 int gsp_update_camera(gsp_context* ctx, const gsp_camera* camera) {
   if (!ctx || !camera) return GSP_ERR_INVALID;
-  int rc = begin_update(ctx, "gsp_update_camera");
-  if (rc != GSP_OK) return rc;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_scene) {
+    ctx->err = "gsp_update_camera needs gsp_upload_scene first";
+    return GSP_ERR_INVALID;
+  }
   if (std::memcmp(&ctx->camera, camera, sizeof(gsp_camera)) == 0) return GSP_OK;
   ctx->camera = *camera;  // (render_consts reads it at the next gsp_render)
-  for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;  // the memo holds the hits of the OLD camera rays
+  for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;  // the memo holds the hits of the OLD camera rays: re-traced
+                                                                 // on the lane's stream before the next batch is generated
   ++ctx->stats.scene_updates;
   return GSP_OK;
 }

@@ -349,11 +349,13 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
 /*
  * (ABI 5) Per-frame scene edits.  The reference re-reads camera, object transforms, materials, BSDF tables and lights on
  * every createRenderPass (S/renderer/PathTracer.cpp:10-19,58-93) and only keeps the BLAS of a mesh (Renderer.cpp:122-131);
- * a host that mirrors it calls these between gsp_render calls instead of uploading the whole scene again.  Each call first
- * completes the samples already queued (they belong to the old scene), leaves the accumulate buffer and the timestamps
- * alone -- like the reference, where an edit simply shows up in the next frame's sample; call gsp_frame_begin to restart the
- * running mean -- and invalidates the primary-hit memo.  All need a prior gsp_upload_scene.
- *   gsp_update_camera     new camera; no geometry work.
+ * a host that mirrors it calls these between gsp_render calls instead of uploading the whole scene again.  The samples
+ * already queued belong to the scene as it was and finish as such; accumulate buffer and timestamps are left alone -- like the
+ * reference, where an edit simply shows up in the next frame's sample; call gsp_frame_begin to restart the running mean -- and
+ * the primary-hit memo is invalidated.  All need a prior gsp_upload_scene.
+ *   gsp_update_camera     new camera; no geometry work and NO WAIT: paths in flight have left the camera behind (only ray
+ *                         generation reads it), so a viewer that moves its camera every frame keeps the path pool full.
+ *                         The two calls below first complete the samples already queued (those read the tables / the BVH).
  *   gsp_update_instances  new transform / emission / bsdf / twofaced per instance.  `num_instances` and every
  *                         first_vertex / vertex_count must equal the uploaded ones (the meshes stay: they are resident on
  *                         the device); BSDF handles are checked against the resident tables.  Re-bakes the world-space
