@@ -346,7 +346,7 @@ def _main():
     lds_nodes_per_ray = st["nodes_from_lds"] / max(1, st["stat_rays"])
     ext_lane_loads = 4.0 * (nodes_per_ray - lds_nodes_per_ray) + 3.0 * tris_per_ray + 2.0
     sh_n = max(1, st["shadow_stat_rays"])
-    sh_lane_loads = 4.0 * (st["shadow_nodes_visited"] - st["shadow_nodes_from_lds"]) / sh_n + 3.0 * st["shadow_tris_tested"] / sh_n + 2.0 + 1.1
+    sh_lane_loads = 4.0 * (st["shadow_nodes_visited"] - st["shadow_nodes_from_lds"]) / sh_n + 3.0 * st["shadow_tris_tested"] / sh_n + 2.0 + st["shadow_stat_occluded"] / sh_n  # (+ the occluded ray's commit load)
     ctx.reset_stats()
 
     local_t = None
@@ -423,12 +423,12 @@ def _main():
         pmc, pmc_src = pmc_for_run(cfg_key, int(st["extend_launches"]), digest) if world == 1 else (None, "N > 1: counters are a single-GPU measurement")
         vertices = float(tot[8])
         ext = kernel_rates((pmc or {}).get("k_trace_extend"), ext_ms, launches, 32.0 * ext_traced0)
-        # k_trace<ConnectIO> streams the 32-B shadow ray in and 16-20 B of its record at the commit; k_shade streams the hit
-        # + the path record in (80 B per vertex)
-        con = kernel_rates((pmc or {}).get("k_trace_connect"), st["connect_kernel_ms"], launches, 50.0 * st["shadow_rays"])
+        # k_trace<ConnectIO> streams the 32-B shadow ray in (an occluded one loads 16 B more at its commit: a gather);
+        # k_shade streams the hit + the path record in (80 B per vertex)
+        con = kernel_rates((pmc or {}).get("k_trace_connect"), st["connect_kernel_ms"], launches, 32.0 * st["shadow_rays"])
         shd = kernel_rates((pmc or {}).get("k_shade"), st["shade_kernel_ms"], launches, 80.0 * vertices)
-        # k_shade's compulsory queue traffic: hit + path record in, the survivor's record and the shadow record out
-        shade_bytes = 80.0 * vertices + 64.0 * max(0.0, st["extension_rays"] - samples) + 64.0 * st["shadow_rays"]
+        # k_shade's compulsory queue traffic: hit + path record in, the survivor's record and the 48-B shadow record out
+        shade_bytes = 80.0 * vertices + 64.0 * max(0.0, st["extension_rays"] - samples) + 48.0 * st["shadow_rays"]
         shd["queue_bytes_per_vertex"] = shade_bytes / max(1.0, vertices)
         shd["queue_gbs"] = shade_bytes / (st["shade_kernel_ms"] * 1e-3) / 1e9 if st["shade_kernel_ms"] > 0 else None
         shd["queue_frac_of_hbm_peak"] = shd["queue_gbs"] / HBM_PEAK_GBS if shd["queue_gbs"] else None

@@ -9,8 +9,8 @@
 //   shade   : one shading vertex per lane (rayhit.rchit:666-797 + the raygen
 //             bookkeeping of raygen.rgen:59-80); each 256-path tile is counting-sorted by BSDF type in
 //             LDS, survivors are compacted into the next queue with a wave64 ballot + an LDS scan +
-//             one atomic pair per tile; paths that need next-event estimation emit a 64-B
-//             shadow-queue record
+//             one atomic pair per tile; paths that need next-event estimation emit a 48-B
+//             shadow-queue record and their unoccluded outcome at once (optimistic commit)
 //   connect : any-hit traversal of the shadow queue, adds the bounce's emitted
 //             radiance to the sample and sets the continuing path's MIS weight
 //                                                (rayhit.rchit:737-757)
@@ -22,16 +22,18 @@
 //   P0 = {o.x, o.y, o.z, d.x}   P1 = {d.y, d.z, bits(seed), bits(sid)}
 //   P2 = {w.r, w.g, w.b, directWeight}   P3 = {sum.r, sum.g, sum.b, bits(flags)}
 //   HIT = {t, u, v, bits(slot)}
-//   S0 = {o.xyz, tmax}  S1 = {d.xyz, bits(next)}  S2 = {sum if unoccluded .rgb, dw_nee}
+//   S0 = {o.xyz, tmax}  S1 = {d.xyz, bits(next)}
 //   S3 = {sum if occluded .rgb, bits(flags of the continuing path | sample id of a path that ended)}
 // `sum` = the radiance the sample has collected so far (raygen.rgen:60-63 `result`).  It TRAVELS WITH THE PATH (r03): a
 // bounce adds to the copy it read with its path record and hands the new value to the continuing path's record, and
 // only the bounce that ends the path stores it in the sample-result ring.  Until r02 every bounce read-modify-wrote the
 // ring entry of its sample instead -- a scattered 16-B load on the dependent chain of k_trace<ConnectIO>'s commit
 // (three loads -> load -> add -> store), 26 % of that kernel's time (profiles/r03_ab_connect_ablation.txt).  The
-// additions per sample and their order are the same, so the images are.  The shadow record carries BOTH outcomes of
-// its bounce, formed by k_shade with connect_vertex itself: the commit of a shadow ray is one 16-B load of the outcome
-// that happened (+ 4 B) and its stores, no arithmetic.
+// additions per sample and their order are the same, so the images are.  k_shade forms BOTH outcomes of a bounce that
+// traces a shadow ray with connect_vertex itself.  r04: the UNOCCLUDED outcome -- what happens to 80-93 % of the shadow rays
+// -- is written at once where it belongs (the continuing path's P3 and MIS weight, or the sample-result ring), and only the
+// occluded outcome travels in the shadow record: the commit of an unoccluded ray is nothing, that of an occluded one a 16-B
+// load and the stores that overwrite the optimistic values (any-hit kernel -5 ... -21 %, profiles/r04_ab_optimistic_nee.txt).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -60,8 +62,7 @@ struct PathQueue {
 struct ShadowQueue {
   q4* S0;
   q4* S1;
-  q4* S2;
-  q4* S3;
+  q4* S3;  // (S2, the unoccluded outcome, left the record in r04: k_shade writes it where it belongs)
 };
 
 // Device counter words of a pipeline lane.  Two TAIL SETS of 32 words (one 128-B line each), used alternately by
@@ -207,18 +208,17 @@ struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any h
     tmax = s0.w;
     pay = fb(s1.w);  // index of the continuing path in the next queue, or none: the commit needs it
   }
-  // The verdict picks which of the two sums k_shade prepared (`(0 + nee) + emis` or `0 + emis` added behind the firefly
-  // test, rayhit.rchit:750-754 + raygen.rgen:60-63) moves on: into the continuing path's record, or -- the path ended
-  // at this vertex -- into the sample-result ring.  One 16-B load of the ray's own record (+ 4 B when unoccluded) and
-  // one or two stores; nothing is read back from where it is written.
+  // k_shade has already written the outcome of the UNOCCLUDED verdict where it belongs -- the continuing path's P3 (sum | flags)
+  // and P2.w (the MIS weight of rayhit.rchit:785-787), or the sample-result ring for a path that ended at this vertex -- because
+  // that is what happens to 80-93 % of the shadow rays (profiles/r04_scene_probe_occlusion.txt).  Only an OCCLUDED ray has work
+  // left: one 16-B load of the other outcome and the stores that overwrite the optimistic ones (same stream, later kernel).
+  // The values are the ones connect_vertex computed in k_shade either way: nothing is recomputed here.
   __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t, uint32_t nx) const {
-    const bool occluded = h.slot >= 0;
-    q4 res = occluded ? sq.S3[i] : sq.S2[i];
-    const float dw = res.w;                                   // (unoccluded: directWeight of the continuing path)
-    if (!occluded) res.w = sq.S3[i].w;                        // flags of the continuing path | sample id
+    if (h.slot < 0) return;
+    q4 res = sq.S3[i];  // {sum if occluded .rgb, flags of the continuing path | sample id of a path that ended}
     if (nx != 0xffffffffu) {
       next_P3[nx] = res;
-      if (!occluded) next_P2[nx].w = dw;                      // rayhit.rchit:785-787
+      next_P2[nx].w = 1.0f;  // no NEE happened: directWeight stays 1 (rayhit.rchit:788-790)
     } else {
       const uint32_t sid = fb(res.w);
       res.w = 0.0f;
@@ -446,25 +446,27 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     }
     __syncthreads();
     const uint32_t j = s_base[0][wave] + (uint32_t)__popcll(am & lt_mask);
+    // both outcomes of a bounce with a shadow ray, by the function k_finish and the host harness apply once the verdict is
+    // known; the UNOCCLUDED one is written where it belongs right here, the occluded one travels with the shadow ray
+    q4 clear = sum, occ = sum;
+    if (has_shadow) {
+      bool nee_done;
+      connect_vertex(rc.clamp, out.shadow, false, clear, nee_done);
+      connect_vertex(rc.clamp, out.shadow, true, occ, nee_done);
+    }
     if (alive) {
       const PathState& p = out.next;
       qst(&nxt.P0[j], mkq(p.o.x, p.o.y, p.o.z, p.d.x));
       qst(&nxt.P1[j], mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid)));
-      qst(&nxt.P2[j], mkq(p.weight.x, p.weight.y, p.weight.z, p.directWeight));
-      // (with a shadow ray pending the sum is not final yet: the connect pass writes P3 of the continuing path)
-      if (!has_shadow) qst(&nxt.P3[j], mkq(sum.x, sum.y, sum.z, ub(p.flags)));
+      qst(&nxt.P2[j], mkq(p.weight.x, p.weight.y, p.weight.z, has_shadow ? out.shadow.dw_nee : p.directWeight));  // rayhit.rchit:785-787
+      qst(&nxt.P3[j], mkq(clear.x, clear.y, clear.z, ub(p.flags)));  // (clear == sum without a shadow ray)
     }
     if (has_shadow) {
       const uint32_t s = s_base[1][wave] + (uint32_t)__popcll(sm & lt_mask);
       const ShadowRay& r = out.shadow;
-      // both outcomes of the bounce, by the function k_finish and the host harness apply once the verdict is known
-      q4 clear = sum, occ = sum;
-      bool nee_done;
-      connect_vertex(rc.clamp, r, false, clear, nee_done);
-      connect_vertex(rc.clamp, r, true, occ, nee_done);
+      if (!alive) result[my_sid] = mkq(clear.x, clear.y, clear.z, 0.0f);  // the path ended here: its sample, unless occluded
       qst(&sq.S0[s], mkq(r.o.x, r.o.y, r.o.z, r.tmax));
       qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(alive ? j : 0xffffffffu)));
-      qst(&sq.S2[s], mkq(clear.x, clear.y, clear.z, r.dw_nee));
       qst(&sq.S3[s], mkq(occ.x, occ.y, occ.z, ub(alive ? out.next.flags : r.sid)));
     }
   }
@@ -713,7 +715,7 @@ struct gsp_context {
     hipStream_t stream = nullptr;
     uint64_t num_pixels = 0;
     uint64_t pool_cap = 0, result_cap = 0;
-    DevBuf<q4> P0[2], P1[2], P2[2], P3[2], hits[2], result, S0, S1, S2, S3;
+    DevBuf<q4> P0[2], P1[2], P2[2], P3[2], hits[2], result, S0, S1, S3;
     DevBuf<q4> memo;          // primary-hit memo: one hit record per owned pixel of this lane
     bool memo_valid = false;  // ... traced for the current scene / camera / frame
     DevBuf<uint32_t> counters;
@@ -1327,7 +1329,6 @@ static int ensure_pool(gsp_context* ctx, gsp_context::Lane& L, uint64_t cap, uin
   CTX_TRY(ctx, L.hits[1].ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S0.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S1.ensure(cap, &ctx->bytes));
-  CTX_TRY(ctx, L.S2.ensure(cap, &ctx->bytes));
   CTX_TRY(ctx, L.S3.ensure(cap, &ctx->bytes));
   L.pool_cap = cap;
   return GSP_OK;
@@ -1385,7 +1386,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   hipEvent_t* ev = timing ? &L.ev[4 * t] : nullptr;
   PathQueue Q[2];
   for (int k = 0; k < 2; ++k) Q[k] = PathQueue{L.P0[k].p, L.P1[k].p, L.P2[k].p, L.P3[k].p};
-  ShadowQueue SQ{L.S0.p, L.S1.p, L.S2.p, L.S3.p};
+  ShadowQueue SQ{L.S0.p, L.S1.p, L.S3.p};
   TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays, nullptr, nullptr, &ctx->dstats.p->lds_nodes};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays, &ctx->dstats.p->sh_occluded,
                             &ctx->dstats.p->sh_occluded_nodes, &ctx->dstats.p->sh_lds_nodes};
@@ -1708,15 +1709,15 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       uint64_t ring_bytes = ctx->opt.ring_bytes;  // (default 16 GiB)
       {
         // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline
-        // takes at most gsp_ctx_options.memory_share (default 40 %) of the memory that is free now (plus what the lane already holds).  224 B of queues per
-        // path of capacity (2 x 64-B path records, 2 x 16-B hit, 64-B shadow record), capacity = 2 x the pool target.
+        // takes at most gsp_ctx_options.memory_share (default 40 %) of the memory that is free now (plus what the lane already holds).  208 B of queues per
+        // path of capacity (2 x 64-B path records, 2 x 16-B hit, 48-B shadow record), capacity = 2 x the pool target.
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          const uint64_t have = L.pool_cap * 224ull + L.result_cap * sizeof(q4);
+          const uint64_t have = L.pool_cap * 208ull + L.result_cap * sizeof(q4);
           const uint64_t budget = (uint64_t)((double)free_b * ctx->memory_share) + have;
-          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 224ull;
+          const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 208ull;
           if (queues > budget / 2) {
-            const uint64_t fit = budget / 2 / 224ull;  // paths of capacity that fit
+            const uint64_t fit = budget / 2 / 208ull;  // paths of capacity that fit
             P.pool_target = std::max<uint64_t>(2 * P.batch_paths, fit > P.batch_paths ? (fit - P.batch_paths) / 2 : 0);
           }
           ring_bytes = std::min<uint64_t>(ring_bytes, std::max<uint64_t>(budget / 2, 4 * P.batch_paths * sizeof(q4)));
@@ -1882,8 +1883,8 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
   ctx->stats.bvh_depth = ctx->bvh.depth;
   ctx->stats.device_bytes = ctx->bytes;
   ctx->stats.algorithmic_bytes = 48ull * ctx->stats.stat_rays + (uint64_t)kNodeBytes * ctx->stats.nodes_visited + 48ull * ctx->stats.tris_tested +
-                                 96ull * ctx->stats.shadow_stat_rays + (uint64_t)kNodeBytes * ctx->stats.shadow_nodes_visited +
-                                 48ull * ctx->stats.shadow_tris_tested;
+                                 32ull * ctx->stats.shadow_stat_rays + 36ull * ctx->stats.shadow_stat_occluded +
+                                 (uint64_t)kNodeBytes * ctx->stats.shadow_nodes_visited + 48ull * ctx->stats.shadow_tris_tested;
   *out = ctx->stats;
   return GSP_OK;
 }

@@ -56,8 +56,11 @@ constexpr int kLdsStackDepth = GSP_LDS_LEVELS;       // LDS levels (entries) per
 #ifndef GSP_LEAF_BATCH_CLOSEST
 #define GSP_LEAF_BATCH_CLOSEST 32
 #endif
+#ifndef GSP_BATCH_COMMIT_ANY
+#define GSP_BATCH_COMMIT_ANY 32
+#endif
 #ifndef GSP_BATCH_COMMIT
-#define GSP_BATCH_COMMIT (ANY ? 32 : 24)
+#define GSP_BATCH_COMMIT (ANY ? GSP_BATCH_COMMIT_ANY : 24)
 #endif
 // triangle groups a lane may hold while it keeps taking node steps (0: it waits for the leaf step as soon as it has
 // triangles to test; 1: it descends on until a second group arrives)

@@ -272,8 +272,8 @@ typedef struct gsp_stats {
   uint64_t num_bvh_nodes;
   uint64_t device_bytes;     /* device memory currently held by the context      */
   uint64_t algorithmic_bytes; /* SURVEY 8(d) bytes of the rays the stats mode covered: per extension ray 32 (ray)
-                                 + 16 (hit) + 64 per node + 48 per triangle record read, per shadow ray 64 + 32 + the
-                                 same node / triangle terms.  What the traversal ASKS of the memory hierarchy; the
+                                 + 16 (hit) + 64 per node + 48 per triangle record read, per shadow ray 32 (+ 36 when it is
+                                 occluded: the commit) + the same node / triangle terms.  What the traversal ASKS of the memory hierarchy; the
                                  bytes that reach HBM are a quarter of it (rocprofv3 FETCH_SIZE) */
   /* (ABI 4) primary-hit memo: every sample of a pixel shoots the same camera ray (raygen.rgen:31-38, no jitter), so the
      camera rays of a frame are traced once (memo_build_rays) and later samples copy the hit.  extension_rays keeps
