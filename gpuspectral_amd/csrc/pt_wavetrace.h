@@ -331,9 +331,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
     if (node_m != 0 && !leaf_step) {
       // measured on the 1M-triangle bench scene: closest-hit 5 steps while >= 32 lanes can take one (r03: the node step
       // lost its sort network, so the bookkeeping around it weighs more: 5 steps -2 % against 3,
-      // profiles/r03_ab_trace_thresholds.txt), any-hit 4 steps while >= 24 can
+      // profiles/r03_ab_trace_thresholds.txt), any-hit 6 steps while >= 24 can (r04, re-swept after the any-hit commit became a
+      // no-op for unoccluded rays: 3 / 4 / 6 / 8 steps 45.0 / 43.7 / 42.5 / 41.2-41.3 ms ... 6 and 8 equal, profiles/r04_ab_anyhit_thresholds.txt)
 #ifndef GSP_NODE_REPS
-#define GSP_NODE_REPS (ANY ? 4 : 5)
+#define GSP_NODE_REPS (ANY ? 6 : 5)
 #endif
 #ifndef GSP_REP_LANES
 #define GSP_REP_LANES (ANY ? 24 : 32)
