@@ -1,9 +1,10 @@
 // main.cpp -- headless counterpart of the reference's S/main.cpp:15-30:
 //   Engine + PathTracer + loadScene + Window::run(frame loop)
 // becomes: load the Mitsuba XML, render N samples per pixel, write the HDR framebuffer.
-//   gsp_render [--dormant-features] <scene.xml> <out.pfm> [width height spp [devices]]
+//   gsp_render [--dormant-features] [--no-nee] [--memory-share F] [--pool-paths N] <scene.xml> <out.pfm> [width height spp [devices]]
 //   devices: "0" (default) or a list "0,1,2,3": the frame is then tiled over those GPUs (MultiGpuPathTracer); an index
-//   may repeat.  --dormant-features: LoadOptions::dormantFeatures (bitmap / checkerboard textures, envmap emitter)
+//   may repeat.  --dormant-features: LoadOptions::dormantFeatures (bitmap / checkerboard textures, envmap emitter);
+//   --no-nee: RenderParams.nee = 0; --memory-share / --pool-paths: gsp_ctx_options (how much device memory the path pool takes)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,13 +19,25 @@ using namespace GPUSpectral;
 
 int main(int argc, char** argv) {
   LoadOptions options;
-  if (argc > 1 && std::string(argv[1]) == "--dormant-features") {
-    options.dormantFeatures = true;
-    --argc;
-    ++argv;
+  gsp_ctx_options ctxOptions;
+  gsp_default_ctx_options(&ctxOptions);
+  bool nee = true;
+  while (argc > 1 && argv[1][0] == '-' && argv[1][1] == '-') {
+    const std::string flag = argv[1];
+    int used = 1;
+    if (flag == "--dormant-features") options.dormantFeatures = true;
+    else if (flag == "--no-nee") nee = false;
+    else if (flag == "--memory-share" && argc > 2) ctxOptions.memory_share = std::atof(argv[2]), used = 2;
+    else if (flag == "--pool-paths" && argc > 2) ctxOptions.pool_paths = std::strtoull(argv[2], nullptr, 10), used = 2;
+    else {
+      std::fprintf(stderr, "gsp_render: unknown option '%s'\n", argv[1]);
+      return 2;
+    }
+    argc -= used;
+    argv += used;
   }
   if (argc < 3) {
-    std::fprintf(stderr, "usage: gsp_render [--dormant-features] scene.xml out.pfm [width height spp [device | d0,d1,...]]\n");
+    std::fprintf(stderr, "usage: gsp_render [--dormant-features] [--no-nee] [--memory-share F] [--pool-paths N] scene.xml out.pfm [width height spp [device | d0,d1,...]]\n");
     return 2;
   }
   const uint32_t width = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 500;  // S/main.cpp:17: 500x500 window
@@ -64,14 +77,16 @@ int main(int argc, char** argv) {
     gsp_stats st;
     double s;
     if (devices.size() == 1) {
-      PathTracer pt(width, height, devices[0]);
+      PathTracer pt(width, height, devices[0], {}, &ctxOptions);
+      pt.params.nee = nee ? 1u : 0u;
       auto t0 = std::chrono::steady_clock::now();
       pt.render(scene, spp);
       img = pt.download();
       s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       st = pt.stats();
     } else {
-      MultiGpuPathTracer pt(width, height, devices);
+      MultiGpuPathTracer pt(width, height, devices, &ctxOptions);
+      pt.params.nee = nee ? 1u : 0u;
       auto t0 = std::chrono::steady_clock::now();
       pt.render(scene, spp);
       img = pt.download();

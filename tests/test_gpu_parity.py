@@ -672,6 +672,34 @@ def test_cpp_cli_renders_the_reference_scene(tmp_path):
     assert np.array_equal(img.reshape(-1, 3), ref.reshape(-1, ref.shape[-1])[:, :3])
 
 
+def test_cpp_cli_options(tmp_path, oracle_mod, cornell):
+    """`gsp_render --no-nee --memory-share F --pool-paths N`: the C++ host passes gsp_ctx_options and RenderParams.nee through
+    (r04); the frame equals the oracle's nee = 0 frame whatever the pool size; an unknown option is a usage error."""
+    import os
+    import subprocess
+
+    from conftest import CORNELL_XML, ROOT
+    from gpuspectral_amd import abi
+
+    lib = os.path.join(ROOT, "gpuspectral_amd", "lib")
+    out = str(tmp_path / "cornell_nonee.pfm")
+    env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([os.path.join(lib, "gsp_render"), "--no-nee", "--memory-share", "0.05", "--pool-paths", "100000", CORNELL_XML, out,
+                        "96", "64", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    with open(out, "rb") as f:
+        assert f.readline() == b"PF\n"
+        w, h = map(int, f.readline().split())
+        f.readline()
+        img = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
+    p = abi.default_render_params()
+    p.nee = 0
+    ref, _ = oracle_mod.Oracle(cornell).render(96, 64, spp=3, params=p)
+    assert np.array_equal(img.reshape(-1, 3), ref[:, :3])
+    r = subprocess.run([os.path.join(lib, "gsp_render"), "--frobnicate", CORNELL_XML, out], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown option" in r.stderr
+
+
 def test_random_scene_fuzz_matches_oracle(ctx, oracle_mod):
     """tests/tools/fuzz_parity.py: random small scenes with all eight BSDF types at ordinary and extreme parameters,
     mirrored / non-uniformly scaled instances, several lights, random cameras: frames (NaN pixels included) and
