@@ -657,6 +657,7 @@ struct gsp_context {
   DevBuf<float> d_invt, d_pos, d_nrm, d_uv;
   DevBuf<uint32_t> d_first;
   std::vector<gsp_instance> h_inst;
+  std::vector<uint8_t> h_tables;  // host copy of the table image (counts + tables): gsp_update_tables compares before it drains
   uint32_t num_bsdfs[GSP_BSDF_TYPE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t num_vertices = 0, total_tris = 0;
   gsp_ctx_options opt{};  // resolved at creation (gsp_internal_resolve_options)
@@ -1012,29 +1013,45 @@ static int check_texture_words(gsp_context* ctx, const gsp_scene_desc* sc, uint3
   return GSP_OK;
 }
 
-// the eight BSDF arrays + the lights of `sc` into the context's table allocation (queued on the context's stream)
-static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
+// The eight BSDF arrays + the lights of `sc`, packed back to back (16-B aligned each) as they sit in the context's one table
+// allocation; the counts ride in front of the image so that "equal images" means equal tables.
+struct TableImage {
+  std::vector<uint8_t> bytes;  // [9 x uint64 count][tables ...]: the device holds bytes.data() + kHead onwards
+  size_t off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, total = 0;
+  static constexpr size_t kHead = 9 * sizeof(uint64_t);
+};
+static int pack_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& img) {
   const void* src[9] = {sc->diffuse_bsdfs, sc->smooth_dielectric_bsdfs, sc->smooth_conductor_bsdfs, sc->smooth_plastic_bsdfs,
                         sc->rough_conductor_bsdfs, sc->smooth_floor_bsdfs, sc->rough_floor_bsdfs, sc->rough_plastic_bsdfs, sc->lights};
   const size_t rec[9] = {sizeof(gsp_diffuse_bsdf), sizeof(gsp_smooth_dielectric_bsdf), sizeof(gsp_smooth_conductor_bsdf),
                          sizeof(gsp_smooth_plastic_bsdf), sizeof(gsp_rough_conductor_bsdf), sizeof(gsp_smooth_floor_bsdf),
                          sizeof(gsp_rough_floor_bsdf), sizeof(gsp_rough_plastic_bsdf), sizeof(gsp_triangle_light)};
-  size_t bytes[9], off[9], total = 0;
+  size_t bytes[9];
+  uint64_t counts[9];
+  img.total = 0;
   for (int k = 0; k < 9; ++k) {
-    bytes[k] = rec[k] * (k < 8 ? sc->num_bsdfs[k] : sc->num_lights);
+    counts[k] = k < 8 ? sc->num_bsdfs[k] : sc->num_lights;
+    bytes[k] = rec[k] * counts[k];
     if (bytes[k] && !src[k]) {
       ctx->err = "null array with non-zero count";
       return GSP_ERR_SCENE;
     }
-    off[k] = total;
-    total += (bytes[k] + 15) & ~(size_t)15;
+    img.off[k] = img.total;
+    img.total += (bytes[k] + 15) & ~(size_t)15;
   }
-  CTX_TRY(ctx, ctx->tables.ensure(std::max<size_t>(total, 16), &ctx->bytes));
-  for (int k = 0; k < 9; ++k) {
-    ctx->table_off[k] = off[k];
-    if (bytes[k]) CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p + off[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream));
-  }
-  ctx->tables_bytes = total;
+  img.bytes.assign(TableImage::kHead + std::max<size_t>(img.total, 16), 0);
+  std::memcpy(img.bytes.data(), counts, sizeof(counts));
+  for (int k = 0; k < 9; ++k)
+    if (bytes[k]) std::memcpy(img.bytes.data() + TableImage::kHead + img.off[k], src[k], bytes[k]);
+  return GSP_OK;
+}
+// image -> device (queued on the context's stream; the image becomes the context's host copy, so the source stays alive)
+static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& img) {
+  CTX_TRY(ctx, ctx->tables.ensure(std::max<size_t>(img.total, 16), &ctx->bytes));
+  ctx->h_tables.swap(img.bytes);
+  CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->h_tables.data() + TableImage::kHead, std::max<size_t>(img.total, 16), hipMemcpyHostToDevice, ctx->stream));
+  for (int k = 0; k < 9; ++k) ctx->table_off[k] = img.off[k];
+  ctx->tables_bytes = img.total;
   ctx->num_lights = sc->num_lights;
   for (int k = 0; k < GSP_BSDF_TYPE_COUNT; ++k) ctx->num_bsdfs[k] = sc->num_bsdfs[k];
   return GSP_OK;
@@ -1075,7 +1092,10 @@ static int bake_and_build(gsp_context* ctx) {
   ctx->node_hist.release();
   ctx->tri_hist.release();
   int rc = build_bvh(st, bi, ctx->bvh, ctx->err);  // (synchronises the stream: inv_t / tri_first may go out of scope)
-  if (rc != GSP_OK) return rc;
+  if (rc != GSP_OK) {
+    (void)hipStreamSynchronize(st);  // ... also on a failed build: the uploads above read host vectors of this frame
+    return rc;
+  }
   ctx->bytes += ctx->bvh.bytes;
   if (ctx->num_textures) {  // the collapse defines the slot order: the per-slot uv follow it
     CTX_TRY(ctx, ctx->tri_uv.ensure(8ull * (ctx->total_tris + ctx->bvh.first_slot + kWide), &ctx->bytes));
@@ -1141,7 +1161,9 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   auto t0 = std::chrono::steady_clock::now();
   hipStream_t st = ctx->stream;
   {
-    int rc_ = upload_tables(ctx, sc);
+    TableImage img;
+    int rc_ = pack_tables(ctx, sc, img);
+    if (rc_ == GSP_OK) rc_ = upload_tables(ctx, sc, img);
     if (rc_ != GSP_OK) return rc_;
   }
   ctx->camera = sc->camera;
@@ -1178,14 +1200,15 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   return GSP_OK;
 }
 
-// common head of the gsp_update_* calls: the samples already queued belong to the scene as it was
+// common head of the gsp_update_* calls.  (The drain -- the samples already queued belong to the scene as it was -- comes only
+// once the call has found something to change: a host that mirrors the reference calls all three every frame.)
 static int begin_update(gsp_context* ctx, const char* what) {
   CTX_TRY(ctx, hipSetDevice(ctx->device));
   if (!ctx->have_scene) {
     ctx->err = std::string(what) + " needs gsp_upload_scene first";
     return GSP_ERR_INVALID;
   }
-  return pipeline_drain(ctx);
+  return GSP_OK;
 }
 
 // No drain: a path in flight left the camera behind when its primary ray was generated (k_generate / the memo are the only
@@ -1225,6 +1248,8 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   rc = check_instances(ctx, instances, num_instances, ctx->num_bsdfs, ctx->num_vertices, nullptr);
   if (rc != GSP_OK) return rc;
   if (num_instances == 0 || std::memcmp(ctx->h_inst.data(), instances, num_instances * sizeof(gsp_instance)) == 0) return GSP_OK;
+  rc = pipeline_drain(ctx);
+  if (rc != GSP_OK) return rc;
   auto t0 = std::chrono::steady_clock::now();
   ctx->have_scene = false;  // (a failed rebuild leaves no half-built tree in use)
   for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
@@ -1252,12 +1277,18 @@ int gsp_update_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
   }
   rc = check_texture_words(ctx, sc, ctx->num_textures);
   if (rc != GSP_OK) return rc;
-  rc = upload_tables(ctx, sc);  // (k_shade stages the tables per launch: nothing else holds a copy)
+  TableImage img;
+  rc = pack_tables(ctx, sc, img);
+  if (rc != GSP_OK) return rc;
+  if (img.bytes == ctx->h_tables) return GSP_OK;  // same counts, same bytes: nothing to do, nothing to wait for
+  rc = pipeline_drain(ctx);
+  if (rc != GSP_OK) return rc;
+  rc = upload_tables(ctx, sc, img);  // (k_shade stages the tables per launch: nothing else holds a copy)
   if (rc != GSP_OK) {
     ctx->have_scene = false;
     return rc;
   }
-  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays are free again
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ++ctx->stats.scene_updates;
   return GSP_OK;
 }

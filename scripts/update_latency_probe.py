@@ -38,6 +38,9 @@ with g.Context(0) as ctx:
         st = ctx.stats()
         print("== %s: upload + build %.1f ms" % (name, st["bvh_build_ms"]))
         print("   no edits                  : %7.1f frames/s" % loop(ctx, sc, 300, lambda f: None))
+        def noop(f):
+            ctx.update_tables(sc); ctx.update_instances(sc.instances); ctx.update_camera(sc.to_world, sc.fov)
+        print("   all three calls, no change: %7.1f frames/s (what a host that re-reads everything per frame pays)" % loop(ctx, sc, 300, noop))
         print("   camera moves every frame  : %7.1f frames/s" % loop(ctx, sc, 300, lambda f: ctx.update_camera(moved(sc.to_world, f), sc.fov)))
         def tables(f):
             b = [x.copy() for x in sc.bsdfs]

@@ -161,6 +161,12 @@ def test_c_abi_updates_equal_a_fresh_upload(oracle_mod):
         ctx.render(spp=SPP)
         upd = ctx.download().copy()
         assert not np.array_equal(upd, before)
+        # calls that change nothing do nothing (a host that mirrors the reference makes all three every frame)
+        n0 = ctx.stats()["scene_updates"]
+        ctx.update_tables(sc)
+        ctx.update_instances(sc.instances)
+        ctx.update_camera(sc.to_world, sc.fov)
+        assert ctx.stats()["scene_updates"] == n0
         # pipelined: an update between two gsp_render calls without a sync in between drains the old samples first
         ctx.frame_begin(W, H)
         ctx.render(spp=2)
