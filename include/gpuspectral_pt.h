@@ -352,10 +352,12 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
  * a host that mirrors it calls these between gsp_render calls instead of uploading the whole scene again.  The samples
  * already queued belong to the scene as it was and finish as such; accumulate buffer and timestamps are left alone -- like the
  * reference, where an edit simply shows up in the next frame's sample; call gsp_frame_begin to restart the running mean -- and
- * the primary-hit memo is invalidated.  All need a prior gsp_upload_scene.
+ * the primary-hit memo is invalidated.  All need a prior gsp_upload_scene.  Every call COMPARES first and returns at once,
+ * before any wait, when its input equals what the device holds: a host that mirrors the reference makes all three every frame.
  *   gsp_update_camera     new camera; no geometry work and NO WAIT: paths in flight have left the camera behind (only ray
  *                         generation reads it), so a viewer that moves its camera every frame keeps the path pool full.
- *                         The two calls below first complete the samples already queued (those read the tables / the BVH).
+ *                         The two calls below, when they have something to change, first complete the samples already
+ *                         queued (those read the tables / the BVH).
  *   gsp_update_instances  new transform / emission / bsdf / twofaced per instance.  `num_instances` and every
  *                         first_vertex / vertex_count must equal the uploaded ones (the meshes stay: they are resident on
  *                         the device); BSDF handles are checked against the resident tables.  Re-bakes the world-space
