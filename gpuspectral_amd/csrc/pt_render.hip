@@ -1734,9 +1734,15 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       while (Kb > 1 && Kb * npix >= (1ull << 30)) --Kb;
       P.Kb = Kb;
       P.batch_paths = Kb * npix;
-      // (at most 192 samples per pixel in flight: tiny frames do not allocate gigabytes; a 1/8 tile share of a
-      // 1080p frame, 259 k pixels, still fills the whole pool)
-      P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, 192 * npix), 2 * P.batch_paths);
+      // (at most 192 samples per pixel in flight for a whole frame: tiny frames do not allocate gigabytes and gsp_peek does not
+      // lag far behind; 384 for a pixel SUBSET -- a tile share of a multi-GPU frame: the 1/8 share of a 1080p frame, 259 k
+      // pixels, must still fill the 96 Mi-path pool, else every GPU of an 8-GPU job runs launches half the size of the
+      // single-GPU run's, profiles/r04_share_probe.txt)
+#ifndef GSP_SHARE_SPP
+#define GSP_SHARE_SPP 384
+#endif
+      const uint64_t per_pixel = ctx->subset ? GSP_SHARE_SPP : 192;
+      P.pool_target = std::max<uint64_t>(std::min<uint64_t>(total_target / ctx->num_lanes, per_pixel * npix), 2 * P.batch_paths);
       uint64_t ring_bytes = ctx->opt.ring_bytes;  // (default 16 GiB)
       {
         // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline

@@ -46,6 +46,24 @@ def test_loaded_library_was_built_from_this_tree():
     assert "-ffp-contract=off" in info["flags"].split()
 
 
+def test_valu_mix_record_belongs_to_the_loaded_library():
+    """csrc/Makefile writes lib/valu_mix.json (static VALU class mix of the three render kernels, scripts/valu_mix.py) next to
+    the library with the library's source digest; bench.py turns it into the class-weighted issue ceiling of `roofline` and
+    ignores a record of another build."""
+    import json
+
+    from gpuspectral_amd import pt
+
+    if os.environ.get("GSP_LIB_PATH"):
+        pytest.skip("GSP_LIB_PATH points at a build variant")
+    rec = json.load(open(os.path.join(os.path.dirname(pt.lib_path()), "valu_mix.json")))
+    assert rec["library_digest"] == pt.build_info()["digest"]
+    for k in ("k_trace_extend", "k_trace_connect", "k_shade"):
+        m = rec["kernels"][k]
+        assert m["full"] + m["half"] + m["quarter"] == m["valu_instructions_static"] > 300
+        assert 2.0 < m["mean_issue_cycles"] < 4.0
+
+
 def test_struct_layouts_match_header(tmp_path):
     """sizeof/offsetof from the C header (gcc) == the ctypes/numpy mirrors."""
     from gpuspectral_amd import abi
