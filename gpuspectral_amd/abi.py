@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-GSP_ABI_VERSION = 5
+GSP_ABI_VERSION = 6
 
 BSDF_DIFFUSE = 0
 BSDF_SMOOTH_DIELECTRIC = 1
@@ -150,7 +150,7 @@ GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2
 
 
 class CtxOptions(C.Structure):
-    """gsp_ctx_options (ABI 5); a field left 0 means "default"."""
+    """gsp_ctx_options (ABI 5, refit_growth: 6); a field left 0 means "default"."""
 
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -162,6 +162,7 @@ class CtxOptions(C.Structure):
         ("finish_paths", C.c_uint32),
         ("reinsert_rounds", C.c_uint32),
         ("gather_route", C.c_uint32),
+        ("refit_growth", C.c_double),  # (ABI 6) 0 default (1.25); <= 1: gsp_update_instances always rebuilds
     ]
 
     def __init__(self, **kw):
@@ -226,6 +227,7 @@ class Stats(C.Structure):
         ("shadow_stat_occluded", C.c_uint64),
         ("shadow_stat_occluded_nodes", C.c_uint64),
         ("scene_updates", C.c_uint64),
+        ("scene_refits", C.c_uint64),  # (ABI 6)
     ]
 
     def as_dict(self):

@@ -26,6 +26,9 @@
 //             PLOC trees, 15.1 vs 14.7 nodes per extension ray, profiles/r03_collapse.txt, and is in the history);
 //             inner children of a node = consecutive nodes, leaf children = consecutive triangle slots: the collapse
 //             defines the final triangle order
+//   refit     (refit_bvh, gsp_update_instances) the reference rebuilds only its TLAS when an object moves
+//             (PathTracer.cpp:10-19); the flattened tree's counterpart: re-bake every packet into its slot, recompute all
+//             node boxes + child orders bottom-up in the existing topology, one launch per level
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +37,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "pt_internal.h"
@@ -86,12 +90,17 @@ __device__ __forceinline__ q4 mkq(float x, float y, float z, float w) {
 }
 
 // scene_bounds[0..2] = ordered min, [3..5] = ordered max
+// remap == nullptr (build): thread t bakes global triangle t into record t.  Refit: thread t bakes global triangle
+// remap[out_first + t] into record out_first + t -- the triangle slot it already has in the tree.
 __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__ isect, q4* __restrict__ shade,
                                                   q4* __restrict__ box_lo, q4* __restrict__ box_hi,
-                                                  uint32_t* __restrict__ scene_bounds) {
-  const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+                                                  uint32_t* __restrict__ scene_bounds, const uint32_t* __restrict__ remap,
+                                                  uint32_t out_first) {
+  const uint32_t t_ = blockIdx.x * kBlock + threadIdx.x;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  if (g < in.num_tris) {
+  if (t_ < in.num_tris) {
+    const uint32_t g = remap ? remap[out_first + t_] : t_;
+    const uint32_t o_ = remap ? out_first + t_ : t_;
     // instance that owns global triangle g: last i with tri_first[i] <= g
     uint32_t a = 0, b = in.num_instances;
     while (b - a > 1) {
@@ -112,13 +121,13 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     const f3 e1 = p1 - p0, e2 = p2 - p0;
     const f3 N = normalize(cross(e1, e2));  // rayhit.rchit:694
     // p0.w: tie-break key of the closest-hit rule (orders like g) + the BSDF type of the hit for the shade sort
-    isect[3ull * g + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float((g << 3) | ((I.bsdf >> 16) & 7u)));
-    isect[3ull * g + 1] = mkq(p1.x, p1.y, p1.z, 0.0f);
-    isect[3ull * g + 2] = mkq(p2.x, p2.y, p2.z, 0.0f);
-    shade[4ull * g + 0] = mkq(N.x, N.y, N.z, __uint_as_float(pack_material(I.bsdf, I.twofaced)));
-    shade[4ull * g + 1] = mkq(n0.x, n0.y, n0.z, I.emission[0]);
-    shade[4ull * g + 2] = mkq(n1.x, n1.y, n1.z, I.emission[1]);
-    shade[4ull * g + 3] = mkq(n2.x, n2.y, n2.z, I.emission[2]);
+    isect[3ull * o_ + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float((g << 3) | ((I.bsdf >> 16) & 7u)));
+    isect[3ull * o_ + 1] = mkq(p1.x, p1.y, p1.z, 0.0f);
+    isect[3ull * o_ + 2] = mkq(p2.x, p2.y, p2.z, 0.0f);
+    shade[4ull * o_ + 0] = mkq(N.x, N.y, N.z, __uint_as_float(pack_material(I.bsdf, I.twofaced)));
+    shade[4ull * o_ + 1] = mkq(n0.x, n0.y, n0.z, I.emission[0]);
+    shade[4ull * o_ + 2] = mkq(n1.x, n1.y, n1.z, I.emission[1]);
+    shade[4ull * o_ + 3] = mkq(n2.x, n2.y, n2.z, I.emission[2]);
     const float px[3] = {p0.x, p0.y, p0.z}, qx[3] = {p1.x, p1.y, p1.z}, rx[3] = {p2.x, p2.y, p2.z};
     float l[3], h[3];
 #pragma unroll
@@ -148,8 +157,8 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
       lo[k] = l[k] - pad;
       hi[k] = h[k] + pad;
     }
-    box_lo[g] = mkq(lo[0], lo[1], lo[2], 0.0f);
-    box_hi[g] = mkq(hi[0], hi[1], hi[2], 0.0f);
+    box_lo[o_] = mkq(lo[0], lo[1], lo[2], 0.0f);
+    box_hi[o_] = mkq(hi[0], hi[1], hi[2], 0.0f);
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -681,6 +690,76 @@ __global__ __launch_bounds__(kBlock) void k_permute_tris(uint32_t n, const uint3
   s2g[s] = s2g_in[m];
 }
 
+// ---- refit --------------------------------------------------------------------------------------------------------
+// what a node record says about its children (pt_trace.h): ni inner ones at nodes child_base + k, then nl leaf ones at
+// triangle slots tri_base + j; an unused position carries the inverted box (qlo 255, qhi 0)
+__device__ __forceinline__ void node_children(const q4* n, int& ni, int& nl, uint32_t& child_base, uint32_t& tri_base) {
+  ni = __popc(__float_as_uint(n[3].x) >> 28);
+  child_base = __float_as_uint(n[2].z);
+  tri_base = __float_as_uint(n[2].w) + (uint32_t)ni;
+  const uint32_t qlx = __float_as_uint(n[1].x), qhx = __float_as_uint(n[1].w);
+  nl = 0;
+  for (int p = ni; p < kWide; ++p)
+    if (!(((qlx >> (8 * p)) & 255u) == 255u && ((qhx >> (8 * p)) & 255u) == 0u)) ++nl;
+}
+
+// One level of the wide tree, deepest level first: a node's child boxes are the node boxes of the level below (box_lo /
+// box_hi, written by the previous launch) and the padded boxes of its triangles (leaf_lo / leaf_hi by slot, k_bake); the record
+// is encoded again in place -- origin, scales, quantised planes, the per-octant child orders -- with the same children in
+// the same positions.
+__global__ __launch_bounds__(kBlock) void k_refit_level(uint32_t first, uint32_t count, q4* __restrict__ nodes,
+                                                        const q4* __restrict__ leaf_lo, const q4* __restrict__ leaf_hi,
+                                                        q4* __restrict__ box_lo, q4* __restrict__ box_hi) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t node = first + t;
+  q4* rec = nodes + (size_t)kNodeQuads * node;
+  const q4 n[4] = {rec[0], rec[1], rec[2], rec[3]};
+  int ni, nl;
+  uint32_t child_base, tri_base;
+  node_children(n, ni, nl, child_base, tri_base);
+  WideChild wc[kWide];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = 0; k < ni + nl; ++k) {
+    if (k < ni) {
+      wc[k].lo = box_lo[child_base + (uint32_t)k];
+      wc[k].hi = box_hi[child_base + (uint32_t)k];
+    } else {
+      wc[k].lo = leaf_lo[tri_base + (uint32_t)(k - ni)];
+      wc[k].hi = leaf_hi[tri_base + (uint32_t)(k - ni)];
+    }
+    lo[0] = fminf(lo[0], wc[k].lo.x), lo[1] = fminf(lo[1], wc[k].lo.y), lo[2] = fminf(lo[2], wc[k].lo.z);
+    hi[0] = fmaxf(hi[0], wc[k].hi.x), hi[1] = fmaxf(hi[1], wc[k].hi.y), hi[2] = fmaxf(hi[2], wc[k].hi.z);
+  }
+  encode_node_w4(rec, wc, ni, nl, child_base, tri_base);
+  box_lo[node] = mkq(lo[0], lo[1], lo[2], 0.0f);
+  box_hi[node] = mkq(hi[0], hi[1], hi[2], 0.0f);
+}
+
+// The tree's quality as the traversal sees it: half the surface area of every child box, decoded from the quantised planes.
+// A ray's chance of entering a box grows with that area, so the sum over the tree tracks the node visits per ray.
+__global__ __launch_bounds__(kBlock) void k_wide_area(uint32_t num_nodes, const q4* __restrict__ nodes, double* __restrict__ area) {
+  const uint32_t node = blockIdx.x * kBlock + threadIdx.x;
+  if (node >= num_nodes) return;
+  const q4* n = nodes + (size_t)kNodeQuads * node;
+  const q4 a = n[0], b = n[1], c = n[2], d = n[3];
+  const float sc[3] = {a.w, d.z, d.w};
+  const uint32_t ql[3] = {__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z)};
+  const uint32_t qh[3] = {__float_as_uint(b.w), __float_as_uint(c.x), __float_as_uint(c.y)};
+  double sum = 0.0;
+  for (int p = 0; p < kWide; ++p) {
+    float e[3];
+    bool used = true;
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t l = (ql[k] >> (8 * p)) & 255u, h = (qh[k] >> (8 * p)) & 255u;
+      if (l > h) used = false;
+      e[k] = (float)(h - l) * sc[k];
+    }
+    if (used) sum += ((double)e[0] * e[1] + (double)e[1] * e[2]) + (double)e[2] * e[0];
+  }
+  area[node] = sum;
+}
+
 struct Scratch {
   std::vector<void*> ptrs;
   size_t bytes = 0;
@@ -708,6 +787,14 @@ void free_bvh(DeviceBvh& b) {
   (void)hipFree(b.tri_isect);
   (void)hipFree(b.tri_shade);
   (void)hipFree(b.slot_to_global);
+  (void)hipFree(b.rf_leaf_lo);
+  (void)hipFree(b.rf_leaf_hi);
+  (void)hipFree(b.rf_box_lo);
+  (void)hipFree(b.rf_box_hi);
+  (void)hipFree(b.rf_area);
+  (void)hipFree(b.rf_total);
+  (void)hipFree(b.rf_tmp);
+  (void)hipFree(b.rf_bounds);
   b = DeviceBvh{};
 }
 
@@ -741,6 +828,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     GSP_HIP_TRY(hipMemcpyAsync(out.nodes, node, kNodeBytes, hipMemcpyHostToDevice, stream));
     out.bytes += kNodeBytes;
     out.num_nodes = 1;
+    out.level_first = {0u, 1u};
     GSP_HIP_TRY(hipStreamSynchronize(stream));
     return GSP_OK;
   }
@@ -779,7 +867,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
   GSP_HIP_TRY(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * n, stream));
 
-  hipLaunchKernelGGL(k_bake, dim3(blocks_for(n)), dim3(kBlock), 0, stream, in, isect_g, shade_g, lo_g, hi_g, bounds);
+  hipLaunchKernelGGL(k_bake, dim3(blocks_for(n)), dim3(kBlock), 0, stream, in, isect_g, shade_g, lo_g, hi_g, bounds, (const uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_morton, dim3(blocks_for(n)), dim3(kBlock), 0, stream, n, lo_g, hi_g, bounds, keys_in, vals_in);
   GSP_HIP_TRY(hipGetLastError());
 
@@ -809,6 +897,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     GSP_HIP_TRY(hipMemcpyAsync(out.slot_to_global + kFirstSlot, s2g_m, 4, hipMemcpyDeviceToDevice, stream));
     out.bytes += kNodeBytes;
     out.num_nodes = 1;
+    out.level_first = {0u, 1u};
     GSP_HIP_TRY(hipStreamSynchronize(stream));
     return GSP_OK;
   }
@@ -904,10 +993,12 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(S.alloc((char**)&scan_tmp, scan_bytes));
   GSP_HIP_TRY(hipMemcpyAsync(items_a, &root2, sizeof(int32_t), hipMemcpyHostToDevice, stream));
   uint32_t count = 1, node_first = 0, tri_done = kFirstSlot, levels = 0;
+  out.level_first.clear();
   // 4-wide default: the parity collapse (children = grandchildren).  On PLOC trees it beats the greedy surface-area
   // collapse -- bench scene 14.7 vs 15.1 nodes per extension ray, 7.5 vs 9.2 per shadow ray (profiles/r03_collapse.txt;
   // the CPU probe agrees: 10.2 vs 10.4, 7.7 vs 8.3) -- while on top-down SAH trees it is the other way round.
   while (count > 0) {
+    out.level_first.push_back(node_first);
     hipLaunchKernelGGL(k_wide_count, dim3(blocks_for(count + 1ull)), dim3(kBlock), 0, stream, (int)count, items_a, nodes2, n_inner, n_leaf);
     GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, n_inner, inner_off, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
     GSP_HIP_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, n_leaf, leaf_off, 0u, (size_t)count + 1, rocprim::plus<uint32_t>(), stream));
@@ -940,6 +1031,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
     return GSP_ERR_DEVICE;
   }
   const uint32_t num_nodes = node_first;
+  out.level_first.push_back(num_nodes);
   if (num_nodes >= kMaxNodes) {
     err = "scene too large: more BVH nodes than the traversal's node index holds (internal error: gsp_upload_scene bounds the triangle count)";
     return GSP_ERR_INVALID;
@@ -954,6 +1046,72 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   GSP_HIP_TRY(hipGetLastError());
   GSP_HIP_TRY(hipStreamSynchronize(stream));
   out.depth = levels;  // levels of the wide tree: a traversal stacks at most one node group per level
+  return GSP_OK;
+}
+
+namespace {
+int tree_area(hipStream_t stream, const DeviceBvh& bvh, double* sum, std::string& err) {
+  hipLaunchKernelGGL(k_wide_area, dim3(blocks_for(bvh.num_nodes)), dim3(kBlock), 0, stream, bvh.num_nodes, bvh.nodes, bvh.rf_area);
+  GSP_HIP_TRY(hipGetLastError());
+  size_t tb = bvh.rf_tmp_bytes;  // (no atomics: the same sum every run)
+  GSP_HIP_TRY(rocprim::reduce(bvh.rf_tmp, tb, bvh.rf_area, bvh.rf_total, 0.0, (size_t)bvh.num_nodes, rocprim::plus<double>(), stream));
+  GSP_HIP_TRY(hipMemcpyAsync(sum, bvh.rf_total, sizeof(double), hipMemcpyDeviceToHost, stream));
+  GSP_HIP_TRY(hipStreamSynchronize(stream));
+  return GSP_OK;
+}
+}  // namespace
+
+int refit_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& bvh, double* growth, std::string& err) {
+  *growth = 1.0;
+  const uint32_t n = bvh.num_tris;
+  if (in.num_tris != n || bvh.level_first.size() < 2 || bvh.level_first.back() != bvh.num_nodes || !bvh.nodes) {
+    err = "refit_bvh: the tree does not belong to this triangle list (internal error)";
+    return GSP_ERR_DEVICE;
+  }
+  if (n == 0) return GSP_OK;
+  const uint32_t slots = n + kFirstSlot + (kWide - 1);
+  if (!bvh.rf_bounds) {  // first refit of this tree (or an earlier one ran out of memory half-way: start over)
+    for (void** q : {(void**)&bvh.rf_leaf_lo, (void**)&bvh.rf_leaf_hi, (void**)&bvh.rf_box_lo, (void**)&bvh.rf_box_hi, (void**)&bvh.rf_area,
+                     (void**)&bvh.rf_total, &bvh.rf_tmp}) {
+      (void)hipFree(*q);
+      *q = nullptr;
+    }
+    size_t tb = 0;
+    GSP_HIP_TRY(rocprim::reduce(nullptr, tb, bvh.rf_area, bvh.rf_total, 0.0, (size_t)bvh.num_nodes, rocprim::plus<double>(), stream));
+    tb = std::max<size_t>(tb, 16);
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_leaf_lo, sizeof(q4) * slots));
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_leaf_hi, sizeof(q4) * slots));
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_box_lo, sizeof(q4) * bvh.num_nodes));
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_box_hi, sizeof(q4) * bvh.num_nodes));
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_area, sizeof(double) * bvh.num_nodes));
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_total, sizeof(double)));
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_tmp, tb));
+    bvh.rf_tmp_bytes = tb;
+    GSP_HIP_TRY(hipMalloc((void**)&bvh.rf_bounds, 8 * sizeof(uint32_t)));  // (last: marks the set complete)
+    bvh.bytes += 2 * sizeof(q4) * ((size_t)slots + bvh.num_nodes) + sizeof(double) * (bvh.num_nodes + 1ull) + tb + 32;
+  }
+  int rc;
+  if (bvh.area_built <= 0.0) {  // the tree is as built: its own measure first
+    rc = tree_area(stream, bvh, &bvh.area_built, err);
+    if (rc != GSP_OK) return rc;
+  }
+  const uint32_t init_bounds[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+  GSP_HIP_TRY(hipMemcpyAsync(bvh.rf_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_bake, dim3(blocks_for(n)), dim3(kBlock), 0, stream, in, bvh.tri_isect, bvh.tri_shade, bvh.rf_leaf_lo, bvh.rf_leaf_hi,
+                     bvh.rf_bounds, (const uint32_t*)bvh.slot_to_global, kFirstSlot);
+  GSP_HIP_TRY(hipGetLastError());
+  for (size_t l = bvh.level_first.size() - 1; l-- > 0;) {
+    const uint32_t first = bvh.level_first[l], count = bvh.level_first[l + 1] - first;
+    if (count == 0) continue;
+    hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(count)), dim3(kBlock), 0, stream, first, count, bvh.nodes, bvh.rf_leaf_lo, bvh.rf_leaf_hi,
+                       bvh.rf_box_lo, bvh.rf_box_hi);
+  }
+  GSP_HIP_TRY(hipGetLastError());
+  double now = 0.0;
+  rc = tree_area(stream, bvh, &now, err);  // (synchronises: the caller's instance tables may go out of scope)
+  if (rc != GSP_OK) return rc;
+  ++bvh.refits;
+  *growth = bvh.area_built > 0.0 ? now / bvh.area_built : (now > 0.0 ? 1.0e30 : 1.0);
   return GSP_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/gpuspectral_pt.h"
 #include "pt_stages.h"
@@ -31,6 +32,18 @@ struct DeviceBvh {
   uint32_t num_nodes = 0;
   uint32_t depth = 0;      // levels of the wide tree (bounds the traversal stack: <= 1 node group per level)
   size_t bytes = 0;
+  // refit (refit_bvh): the tree is stored level by level -- level l = nodes [level_first[l], level_first[l + 1]) -- so the
+  // boxes can be recomputed bottom-up, one launch per level, without parent links
+  std::vector<uint32_t> level_first;
+  double area_built = 0.0;  // sum of the child-box surface areas right after the last full build (0 = not measured yet)
+  uint32_t refits = 0;      // refits since that build
+  // scratch of refit_bvh, allocated by the first refit of a tree and kept with it (a per-frame call: seven hipMalloc / hipFree
+  // pairs cost more than the kernels): padded triangle boxes by slot, node boxes, per-node areas, reduction space
+  q4 *rf_leaf_lo = nullptr, *rf_leaf_hi = nullptr, *rf_box_lo = nullptr, *rf_box_hi = nullptr;
+  double *rf_area = nullptr, *rf_total = nullptr;
+  void* rf_tmp = nullptr;
+  size_t rf_tmp_bytes = 0;
+  uint32_t* rf_bounds = nullptr;
 };
 
 struct BuildInput {
@@ -54,6 +67,11 @@ __attribute__((visibility("hidden"))) void gsp_internal_resolve_options(const gs
 // Bakes the instances' triangles to world space and builds the wide BVH (PLOC + reinsertion + collapse) on `stream`.
 // Returns GSP_OK or an error code with `err` set.
 int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::string& err);
+// The instances of `in` have changed (transforms, materials, emission) but not the triangle list: re-bakes every triangle
+// packet into its slot and recomputes all node boxes, child orders included, bottom-up in the existing topology.  Results of a
+// trace do not depend on the topology (closest-hit rule, pt_trace.h), its speed does: *growth = summed child-box area after /
+// right after the last full build; the caller rebuilds when that exceeds its bound.  Synchronises the stream.
+int refit_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& bvh, double* growth, std::string& err);
 void free_bvh(DeviceBvh& b);
 
 }  // namespace gsp

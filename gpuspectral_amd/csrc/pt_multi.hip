@@ -550,6 +550,7 @@ int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
       t.memo_build_rays += s.memo_build_rays;
       t.bvh_depth = std::max(t.bvh_depth, s.bvh_depth);
       t.scene_updates = std::max(t.scene_updates, s.scene_updates);
+      t.scene_refits = std::max(t.scene_refits, s.scene_refits);
       t.extend_launches += s.extend_launches;
       t.device_bytes += s.device_bytes;
       t.render_seconds = std::max(t.render_seconds, s.render_seconds);

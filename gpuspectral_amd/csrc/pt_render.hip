@@ -875,6 +875,7 @@ void gsp_default_ctx_options(gsp_ctx_options* o) {
   o->finish_paths = kFinishPaths;
   o->reinsert_rounds = 7;        // 6 rounds
   o->gather_route = GSP_GATHER_AUTO;
+  o->refit_growth = 1.25;
 }
 
 }  // extern "C"
@@ -895,6 +896,7 @@ void gsp::gsp_internal_resolve_options(const gsp_ctx_options* in, gsp_ctx_option
   if (c.finish_paths) out->finish_paths = c.finish_paths;
   if (c.reinsert_rounds) out->reinsert_rounds = std::min<uint32_t>(c.reinsert_rounds, 65u);
   if (c.gather_route <= GSP_GATHER_COPY) out->gather_route = c.gather_route;
+  if (c.refit_growth > 0.0) out->refit_growth = c.refit_growth;  // (<= 1: no refit can stay below it -> always rebuild)
 }
 
 extern "C" {
@@ -1059,9 +1061,12 @@ static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage&
 
 // instance table (ctx->h_inst) -> device, transformInvT per instance, world-space bake + BVH build from the RESIDENT vertex
 // arrays, per-slot uv gather of a textured scene, traversal spill region
-static int bake_and_build(gsp_context* ctx) {
+// refit == true (gsp_update_instances): keep the tree's topology if its boxes stay within gsp_ctx_options.refit_growth of what
+// they were after the last full build; *refitted says which of the two happened
+static int bake_and_build(gsp_context* ctx, bool refit = false, bool* refitted = nullptr) {
   hipStream_t st = ctx->stream;
   const uint32_t ni = (uint32_t)ctx->h_inst.size();
+  if (refitted) *refitted = false;
   // ---- PathTracer::prepareScene (PathTracer.cpp:58-93): per-instance table ----
   std::vector<float> inv_t(16ull * ni);
   std::vector<uint32_t> tri_first(ni + 1ull);
@@ -1087,6 +1092,20 @@ static int bake_and_build(gsp_context* ctx) {
   bi.normals = ctx->d_nrm.p;
   bi.num_tris = (uint32_t)ctx->total_tris;
   bi.reinsert_rounds = (int)ctx->opt.reinsert_rounds - 1;
+  if (refit && ctx->opt.refit_growth > 1.0 && ctx->bvh.nodes && ctx->bvh.num_tris == bi.num_tris && bi.num_tris > 0) {
+    double growth = 0.0;
+    const size_t held = ctx->bvh.bytes;
+    int rc = refit_bvh(st, bi, ctx->bvh, &growth, ctx->err);  // (synchronises the stream)
+    ctx->bytes += ctx->bvh.bytes - held;                      // (the first refit of a tree allocates its scratch)
+    if (rc != GSP_OK) {
+      (void)hipStreamSynchronize(st);
+      return rc;
+    }
+    if (growth <= ctx->opt.refit_growth) {  // (per-slot uv of a textured scene: the slot order has not changed)
+      if (refitted) *refitted = true;
+      return GSP_OK;
+    }
+  }
   ctx->bytes -= ctx->bvh.bytes;
   if (ctx->node_hist.p) ctx->bytes -= (ctx->node_hist.count + ctx->tri_hist.count) * sizeof(uint32_t);
   ctx->node_hist.release();
@@ -1196,6 +1215,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   if (rc != GSP_OK) return rc;
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->stats.scene_updates = 0;
+  ctx->stats.scene_refits = 0;
   ctx->have_scene = true;
   return GSP_OK;
 }
@@ -1254,11 +1274,13 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   ctx->have_scene = false;  // (a failed rebuild leaves no half-built tree in use)
   for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
   ctx->h_inst.assign(instances, instances + num_instances);
-  rc = bake_and_build(ctx);
+  bool refitted = false;
+  rc = bake_and_build(ctx, true, &refitted);
   if (rc != GSP_OK) return rc;
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->have_scene = true;
   ++ctx->stats.scene_updates;
+  if (refitted) ++ctx->stats.scene_refits;
   return GSP_OK;
 }
 
@@ -1933,9 +1955,10 @@ int gsp_reset_stats(gsp_context* ctx) {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
-  const uint64_t updates = ctx->stats.scene_updates;  // (counts since the last gsp_upload_scene, not since the last reset)
+  const uint64_t updates = ctx->stats.scene_updates, refits = ctx->stats.scene_refits;  // (counts since the last gsp_upload_scene, not since the last reset)
   ctx->stats = gsp_stats{};
   ctx->stats.scene_updates = updates;
+  ctx->stats.scene_refits = refits;
   if (ctx->dstats.p) {
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
     CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));

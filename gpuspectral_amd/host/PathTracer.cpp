@@ -118,7 +118,7 @@ void PathTracer::reset() {
 // PathTracer.cpp:10-19,58-93.  The reference rebuilds the TLAS and re-uploads every table, the instance records and the
 // camera each frame; here the scene is compared BY VALUE with what the device holds (SceneTracker) and only what changed
 // is sent: nothing in the common case, the camera alone for a moved camera, the tables for an edited BSDF or light, a
-// re-bake + BVH rebuild from the resident meshes for an edited transform or material, everything for another object list.
+// re-bake from the resident meshes + refit of the tree (a rebuild when it has degraded) for an edited transform or material, everything for another object list.
 // Tables go before instances: an instance may name a BSDF the new tables add.
 void PathTracer::prepareScene(const Scene& scene) {
   std::vector<gsp_instance> inst;

@@ -57,9 +57,10 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 5 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth;
+#define GSP_ABI_VERSION 6 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth;
                              5: gsp_update_camera / _instances / _tables (+ gsp_multi_*), gsp_ctx_options + gsp_ctx_create_ex /
-                                gsp_multi_create_ex, gsp_render_params.nee, gsp_stats.scene_updates */
+                                gsp_multi_create_ex, gsp_render_params.nee, gsp_stats.scene_updates;
+                             6: gsp_update_instances refits the tree (gsp_ctx_options.refit_growth, gsp_stats.scene_refits) */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -267,7 +268,7 @@ typedef struct gsp_stats {
   uint64_t extend_launches;
   double shade_kernel_ms;
   double connect_kernel_ms;
-  double bvh_build_ms;       /* last gsp_upload_scene                            */
+  double bvh_build_ms;       /* last gsp_upload_scene / gsp_update_instances (build or refit) */
   uint64_t num_triangles;
   uint64_t num_bvh_nodes;
   uint64_t device_bytes;     /* device memory currently held by the context      */
@@ -291,6 +292,7 @@ typedef struct gsp_stats {
   uint64_t shadow_stat_occluded_nodes; /* ... and the node records those read (the rest of shadow_nodes_visited: unoccluded) */
   uint64_t scene_updates;    /* (ABI 5) gsp_update_camera / _instances / _tables calls that changed something since the last
                                 gsp_upload_scene (a test hook: which path did the host layer take?) */
+  uint64_t scene_refits;     /* (ABI 6) of those, gsp_update_instances calls that kept the tree's topology (refit) */
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;
@@ -336,6 +338,9 @@ typedef struct gsp_ctx_options {
                                 0xffffffff = never                                                                    */
   uint32_t reinsert_rounds;  /* BVH build: parallel-reinsertion rounds + 1 (0 default = 6 rounds, 1 = none, ...)      */
   uint32_t gather_route;     /* gsp_multi_create_ex only: GSP_GATHER_*                                                */
+  double refit_growth;       /* (ABI 6) gsp_update_instances keeps the tree's topology and only recomputes its boxes while
+                                their summed surface area stays below this multiple of what it was after the last full
+                                build; beyond it the tree is rebuilt.  0 default (1.25); <= 1 = always rebuild             */
 } gsp_ctx_options;
 void gsp_default_ctx_options(gsp_ctx_options* o);
 int gsp_ctx_create_ex(int device, const gsp_ctx_options* options, gsp_context** out);
@@ -361,8 +366,11 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
  *   gsp_update_instances  new transform / emission / bsdf / twofaced per instance.  `num_instances` and every
  *                         first_vertex / vertex_count must equal the uploaded ones (the meshes stay: they are resident on
  *                         the device); BSDF handles are checked against the resident tables.  Re-bakes the world-space
- *                         packets and rebuilds the BVH on the device (26-37 ms for a million triangles), as the reference
- *                         rebuilds its TLAS.
+ *                         packets into their slots and REFITS the tree -- same topology, every node box and child order
+ *                         recomputed bottom-up (a few ms for a million triangles) -- as the reference rebuilds only its
+ *                         TLAS; when the boxes have grown past gsp_ctx_options.refit_growth (an object has moved far
+ *                         from where the tree was built for) the BVH is rebuilt instead (26-37 ms).  Images do not
+ *                         depend on which of the two happened: the closest-hit rule is independent of the tree.
  *   gsp_update_tables     the eight BSDF arrays + num_bsdfs and the lights + num_lights of `scene` replace the resident
  *                         ones (all other fields of `scene` are ignored); every resident instance's handle must stay in
  *                         range.  No geometry work.  Textured scenes (dormant-feature extension): has_texture values are

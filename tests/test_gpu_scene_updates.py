@@ -1,4 +1,4 @@
-"""Per-frame scene semantics of the drop-in boundary (ABI 5): the reference's createRenderPass re-reads the camera, every
+"""Per-frame scene semantics of the drop-in boundary (ABI 5, refit: 6): the reference's createRenderPass re-reads the camera, every
 object's transform and material, the eight BSDF tables and the lights on EVERY call and only keeps the BLAS of a mesh
 (S/renderer/PathTracer.cpp:10-19,58-93; Renderer.cpp:122-131).  The C++ PathTracer compares the scene by value each
 frame (SceneTracker) and sends gsp_update_camera / _tables / _instances; every test compares the GPU frame bit for bit
@@ -204,6 +204,69 @@ def test_c_abi_updates_equal_a_fresh_upload(oracle_mod):
     acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=2, accum=acc)
     sc.to_world = keep
     assert np.array_equal(mixed, acc)
+
+
+def test_update_instances_refits_then_rebuilds(oracle_mod):
+    """(ABI 6) gsp_update_instances keeps the tree's topology while its boxes stay within gsp_ctx_options.refit_growth of the
+    built tree's (the reference rebuilds only its TLAS, PathTracer.cpp:10-19) and rebuilds beyond it.  Frames and ray counts
+    equal the oracle's either way, and a context that always rebuilds renders the same bytes."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi, scenes
+
+    W, H, SPP = 96, 54, 2
+    sc = scenes.interior(40_000)
+    base = sc.instances.copy()
+    k = int(np.argmax(base["vertex_count"]))
+
+    def edited(step, far=False):
+        inst = base.copy()
+        t = inst["transform"][k].copy()
+        t[12:15] += (np.float32(60.0) if far else np.float32(0.02 * step)) * np.array([1.0, 0.3, -0.5], np.float32)
+        inst["transform"][k] = t
+        if step % 2:  # materials and emission travel with the instance record as well
+            inst["twofaced"][(7 * step) % len(inst)] ^= 1
+        return inst
+
+    frames = {}
+    for growth in (0.0, 1.0):  # default (refit) / always rebuild
+        with g.Context(0, options=abi.CtxOptions(refit_growth=growth)) as ctx:
+            ctx.upload_scene(sc)
+            nodes = ctx.stats()["num_bvh_nodes"]
+            out = []
+            for step in range(1, 7):
+                sc.instances = edited(step)
+                ctx.update_instances(sc.instances)
+                st = ctx.stats()
+                assert st["scene_updates"] == step
+                assert st["scene_refits"] == (step if growth == 0.0 else 0), (growth, step, st["scene_refits"])
+                assert st["num_bvh_nodes"] == nodes or growth == 1.0
+                ctx.frame_begin(W, H)
+                ctx.render(spp=SPP)
+                out.append(ctx.download().reshape(-1, 4).copy())
+            # the object leaves the room: the refitted boxes outgrow the bound, the tree is rebuilt
+            sc.instances = edited(7, far=True)
+            ctx.update_instances(sc.instances)
+            st = ctx.stats()
+            assert st["scene_updates"] == 7 and st["scene_refits"] == (6 if growth == 0.0 else 0)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=SPP)
+            out.append(ctx.download().reshape(-1, 4).copy())
+            # ... and comes back: a refit of the NEW tree (its measure is the rebuilt one's)
+            sc.instances = edited(6)
+            ctx.update_instances(sc.instances)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=SPP)
+            out.append(ctx.download().reshape(-1, 4).copy())
+            frames[growth] = out
+    for a, b in zip(frames[0.0], frames[1.0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(frames[0.0][5], frames[0.0][7])  # step 6 twice
+    ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=SPP)
+    assert np.array_equal(frames[0.0][7], ref)
+    sc.instances = edited(7, far=True)
+    ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=SPP)
+    assert np.array_equal(frames[0.0][6], ref)
+    sc.instances = base
 
 
 def test_multi_updates_reach_every_share(oracle_mod, cornell):

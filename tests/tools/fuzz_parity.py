@@ -124,6 +124,9 @@ def mutate(sc, seed):
     return sc2, changed
 
 
+INSTANCE_UPDATES = [0, 0]  # gsp_update_instances calls of check_updates that changed something, and how many of them refitted
+
+
 def check_updates(ctx, oracle_mod, seed, W=40, H=28, spp=3):
     """random_scene(seed) is uploaded and rendered, then edited in place through gsp_update_camera / _tables / _instances
     (two rounds of edits) -- every frame against the oracle on the scene as it stands."""
@@ -136,7 +139,10 @@ def check_updates(ctx, oracle_mod, seed, W=40, H=28, spp=3):
             if "tables" in what:
                 ctx.update_tables(sc)
             if "instances" in what:
+                r0 = ctx.stats()["scene_refits"]
                 ctx.update_instances(sc.instances)
+                INSTANCE_UPDATES[0] += 1
+                INSTANCE_UPDATES[1] += ctx.stats()["scene_refits"] - r0  # (the rest rebuilt: the edit outgrew the refit bound)
             if "camera" in what:
                 ctx.update_camera(sc.to_world, sc.fov)
         ctx.frame_begin(W, H)
@@ -167,4 +173,6 @@ if __name__ == "__main__":
             if not ok:
                 bad.append((seed, ndiff))
                 print("seed %d: MISMATCH (%d pixels, %d tris)" % (seed, ndiff, tris), flush=True)
+    if INSTANCE_UPDATES[0]:
+        print("gsp_update_instances: %d edits, %d refitted the tree, %d rebuilt it" % (INSTANCE_UPDATES[0], INSTANCE_UPDATES[1], INSTANCE_UPDATES[0] - INSTANCE_UPDATES[1]))
     print("%d scenes%s, %d mismatching: %s" % (n, " with the dormant-feature extension" if dormant else (" with nee = 0" if nee == 0 else ""), len(bad), bad))
