@@ -79,6 +79,38 @@ def test_cornell_materials_with_textures(oracle_mod, materials_scene):
     assert st["shadow_rays"] == ost["shadow_rays"]
 
 
+def test_textured_scene_follows_a_refit(oracle_mod, materials_scene):
+    """gsp_update_instances on a textured scene (ABI 6): a refit keeps the triangle slots, so the per-slot texture coordinates
+    stay where they are; a rebuild gathers them again.  Both frames equal the oracle on the edited scene."""
+    import copy
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi
+
+    W, H, SPP = 80, 80, 3
+    sc = textured.decorate(copy.deepcopy(materials_scene), seed=9)
+    inst = sc.instances.copy()
+    k = int(np.argmax(inst["vertex_count"]))
+    t = inst["transform"][k].copy()
+    t[12] += np.float32(0.03)
+    t[13] -= np.float32(0.02)
+    inst["transform"][k] = t
+    frames = []
+    for growth in (0.0, 1.0):
+        with g.Context(0, options=abi.CtxOptions(refit_growth=growth)) as ctx:
+            ctx.upload_scene(sc)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=1)  # (the pipeline has run on the tree as built)
+            ctx.update_instances(inst)
+            assert ctx.stats()["scene_refits"] == (1 if growth == 0.0 else 0)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=SPP)
+            frames.append(ctx.download().reshape(-1, 4).copy())
+    sc.instances = inst
+    ref, _ = oracle_mod.Oracle(sc).render(W, H, spp=SPP)
+    assert np.array_equal(frames[0], ref) and np.array_equal(frames[1], ref)
+
+
 def test_bad_extension_inputs_are_rejected(materials_scene):
     import copy
 
