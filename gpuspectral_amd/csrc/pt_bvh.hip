@@ -240,11 +240,8 @@ __global__ __launch_bounds__(kBlock) void k_ploc_init(int n, int32_t* __restrict
   if (i < n) code[i] = make_leaf((uint32_t)i, 1);
 }
 
-// nearest neighbour of every cluster inside the window [i - R, i + R]: smallest merged half-area
-__global__ __launch_bounds__(kBlock) void k_ploc_nn(int n, const q4* __restrict__ lo, const q4* __restrict__ hi,
-                                                    int32_t* __restrict__ nn) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+// nearest neighbour of cluster i inside the window [i - R, i + R]: smallest merged half-area
+__device__ __forceinline__ int ploc_nearest(int i, int n, const q4* lo, const q4* hi) {
   const q4 a_lo = lo[i], a_hi = hi[i];
   float best = 3.0e38f;
   int best_j = i > 0 ? i - 1 : i + 1;
@@ -260,7 +257,13 @@ __global__ __launch_bounds__(kBlock) void k_ploc_nn(int n, const q4* __restrict_
       best_j = j;
     }
   }
-  nn[i] = best_j;
+  return best_j;
+}
+__global__ __launch_bounds__(kBlock) void k_ploc_nn(int n, const q4* __restrict__ lo, const q4* __restrict__ hi,
+                                                    int32_t* __restrict__ nn) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  nn[i] = ploc_nearest(i, n, lo, hi);
 }
 
 // keep[i] = 0 for the right partner of a mutual pair (it disappears), isnew[i] = 1 for the left one
@@ -274,27 +277,17 @@ __global__ __launch_bounds__(kBlock) void k_ploc_flags(int n, const int32_t* __r
   isnew[i] = (mutual && i < j) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(kBlock) void k_ploc_apply(int n, const int32_t* __restrict__ nn,
-                                                       const uint32_t* __restrict__ keep,
-                                                       const uint32_t* __restrict__ isnew,
-                                                       const uint32_t* __restrict__ kpos,
-                                                       const uint32_t* __restrict__ npos, uint32_t node_base,
-                                                       const int32_t* __restrict__ code_in, const q4* __restrict__ lo_in,
-                                                       const q4* __restrict__ hi_in, int32_t* __restrict__ code_out,
-                                                       q4* __restrict__ lo_out, q4* __restrict__ hi_out,
-                                                       q4* __restrict__ nodes2, int32_t* __restrict__ parent_int,
-                                                       int32_t* __restrict__ parent_leaf) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n || !keep[i]) return;
-  const uint32_t p = kpos[i];
-  if (!isnew[i]) {
+// cluster i survives this round at position p of the next array: unchanged, or (isnew) merged with its partner j into
+// binary node `id`
+__device__ __forceinline__ void ploc_emit(int i, int j, bool isnew, uint32_t p, int32_t id, const int32_t* code_in, const q4* lo_in,
+                                          const q4* hi_in, int32_t* code_out, q4* lo_out, q4* hi_out, q4* nodes2, int32_t* parent_int,
+                                          int32_t* parent_leaf) {
+  if (!isnew) {
     code_out[p] = code_in[i];
     lo_out[p] = lo_in[i];
     hi_out[p] = hi_in[i];
     return;
   }
-  const int j = nn[i];
-  const int32_t id = (int32_t)(node_base + npos[i]);
   const int32_t cl = code_in[i], cr = code_in[j];
   const q4 llo = lo_in[i], lhi = hi_in[i], rlo = lo_in[j], rhi = hi_in[j];
   q4* N = nodes2 + 4ll * id;
@@ -307,6 +300,82 @@ __global__ __launch_bounds__(kBlock) void k_ploc_apply(int n, const int32_t* __r
   code_out[p] = id;
   lo_out[p] = mkq(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), 0.0f);
   hi_out[p] = mkq(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), 0.0f);
+}
+__global__ __launch_bounds__(kBlock) void k_ploc_apply(int n, const int32_t* __restrict__ nn,
+                                                       const uint32_t* __restrict__ keep,
+                                                       const uint32_t* __restrict__ isnew,
+                                                       const uint32_t* __restrict__ kpos,
+                                                       const uint32_t* __restrict__ npos, uint32_t node_base,
+                                                       const int32_t* __restrict__ code_in, const q4* __restrict__ lo_in,
+                                                       const q4* __restrict__ hi_in, int32_t* __restrict__ code_out,
+                                                       q4* __restrict__ lo_out, q4* __restrict__ hi_out,
+                                                       q4* __restrict__ nodes2, int32_t* __restrict__ parent_int,
+                                                       int32_t* __restrict__ parent_leaf) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || !keep[i]) return;
+  ploc_emit(i, nn[i], isnew[i] != 0u, kpos[i], (int32_t)(node_base + npos[i]), code_in, lo_in, hi_in, code_out, lo_out, hi_out, nodes2,
+            parent_int, parent_leaf);
+}
+
+// The last rounds of PLOC: once few clusters are left a round is five launches, two scans and a read-back for microseconds of
+// work, and it takes as many rounds to get from 2048 clusters to one as from a million to 2048.  ONE block runs them all:
+// the same search, the same mutual-pair rule, the same positions as the kernels above (so the same tree), the scans in LDS.
+constexpr int kPlocTail = 2048, kPlocTailThreads = 1024;
+__global__ __launch_bounds__(kPlocTailThreads) void k_ploc_tail(int m, uint32_t node_base, int32_t* code_a, q4* lo_a, q4* hi_a,
+                                                                int32_t* code_b, q4* lo_b, q4* hi_b, q4* nodes2, int32_t* parent_int,
+                                                                int32_t* parent_leaf, int32_t* result) {
+  __shared__ int32_t s_nn[kPlocTail];
+  __shared__ uint16_t s_kpos[kPlocTail], s_npos[kPlocTail];  // position inside the thread's own run of clusters
+  __shared__ uint32_t s_part[2][kPlocTailThreads];           // per-thread totals, then their exclusive scan
+  __shared__ uint32_t s_tot[2];
+  const int tid = threadIdx.x;
+  while (m > 1) {
+    for (int i = tid; i < m; i += kPlocTailThreads) s_nn[i] = ploc_nearest(i, m, lo_a, hi_a);
+    __syncthreads();
+    const int per = (m + kPlocTailThreads - 1) / kPlocTailThreads, b = min(m, tid * per), e = min(m, b + per);
+    uint32_t ck = 0, cn = 0;
+    for (int i = b; i < e; ++i) {
+      const int j = s_nn[i];
+      const bool mutual = s_nn[j] == i;
+      s_kpos[i] = (uint16_t)ck;
+      s_npos[i] = (uint16_t)cn;
+      ck += (mutual && i > j) ? 0u : 1u;
+      cn += (mutual && i < j) ? 1u : 0u;
+    }
+    s_part[0][tid] = ck;
+    s_part[1][tid] = cn;
+    __syncthreads();
+    if (tid < 2) {
+      uint32_t acc = 0;
+      for (int t = 0; t < kPlocTailThreads; ++t) {
+        const uint32_t c = s_part[tid][t];
+        s_part[tid][t] = acc;
+        acc += c;
+      }
+      s_tot[tid] = acc;
+    }
+    __syncthreads();
+    for (int i = b; i < e; ++i) {
+      const int j = s_nn[i];
+      const bool mutual = s_nn[j] == i;
+      if (mutual && i > j) continue;  // the right partner of a pair disappears
+      ploc_emit(i, j, mutual && i < j, s_part[0][tid] + s_kpos[i], (int32_t)(node_base + s_part[1][tid] + s_npos[i]), code_a, lo_a, hi_a,
+                code_b, lo_b, hi_b, nodes2, parent_int, parent_leaf);
+    }
+    __syncthreads();  // (the next round reads what this one wrote: same block, workgroup-scope fence)
+    const uint32_t kept = s_tot[0], made = s_tot[1];
+    __syncthreads();
+    if (made == 0 || kept != (uint32_t)m - made) {  // cannot happen (the closest pair is mutual); do not spin on it
+      if (tid == 0) result[0] = -1, result[1] = 0;
+      return;
+    }
+    node_base += made;
+    m = (int)kept;
+    int32_t* tc = code_a; code_a = code_b; code_b = tc;
+    q4* tl = lo_a; lo_a = lo_b; lo_b = tl;
+    q4* th = hi_a; hi_a = hi_b; hi_b = th;
+  }
+  if (tid == 0) result[0] = code_a[0], result[1] = 1;
 }
 
 // a child of a binary node: box + code
@@ -760,15 +829,32 @@ __global__ __launch_bounds__(kBlock) void k_wide_area(uint32_t num_nodes, const 
   area[node] = sum;
 }
 
+// Build scratch: ~30 arrays that live for one build.  One arena (reserve) instead of thirty hipMalloc / hipFree pairs -- each of
+// those is a driver call of 0.1-0.2 ms, a third of a million-triangle build's wall time; a request the arena cannot hold falls
+// back to its own allocation.
 struct Scratch {
   std::vector<void*> ptrs;
   size_t bytes = 0;
+  char* arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
   ~Scratch() {
     for (void* p : ptrs) (void)hipFree(p);
+    (void)hipFree(arena);
+  }
+  void reserve(size_t b) {  // best effort: without the arena every request allocates for itself
+    if (arena || b == 0) return;
+    if (hipMalloc((void**)&arena, b) == hipSuccess) arena_bytes = b, bytes += b;
+    else arena = nullptr, (void)hipGetLastError();
   }
   template <class T>
   hipError_t alloc(T** p, size_t count) {
     size_t b = std::max<size_t>(count, 1) * sizeof(T);
+    const size_t at = (arena_used + 255) & ~(size_t)255;
+    if (arena && at + b <= arena_bytes) {
+      *p = (T*)(arena + at);
+      arena_used = at + b;
+      return hipSuccess;
+    }
     hipError_t e = hipMalloc((void**)p, b);
     if (e == hipSuccess) {
       ptrs.push_back(*p);
@@ -834,6 +920,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
   }
 
   Scratch S;
+  S.reserve(640ull * n + (1ull << 20));  // (the requests below sum to ~600 B per triangle + the sort's and scans' temporaries)
   q4 *isect_g, *shade_g, *lo_g, *hi_g, *leaf_lo, *leaf_hi, *int_lo, *int_hi, *nodes2, *isect_m, *shade_m;
   uint32_t *bounds, *vals_in, *vals_out, *arrive, *flag, *idx4, *s2g_m;
   uint64_t *keys_in, *keys_out;
@@ -920,7 +1007,7 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
       hipLaunchKernelGGL(k_ploc_init, dim3(blocks_for(n)), dim3(kBlock), 0, stream, (int)n, code_a);
       q4 *lo_a = leaf_lo, *hi_a = leaf_hi, *lo_b = int_lo, *hi_b = int_hi;
       uint32_t m = n, node_base = 0;
-      while (m > 1) {
+      while (m > (uint32_t)kPlocTail) {
         hipLaunchKernelGGL(k_ploc_nn, dim3(blocks_for(m)), dim3(kBlock), 0, stream, (int)m, lo_a, hi_a, nn);
         hipLaunchKernelGGL(k_ploc_flags, dim3(blocks_for(m)), dim3(kBlock), 0, stream, (int)m, nn, keep, isnew);
         GSP_HIP_TRY(hipMemsetAsync(keep + m, 0, sizeof(uint32_t), stream));
@@ -943,8 +1030,23 @@ int build_bvh(hipStream_t stream, const BuildInput& in, DeviceBvh& out, std::str
         std::swap(lo_a, lo_b);
         std::swap(hi_a, hi_b);
       }
-      GSP_HIP_TRY(hipMemcpyAsync(&root2, code_a, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-      GSP_HIP_TRY(hipStreamSynchronize(stream));
+      if (m > 1) {  // the remaining rounds in one launch
+        int32_t* tail_result = (int32_t*)kpos;  // (two words of a scan array nobody reads any more)
+        hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kPlocTailThreads), 0, stream, (int)m, node_base, code_a, lo_a, hi_a, code_b, lo_b, hi_b,
+                           nodes2, parent_int, parent_leaf, tail_result);
+        GSP_HIP_TRY(hipGetLastError());
+        int32_t res[2] = {0, 0};
+        GSP_HIP_TRY(hipMemcpyAsync(res, tail_result, sizeof(res), hipMemcpyDeviceToHost, stream));
+        GSP_HIP_TRY(hipStreamSynchronize(stream));
+        if (res[1] != 1) {
+          err = "PLOC made no progress (internal error)";
+          return GSP_ERR_DEVICE;
+        }
+        root2 = res[0];
+      } else {
+        GSP_HIP_TRY(hipMemcpyAsync(&root2, code_a, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        GSP_HIP_TRY(hipStreamSynchronize(stream));
+      }
       // leaf_lo/leaf_hi may have been overwritten by the ping-pong: nothing below reads them again
       // ---- parallel reinsertion rounds (above): no host round trip inside
       const int rounds = in.reinsert_rounds < 0 ? kReinsertRounds : std::min(in.reinsert_rounds, 64);

@@ -369,7 +369,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
  *                         packets into their slots and REFITS the tree -- same topology, every node box and child order
  *                         recomputed bottom-up (a few ms for a million triangles) -- as the reference rebuilds only its
  *                         TLAS; when the boxes have grown past gsp_ctx_options.refit_growth (an object has moved far
- *                         from where the tree was built for) the BVH is rebuilt instead (26-37 ms).  Images do not
+ *                         from where the tree was built for) the BVH is rebuilt instead (18 ms).  Images do not
  *                         depend on which of the two happened: the closest-hit rule is independent of the tree.
  *   gsp_update_tables     the eight BSDF arrays + num_bsdfs and the lights + num_lights of `scene` replace the resident
  *                         ones (all other fields of `scene` are ignored); every resident instance's handle must stay in
