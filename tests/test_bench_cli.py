@@ -82,6 +82,24 @@ def test_pmc_file_is_refused_for_another_build(tmp_path, monkeypatch):
     assert pmc["k_trace_extend"]["SQ_INSTS_VALU"] == 6.0 and "scaled" in src
 
 
+def test_committed_counter_files_belong_to_the_library_in_the_tree():
+    """profiles/pmc_bench_*.json are what the driver's bench run reads for `roofline`'s counter fields: a change of any csrc
+    source or of the header re-stamps the library, so the evidence run (scripts/final_evidence_run.sh) must follow it -- this
+    fails here, on CPU, when it has not."""
+    import glob
+    import json
+
+    import gpuspectral_amd as g
+
+    if os.environ.get("GSP_LIB_PATH"):
+        pytest.skip("GSP_LIB_PATH points at a build variant")
+    digest = g.pt.build_info()["digest"]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_bench_*.json")))
+    assert files
+    for f in files:
+        assert json.load(open(f))["library_digest"] == digest, "%s was collected on another build: rerun scripts/final_evidence_run.sh" % os.path.basename(f)
+
+
 def test_gpus_defaults_to_world_size(monkeypatch, capsys):
     """`torchrun --nproc-per-node N bench.py` without --gpus runs with N ranks: no mismatch exit."""
     b = _load_bench()
