@@ -507,6 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
   FinishStack stk{(lds_u32*)s_stack + threadIdx.x, 0u};
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   unsigned long long ext = 0, sh = 0, shaded = 0;
+  uint32_t done_slot = 0xffffffffu;  // sample slot of the path this lane has run to its end (none: beyond the queue)
   if (i < n) {
     const q4 p0 = q.P0[i], p1 = q.P1[i], p2 = q.P2[i];
     PathState in;
@@ -548,7 +549,20 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
       in = out.next;
     }
     result[sid] = res;
-    atomicSub(&live[sid / slot_paths], 1u);
+    done_slot = sid / slot_paths;
+  }
+  // every path of this launch leaves its sample slot's live count: one atomic per wave and slot (the lanes of a wave almost
+  // always share a slot), not one per path -- 262 144 of them on one word are 3 ms at the 88 M requests/s a cache line takes
+  // (profiles/r04_atomic_rate.txt), most of what this kernel took at the end of a drain
+  {
+    uint64_t dm = __ballot(done_slot != 0xffffffffu);
+    while (dm) {  // wave-uniform
+      const int first = __ffsll((unsigned long long)dm) - 1;
+      const uint32_t s0 = (uint32_t)__shfl((int)done_slot, first);
+      const uint64_t same = __ballot(done_slot == s0) & dm;
+      if ((int)(threadIdx.x & 63) == first) atomicSub(&live[s0], (uint32_t)__popcll(same));
+      dm &= ~same;
+    }
   }
   ext = wave_sum(ext);
   sh = wave_sum(sh);
