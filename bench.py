@@ -106,6 +106,8 @@ def pmc_for_run(config, timed_launches, digest):
             if len(vals) < take:
                 return None, "PMC file has fewer dispatches than the timed region"
             vals_out[name] = float(sum(vals[-take:])) * (1.0 if scale is None else scale)
+        if len(k.get("trace_us", [])) >= take:  # durations of the same dispatches in the kernel-trace pass (no counters)
+            vals_out["trace_us_sum"] = float(sum(k["trace_us"][-take:])) * (1.0 if scale is None else scale)
         out[kname] = vals_out
     src = "profiles/%s (%s, library %s)%s" % (os.path.basename(pm_path), pm.get("source", "?"), digest,
                                               "" if scale is None else ", per-launch averages of its %d timed launches scaled" % take)
@@ -119,9 +121,14 @@ def kernel_rates(c, ms, launches, coalesced_read_bytes):
     the missing half of the kernel's coalesced reads is added back; WRITE_SIZE is exact for streaming writes and an
     upper bound (x 2) for scattered 16-B ones."""
     r = {"valu_ginstr_s": None, "issue_frac": None, "lanes_per_instr": None, "effective": None, "wait_share": None,
-         "traffic": None, "hbm_gbs": None, "hbm_frac": None, "l2_hit_rate": None}
+         "traffic": None, "hbm_gbs": None, "hbm_frac": None, "l2_hit_rate": None, "shader_clock_ghz": None}
     if not c or ms <= 0:
         return r
+    # the clock the chip held during this kernel: GRBM_GUI_ACTIVE (busy cycles, summed over the 8 XCDs) of the profiled
+    # dispatches over their durations in the kernel-trace pass -- 2.1-2.3 GHz under these kernels, not the 2.4 GHz the peaks
+    # above are quoted at (the chip regulates its clock by power)
+    if c.get("GRBM_GUI_ACTIVE", 0) > 0 and c.get("trace_us_sum", 0) > 0:
+        r["shader_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["trace_us_sum"] * 1e-6) / 1e9
     insts = c.get("SQ_INSTS_VALU", 0.0)
     if insts > 0:
         r["valu_ginstr_s"] = insts / (ms * 1e-3) / 1e9
@@ -455,6 +462,9 @@ def _main():
             k["valu_mean_issue_cycles"] = cyc
             k["valu_weighted_peak_ginstr_s"] = 1024 * 2.4 / cyc if cyc else None
             k["issue_frac_weighted"] = k["valu_ginstr_s"] / k["valu_weighted_peak_ginstr_s"] if (cyc and k["valu_ginstr_s"]) else None
+            # ... and against the same ceiling at the clock the chip actually held (informational: `frac` stays on the nominal peak)
+            k["issue_frac_weighted_at_clock"] = (k["valu_ginstr_s"] / (1024 * k["shader_clock_ghz"] / cyc)
+                                                 if (cyc and k["valu_ginstr_s"] and k.get("shader_clock_ghz")) else None)
             fr = {"valu_issue_weighted": k["issue_frac_weighted"], "l1_request": k["l1_request_frac"], "hbm": k["hbm_frac"]}
             fr = {a: b for a, b in fr.items() if b is not None}
             k["bound"] = max(fr, key=fr.get) if fr else None
@@ -475,6 +485,7 @@ def _main():
             "achieved": pick[0], "peak": pick[1], "unit": pick[2], "frac": pick[3],
             "fractions": {"valu_issue": ext["issue_frac"], "valu_issue_weighted": ext["issue_frac_weighted"],
                           "l1_request": ext["l1_request_frac"], "hbm": ext["hbm_frac"]},
+            "shader_clock_ghz": ext["shader_clock_ghz"], "valu_issue_weighted_at_clock": ext["issue_frac_weighted_at_clock"],
             "valu_ginstr_s": ext["valu_ginstr_s"], "valu_peak_ginstr_s": VALU_PEAK_GINST,
             "valu_weighted_peak_ginstr_s": ext["valu_weighted_peak_ginstr_s"], "valu_mean_issue_cycles": ext["valu_mean_issue_cycles"],
             "lane_loads_per_ray": ext_lane_loads, "lds_nodes_per_ray": lds_nodes_per_ray, "lane_loads_g_s": ext["lane_loads_g_s"],
