@@ -19,4 +19,7 @@ cp gpurun_out/pmc_${TAG}_s20_w5/summary.txt $O/pmc_summary_s20_w5.txt
 find gpurun_out/pmc_${TAG}_s4_w1/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_s4_w1.csv \;
 find gpurun_out/pmc_${TAG}_s20_w5/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_s20_w5.csv \;
 SECONDS_=4 timeout 900 python tests/tools/scene_probe.py coffee staircase2 cornell-box living-room interior materials caustics > $O/scene_probe.txt 2>&1
+timeout 600 python scripts/update_latency_probe.py > $O/update_latency.txt 2>&1
+timeout 600 python scripts/refit_quality_probe.py > $O/refit_quality.txt 2>&1
+timeout 300 python scripts/build_time_probe.py > $O/build_time.txt 2>&1
 cat $O/gputest.txt; tail -3 $O/smoke.txt; cut -c1-600 $O/bench_n1_s20_w5.json
