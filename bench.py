@@ -18,25 +18,29 @@ scene at 1920x1080, on 1/2/4/8 MI355X.
 * Timed region: barrier + device sync on both sides, max over ranks.
 * Scene upload and BVH build are outside the timed region (reported separately).
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, k_trace<ExtendIO> (closest-hit BVH traversal),
-against the three ceilings it runs near, `bound` naming the one it is closest to:
-  valu_issue_weighted  wave64 VALU instructions per second (rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from the
-                       committed PMC passes over this same command line, profiles/pmc_bench_*.json, over this run's HIP-event
-                       kernel time) against 1024 SIMDs x 2.4 GHz / the kernel's mean issue cost (static class mix of the
-                       loaded library: full / half / quarter-rate instructions, lib/valu_mix.json); `fractions.valu_issue`
-                       is the same rate against 2 cycles per instruction;
-  l1_request           16-B lane loads per second (from the live statistics pass: 4 per node record not served from LDS,
-                       3 per triangle packet, 2 for the ray) against one per cycle and CU;
-  hbm                  counter bytes per second against 8 TB/s.
-The memory side in detail: counter HBM bytes per launch (`traffic`, FETCH_SIZE / WRITE_SIZE with the
-calibration of scripts/microbench/fetch_calib.hip) as a fraction of the 8 TB/s peak (`hbm_frac`), and the SURVEY 8(d)
-algorithmic bytes (every node / triangle record the traversal reads, mostly served by L2 / Infinity Cache) as
-`algorithmic_gbs` -- informational, not a fraction of anything.  `frac` is an issue-rate UTILISATION (a build that
-executes more instructions per ray scores higher), so the work-normalised figures stand next to it: `effective` =
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, k_trace<ExtendIO> (closest-hit BVH traversal).
+It is bound by VALU ISSUE (no dense contraction: MFMA unused; HBM at about a third of its peak), so
+  frac = achieved / peak = wave64 VALU instructions per second (rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from
+         the committed PMC passes over this same command line, profiles/pmc_bench_*.json -- `counters_from` says which file --
+         over THIS run's HIP-event kernel time) / 1228.8 G/s (1024 SIMD-32 x 2.4 GHz / 2 cycles, MI355X_MICROARCH.md).
+`fractions` carries the other ceilings next to it, each defined in one line in DESIGN.md 5:
+  valu_issue_weighted            the same rate against 1024 x 2.4 GHz / the kernel's mean issue cost, where the class mix is
+                                 DYNAMIC (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 / INT32 / INT64 / CVT of the same
+                                 launches; cost of a class = static mix inside the class, lib/valu_mix.json; class membership
+                                 calibrated by profiles/r05_valu_class_calib.txt); `valu_issue_weighted_static` = r04's figure
+                                 (static mix of the binary), kept for comparison
+  valu_issue_weighted_at_clock   ... at the clock the chip HELD under the kernel (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)
+  l1_request                     16-B lane loads per second (live statistics pass) against one per cycle and CU
+  hbm                            counter bytes (FETCH_SIZE + WRITE_SIZE, corrected as the guide prescribes) per second / 8 TB/s
+`traffic` = those counter bytes per launch.  SURVEY 8(d)'s byte model (every node / triangle record the traversal reads,
+charged as if it came from HBM) is reported as `survey_byte_model`: it is NOT a bound for a 31-MB tree -- half of the node
+visits are served by the LDS copy of the top of the tree and L2 hits 56 % -- so it is printed with
+`traffic_over_survey_model` (~0.25) instead of as a rate against the HBM peak.  `frac` is an issue-rate UTILISATION (a build
+that executes more instructions per ray scores higher), so the work-normalised figures stand next to it: `effective` =
 frac x lanes enabled per instruction, `valu_instr_per_ray`, `valu_lane_instr_per_ray`; `other_kernels` carries the same
-figures for k_trace<ConnectIO> and k_shade.  The PMC file must carry the source digest of the loaded library
-(`config.library_digest`): a file from another build is refused and the fields stay null.  `cpu_baseline` times the scalar CPU oracle on this
-box's host cores on a bounded sample of the same workload (N = 1 only).
+figures for k_trace<ConnectIO> and k_shade.  A PMC file must carry the digest of the render kernels' instruction streams
+(`config.kernel_digest`, lib/valu_mix.json) of the loaded library: a file from other device code is refused and the fields
+stay null.  `cpu_baseline` times the scalar CPU oracle on this box's host cores on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
 import json
@@ -59,13 +63,14 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 PMC_GLOB = os.path.join(ROOT, "profiles", "pmc_bench_*.json")  # one file per profiled command line (steps / warmup)
 
 
-def pmc_for_run(config, timed_launches, digest):
+def pmc_for_run(config, timed_launches, digest, kernel_digest=None):
     """Counters of the timed launches of the three render kernels from the committed rocprofv3 --pmc passes
     (scripts/pmc_bench.sh) over THIS command with THIS build: the passes ran the same workload, so their last
     `timed_launches` dispatches of a kernel are the launches of the timed region (it is the tail of the run).
     -> ({kernel: {counter: sum over the timed launches}}, source string) or (None, reason): a file taken on another
-    workload, or with a library whose source digest differs from the loaded one, is refused -- the fields stay null
-    rather than describe another binary."""
+    workload, or with other DEVICE CODE, is refused -- the fields stay null rather than describe another binary.  "Same
+    device code" = the file's `kernel_digest` (sha256 of the three render kernels' instruction streams, lib/valu_mix.json)
+    equals the loaded library's; files from before r05 carry only the library's source digest and must match that."""
     import glob
 
     want = {k: config[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
@@ -80,12 +85,13 @@ def pmc_for_run(config, timed_launches, digest):
         have = cand.get("bench_config", {})
         if not all(have.get(k) == v for k, v in want.items()):
             continue
-        if cand.get("library_digest") != digest:
+        same = (cand.get("kernel_digest") == kernel_digest) if (kernel_digest and cand.get("kernel_digest")) else (cand.get("library_digest") == digest)
+        if not same:
             stale += 1
             continue
         cands.append((path, cand))
     if not cands:
-        return None, ("stale build: %d PMC file(s) of this workload were taken with another library digest" % stale) if stale else "no PMC file for this workload"
+        return None, ("stale build: %d PMC file(s) of this workload were taken with other device code (kernel / library digest)" % stale) if stale else "no PMC file for this workload"
     exact = [(p, c) for p, c in cands if c.get("timed_launches") == timed_launches and c.get("steps") == config.get("steps")
              and c.get("warmup") == config.get("warmup")]
     if exact:
@@ -109,7 +115,7 @@ def pmc_for_run(config, timed_launches, digest):
         if len(k.get("trace_us", [])) >= take:  # durations of the same dispatches in the kernel-trace pass (no counters)
             vals_out["trace_us_sum"] = float(sum(k["trace_us"][-take:])) * (1.0 if scale is None else scale)
         out[kname] = vals_out
-    src = "profiles/%s (%s, library %s)%s" % (os.path.basename(pm_path), pm.get("source", "?"), digest,
+    src = "profiles/%s (%s, kernels %s)%s" % (os.path.basename(pm_path), pm.get("source", "?"), pm.get("kernel_digest") or ("library " + str(pm.get("library_digest"))),
                                               "" if scale is None else ", per-launch averages of its %d timed launches scaled" % take)
     return out, src
 
@@ -368,25 +374,33 @@ def _main():
         ctx.render(spp=S, first_timestamp=ts, collect_kernel_times=1)
         ts += S
     frame = None
+    gather_s = 0.0
     if dist is not None:
-        # the single collective of the job: HDR tiles -> rank 0 over xGMI
+        # the single collective of the job: HDR tiles -> rank 0 over xGMI.  Its own time (this rank's tracer drained first, so
+        # that the clock does not charge the gather with the tail of the render; device-synchronised on both sides) goes into
+        # the line as config.gather_ms (max over ranks) -- still INSIDE the timed region
+        ctx.sync()
+        t_g = time.perf_counter()
         if on_gpu:
             ctx.copy_accum_to_device(local_t.data_ptr(), npix_local * 16)
         else:
             local_t.copy_(torch.from_numpy(ctx.download_compact()))
         frame = multigpu.gather_frame(local_t, W, H, rank, world, dist, force=args.force_dist)
+        if on_gpu:
+            torch.cuda.synchronize()
+        gather_s = time.perf_counter() - t_g
     barrier()
     elapsed = time.perf_counter() - t_begin
 
     st = ctx.stats()
     local = np.array(
         [elapsed, st["extension_rays"], st["shadow_rays"], st["samples"], st["extend_kernel_ms"], st["extend_launches"],
-         st["shade_kernel_ms"], st["connect_kernel_ms"], st["shaded_vertices"], st["memoised_rays"], st["memo_build_rays"]],
+         st["shade_kernel_ms"], st["connect_kernel_ms"], st["shaded_vertices"], st["memoised_rays"], st["memo_build_rays"], gather_s],
         np.float64,
     )
     # what a first 8-GPU run needs in order to explain its own imbalance: every rank's own clock, work and pool
     mine = np.array([elapsed, st["traced_rays"], st["samples"], npix_local, st["extend_kernel_ms"] + st["shade_kernel_ms"] + st["connect_kernel_ms"],
-                     st["extend_launches"], st["device_bytes"], st["render_seconds"], upload_s], np.float64)
+                     st["extend_launches"], st["device_bytes"], st["render_seconds"], upload_s, gather_s], np.float64)
     per_rank = [mine]
     if dist is not None:
         tm = torch.from_numpy(mine).to(tdev)
@@ -401,6 +415,7 @@ def _main():
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0].item())
+        gather_s = float(tmax[11].item())
         tot = tsum.cpu().numpy()
     else:
         tot = local
@@ -427,7 +442,16 @@ def _main():
         cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S,
                    "steps": args.steps, "warmup": args.warmup, "primary_memo": bool(st["memoised_rays"] > 0)}
         digest = g.pt.build_info()["digest"]
-        pmc, pmc_src = pmc_for_run(cfg_key, int(st["extend_launches"]), digest) if world == 1 else (None, "N > 1: counters are a single-GPU measurement")
+        # class tables + the digest of the render kernels' instruction streams, written next to the library by csrc/Makefile
+        mixf = os.path.join(os.path.dirname(g.lib_path()), "valu_mix.json")
+        vmix, kernel_digest = {}, None
+        try:
+            vm = json.load(open(mixf))
+            if vm.get("library_digest") == digest:
+                vmix, kernel_digest = vm["kernels"], vm.get("kernel_digest")
+        except (OSError, ValueError):
+            pass
+        pmc, pmc_src = pmc_for_run(cfg_key, int(st["extend_launches"]), digest, kernel_digest) if world == 1 else (None, "N > 1: counters are a single-GPU measurement")
         vertices = float(tot[8])
         ext = kernel_rates((pmc or {}).get("k_trace_extend"), ext_ms, launches, 32.0 * ext_traced0)
         # k_trace<ConnectIO> streams the 32-B shadow ray in (an occluded one loads 16 B more at its commit: a gather);
@@ -439,55 +463,54 @@ def _main():
         shd["queue_bytes_per_vertex"] = shade_bytes / max(1.0, vertices)
         shd["queue_gbs"] = shade_bytes / (st["shade_kernel_ms"] * 1e-3) / 1e9 if st["shade_kernel_ms"] > 0 else None
         shd["queue_frac_of_hbm_peak"] = shd["queue_gbs"] / HBM_PEAK_GBS if shd["queue_gbs"] else None
-        # ---- the ceilings the traversal runs against, each as a fraction (DESIGN.md 5 defines them in one line each):
-        #   valu_issue           wave64 VALU instructions / s over 1024 SIMDs x 2.4 GHz / 2 cycles (every instruction full rate)
-        #   valu_issue_weighted  ... over 1024 x 2.4 GHz / the kernel's mean issue cost (static class mix: 2 / 4 / 8 cycles)
-        #   l1_request           lane loads / s over one per cycle and CU
-        #   hbm                  counter bytes / s over 8 TB/s
-        mixf = os.path.join(os.path.dirname(g.lib_path()), "valu_mix.json")
-        vmix = {}
-        try:
-            vm = json.load(open(mixf))
-            if vm.get("library_digest") == digest:
-                vmix = vm["kernels"]
-        except (OSError, ValueError):
-            pass
 
         def ceilings(k, kname, lane_loads_per_ray, rays, ms):
             """adds the request-path and class-weighted issue figures to a kernel_rates() dict"""
+            c = (pmc or {}).get(kname) or {}
             k["lane_loads_per_ray"] = lane_loads_per_ray
             k["lane_loads_g_s"] = lane_loads_per_ray * rays / (ms * 1e-3) / 1e9 if ms > 0 else None
             k["l1_request_frac"] = k["lane_loads_g_s"] / L1_REQUEST_PEAK_G if k["lane_loads_g_s"] else None
-            cyc = (vmix.get(kname) or {}).get("mean_issue_cycles")
+            tab = vmix.get(kname) or {}
+            cyc_static = tab.get("mean_issue_cycles")
+            # DYNAMIC class mix: the hardware's class counters of the same launches x the issue cost of each class
+            cyc, shares = None, None
+            if tab.get("classes") and c.get("SQ_INSTS_VALU", 0) > 0 and "SQ_INSTS_VALU_FMA_F32" in c:
+                from scripts import valu_mix as _vm
+
+                dyn = {cl: c.get("SQ_INSTS_VALU_" + cl, 0.0) for cl in _vm.HW_CLASSES[:-1]}
+                cyc, shares = _vm.dynamic_mean_cost(tab["classes"], dyn, c["SQ_INSTS_VALU"])
+            k["valu_mean_issue_cycles_static"] = cyc_static
             k["valu_mean_issue_cycles"] = cyc
+            k["valu_class_shares"] = shares
+            k["issue_frac_weighted_static"] = k["valu_ginstr_s"] / (1024 * 2.4 / cyc_static) if (cyc_static and k["valu_ginstr_s"]) else None
             k["valu_weighted_peak_ginstr_s"] = 1024 * 2.4 / cyc if cyc else None
             k["issue_frac_weighted"] = k["valu_ginstr_s"] / k["valu_weighted_peak_ginstr_s"] if (cyc and k["valu_ginstr_s"]) else None
             # ... and against the same ceiling at the clock the chip actually held (informational: `frac` stays on the nominal peak)
             k["issue_frac_weighted_at_clock"] = (k["valu_ginstr_s"] / (1024 * k["shader_clock_ghz"] / cyc)
                                                  if (cyc and k["valu_ginstr_s"] and k.get("shader_clock_ghz")) else None)
-            fr = {"valu_issue_weighted": k["issue_frac_weighted"], "l1_request": k["l1_request_frac"], "hbm": k["hbm_frac"]}
-            fr = {a: b for a, b in fr.items() if b is not None}
-            k["bound"] = max(fr, key=fr.get) if fr else None
+            fr = {"valu_issue": k["issue_frac"], "l1_request": k["l1_request_frac"], "hbm": k["hbm_frac"]}
+            fr = {a_: b_ for a_, b_ in fr.items() if b_ is not None}
+            k["bound"] = max(fr, key=fr.get) if fr else None  # (of the three datasheet ceilings; the weighted figures are secondaries)
             return k
 
         ceilings(ext, "k_trace_extend", ext_lane_loads, ext_traced0, ext_ms)
         ceilings(con, "k_trace_connect", sh_lane_loads, st["shadow_rays"], st["connect_kernel_ms"])
         ceilings(shd, "k_shade", 9.0, vertices, st["shade_kernel_ms"])  # 5 coalesced record quads + the 4 quads of the shading packet
-        bound = ext["bound"] or "valu_issue"
-        pick = {"valu_issue_weighted": (ext["valu_ginstr_s"], ext["valu_weighted_peak_ginstr_s"], "G wave64 VALU instr/s", ext["issue_frac_weighted"]),
-                "l1_request": (ext["lane_loads_g_s"], L1_REQUEST_PEAK_G, "G lane loads/s", ext["l1_request_frac"]),
-                "hbm": (ext["hbm_gbs"], HBM_PEAK_GBS, "GB/s", ext["hbm_frac"]),
-                "valu_issue": (ext["valu_ginstr_s"], VALU_PEAK_GINST, "G wave64 VALU instr/s", ext["issue_frac"])}[bound]
+        survey_gbs = alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else None
         roof = {
             "kernel": "k_trace<ExtendIO> (closest-hit traversal of the wide BVH)",
-            # the ceiling the kernel is CLOSEST to (largest fraction) of: class-weighted VALU issue, L1 request path, HBM
-            "bound": bound,
-            "achieved": pick[0], "peak": pick[1], "unit": pick[2], "frac": pick[3],
+            # VALU issue against the guide's datasheet peak: the ceiling this kernel runs against (no MFMA by design, HBM ~1/3)
+            "bound": "valu_issue",
+            "achieved": ext["valu_ginstr_s"], "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instr/s", "frac": ext["issue_frac"],
             "fractions": {"valu_issue": ext["issue_frac"], "valu_issue_weighted": ext["issue_frac_weighted"],
+                          "valu_issue_weighted_static": ext["issue_frac_weighted_static"],
+                          "valu_issue_weighted_at_clock": ext["issue_frac_weighted_at_clock"],
                           "l1_request": ext["l1_request_frac"], "hbm": ext["hbm_frac"]},
-            "shader_clock_ghz": ext["shader_clock_ghz"], "valu_issue_weighted_at_clock": ext["issue_frac_weighted_at_clock"],
+            "largest_datasheet_fraction": ext["bound"],
+            "shader_clock_ghz": ext["shader_clock_ghz"],
             "valu_ginstr_s": ext["valu_ginstr_s"], "valu_peak_ginstr_s": VALU_PEAK_GINST,
             "valu_weighted_peak_ginstr_s": ext["valu_weighted_peak_ginstr_s"], "valu_mean_issue_cycles": ext["valu_mean_issue_cycles"],
+            "valu_mean_issue_cycles_static": ext["valu_mean_issue_cycles_static"], "valu_class_shares": ext["valu_class_shares"],
             "lane_loads_per_ray": ext_lane_loads, "lds_nodes_per_ray": lds_nodes_per_ray, "lane_loads_g_s": ext["lane_loads_g_s"],
             "l1_request_peak_g_s": L1_REQUEST_PEAK_G,
             "lanes_per_instr": ext["lanes_per_instr"],
@@ -496,12 +519,18 @@ def _main():
             "valu_instr_per_ray": None, "valu_lane_instr_per_ray": None,
             "wait_share": ext["wait_share"],
             "traffic": ext["traffic"], "hbm_gbs": ext["hbm_gbs"], "hbm_frac": ext["hbm_frac"], "l2_hit_rate": ext["l2_hit_rate"],
-            "algorithmic_bytes_per_launch": alg_bytes / launches,
-            "algorithmic_gbs": alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else None,
-            "bytes_per_ray": b_ray, "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+            # SURVEY 8(d)'s byte model: what the traversal ASKS of the memory hierarchy if every record came from HBM.  Not a
+            # bound (LDS serves half of the node visits, L2 most of the rest): above the HBM peak by construction
+            "survey_byte_model": {"bytes_per_ray": b_ray, "bytes_per_launch": alg_bytes / launches, "gbs_if_all_from_hbm": survey_gbs,
+                                  "note": "not a roofline: the top of the tree is read from LDS and L2"},
+            "traffic_over_survey_model": (ext["traffic"] / (alg_bytes / launches)) if (ext["traffic"] and alg_bytes > 0) else None,
+            "nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
             "launches": int(launches), "avg_launch_ms": ext_ms / launches,
             "extend_ms": ext_ms, "shade_ms": st["shade_kernel_ms"], "connect_ms": st["connect_kernel_ms"],
             "other_kernels": {"k_trace<ConnectIO>": con, "k_shade": shd},
+            # the counters were NOT measured in this run (they cannot be read in-process): they are the committed rocprofv3
+            # passes over the same command line and the same device code; the times they are divided by ARE this run's
+            "counters_from": ("committed PMC file " + pmc_src) if pmc else None,
             "pmc": pmc_src,
         }
         if pmc and pmc.get("k_trace_extend") and ext_traced0 > 0:
@@ -534,6 +563,8 @@ def _main():
                 "max_depth": 50,
                 "parallelism": "tile%d" % world if world > 1 else "single",
                 "collective": ("%s, %d rank(s), one gather of HDR tiles" % (dist.get_backend(), world)) if dist is not None else None,
+                # the gather alone (device copy of the accumulate buffer + dist.gather + rank 0's scatter), max over ranks; inside `elapsed`
+                "gather_ms": gather_s * 1e3 if dist is not None else None,
                 "extension_rays": int(traced_ext),
                 "shadow_rays": int(sh_rays),
                 "primary_memo": bool(memoised > 0),
@@ -542,9 +573,10 @@ def _main():
                 "bvh_build_ms": st["bvh_build_ms"],
                 "scene_upload_ms": upload_s * 1e3,
                 "library_digest": digest,
+                "kernel_digest": kernel_digest,  # of the three render kernels' instruction streams: what the counter files belong to
                 "per_rank": [{"rank": r, "elapsed_s": float(v[0]), "traced_rays": int(v[1]), "samples": int(v[2]), "pixels": int(v[3]),
                               "kernel_ms": float(v[4]), "launches": int(v[5]), "device_bytes": int(v[6]),
-                              "render_call_s": float(v[7]), "scene_upload_s": float(v[8])} for r, v in enumerate(per_rank)],
+                              "render_call_s": float(v[7]), "scene_upload_s": float(v[8]), "gather_s": float(v[9])} for r, v in enumerate(per_rank)],
             },
             "roofline": roof,
         }

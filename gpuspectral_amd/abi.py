@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-GSP_ABI_VERSION = 6
+GSP_ABI_VERSION = 7
 
 BSDF_DIFFUSE = 0
 BSDF_SMOOTH_DIELECTRIC = 1
@@ -137,13 +137,13 @@ class RenderParams(C.Structure):
         ("timestamps_in_flight", C.c_uint32),
         ("collect_traversal_stats", C.c_uint32),
         ("collect_kernel_times", C.c_uint32),
-        ("nee", C.c_uint32),  # (ABI 5) RenderParams.nee, PathTracer.h:36-41; 1 = the shipped shader (`#define NEE true`)
+        ("disable_nee", C.c_uint32),  # (ABI 7) RenderParams.nee inverted, PathTracer.h:36-41; 0 = the shipped shader (`#define NEE true`)
     ]
 
 
 def default_render_params(spp=1, first_timestamp=0):
     """The reference's shader literals: raygen.rgen:27,60,66; rayhit.rchit:656."""
-    return RenderParams(spp, first_timestamp, 50, 10, 20.0, 0, 0, 0, 1)
+    return RenderParams(spp, first_timestamp, 50, 10, 20.0, 0, 0, 0, 0)
 
 
 GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2

@@ -81,6 +81,9 @@ enum { T_NEXT = 0, T_SHADOW = 1, T_FIN_EXT = 2, T_FIN_SH = 4 };  // within a tai
 enum { C_LIVE = 2 * kTailSet, C_READBACK = C_LIVE + kMaxSlots,
        C_WORK_EXT = ((C_READBACK + 31) / 32) * 32, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
        C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
+#ifdef GSP_SHADE_PROFILE
+__device__ unsigned long long g_shade_profile[PR_COUNT * 4];
+#endif
 struct DevStats {
   unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays, sh_occluded, sh_occluded_nodes, lds_nodes, sh_lds_nodes;
 };
@@ -325,6 +328,9 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave start in the global queues
   __shared__ q4 s_hq[kShadeBlock], s_p0[kShadeBlock], s_p1[kShadeBlock], s_p2[kShadeBlock], s_p3[kShadeBlock];
   for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxSlots; k += kShadeBlock) s_dead[k] = 0;
+#ifdef GSP_SHADE_PROFILE
+  for (uint32_t k = threadIdx.x; k < (uint32_t)PR_COUNT * 4; k += kShadeBlock) gsp_prof_table()[k] = 0;
+#endif
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
@@ -336,8 +342,13 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   for (uint32_t it = 0; it < iters; ++it) {
     // ---- order the tile by the BSDF type of the hit (8 = miss, 9 = beyond the queue) so that the
     // lanes of a wave run the same branch of the 8-way BSDF switch (rayhit.rchit:630-654): LDS
-    // counting sort of 1024 keys
+    // counting sort of the tile's keys, laid out back to back.  (r05: on the bench scene that leaves three pure diffuse waves
+    // and one wave with every other type of the tile, for which the others wait at the compaction barrier -- the lane profile,
+    // profiles/r05_shade_lane_profile.txt; dealing the keys over the waves halves that wait and does not make the kernel
+    // faster, profiles/r05_ab_shade_placement.txt, scripts/experiments/r05_shade_balanced_placement.patch)
     const uint32_t tile = it * stride + blockIdx.x * kShadeBlock;
+    GSP_PROF_BEGIN(PR_TILE);
+    GSP_PROF_BEGIN(PR_LOADSORT);
     {
       if (threadIdx.x < 12) s_bin[threadIdx.x] = 0;
       __syncthreads();
@@ -368,13 +379,24 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       s_order[s_bin[key] + rank] = (uint16_t)threadIdx.x;
       __syncthreads();
     }
+    GSP_PROF_END(PR_LOADSORT);
     const uint32_t src = s_order[threadIdx.x];
     const uint32_t i = tile + src;
     bool alive = false, has_shadow = false;
     uint32_t my_sid = 0;
     ShadeOut out;
     q4 sum = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+#ifdef GSP_SHADE_PROFILE
+    {  // how many sort keys (BSDF types, miss, beyond the queue) share this wave?
+      const q4 hk = s_hq[src];
+      const uint32_t wk = fb(hk.w), key2 = (i < n) ? ((wk == 0xffffffffu) ? 8u : ((wk >> 28) & 7u)) : 9u;
+      int kinds = 0;
+      for (uint32_t k = 0; k < 10; ++k) kinds += __ballot(key2 == k) != 0ull;
+      if (lane == 0) atomicAdd(gsp_prof_table() + 4 * (PR_TYPES_IN_WAVE + kinds), 1ull);
+    }
+#endif
     if (i < n) {
+      GSP_PROF_BEGIN(PR_FETCH);
       const q4 hq = s_hq[src];
       const q4 p0 = s_p0[src], p1 = s_p1[src], p2 = s_p2[src];
       sum = s_p3[src];  // the sample's sum so far + the flags word
@@ -388,7 +410,9 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
         const uint32_t w = fb(hq.w);
         h.slot = (w == 0xffffffffu) ? -1 : (int32_t)(w & 0x0fffffffu);
       }
+      GSP_PROF_END(PR_FETCH);
       if (h.slot >= 0) {  // miss: miss.rmiss:15-18, the path ends and adds nothing
+        GSP_PROF_BEGIN(PR_VERTEX);
         PathState in;
         in.o = mk3(p0.x, p0.y, p0.z);
         in.d = mk3(p0.w, p1.x, p1.y);
@@ -402,6 +426,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
         has_shadow = out.has_shadow;
         ++shaded;
         if (!has_shadow) add_emitted(rc.clamp, out.emitted, sum);  // (else k_trace<ConnectIO> adds the bounce's terms)
+        GSP_PROF_END(PR_VERTEX);
       } else if (TEX && S.tex.env_texels != nullptr) {  // escaped: environment radiance, then the path ends
         PathState in;
         in.d = mk3(p0.w, p1.x, p1.y);
@@ -413,6 +438,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     }
     // paths that ended here leave their sample slot's live count (a slot is resolved when it
     // reaches 0): summed per block in LDS, flushed once at the end of the kernel
+    GSP_PROF_BEGIN(PR_COMPACT);
     {
       const bool died = (i < n) && !alive;
       uint64_t dm = __ballot(died);
@@ -446,6 +472,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     }
     __syncthreads();
     const uint32_t j = s_base[0][wave] + (uint32_t)__popcll(am & lt_mask);
+    GSP_PROF_END(PR_COMPACT);
+    GSP_PROF_BEGIN(PR_WRITE);
     // both outcomes of a bounce with a shadow ray, by the function k_finish and the host harness apply once the verdict is
     // known; the UNOCCLUDED one is written where it belongs right here, the occluded one travels with the shadow ray
     q4 clear = sum, occ = sum;
@@ -469,8 +497,14 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(alive ? j : 0xffffffffu)));
       qst(&sq.S3[s], mkq(occ.x, occ.y, occ.z, ub(alive ? out.next.flags : r.sid)));
     }
+    GSP_PROF_END(PR_WRITE);
+    GSP_PROF_END(PR_TILE);
   }
   __syncthreads();
+#ifdef GSP_SHADE_PROFILE
+  for (uint32_t k = threadIdx.x; k < (uint32_t)PR_COUNT * 4; k += kShadeBlock)
+    if (gsp_prof_table()[k]) atomicAdd(&g_shade_profile[k], gsp_prof_table()[k]);
+#endif
   for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxSlots; k += kShadeBlock)
     if (s_dead[k]) atomicSub(&live[k], s_dead[k]);
   shaded = wave_sum(shaded);
@@ -847,7 +881,7 @@ void gsp_default_render_params(gsp_render_params* p) {
   p->max_depth = 50;       // raygen.rgen:27
   p->rr_start_depth = 10;  // raygen.rgen:66
   p->clamp = 20.0f;        // raygen.rgen:60
-  p->nee = 1;              // `#define NEE true`, rayhit.rchit:656
+  p->disable_nee = 0;      // `#define NEE true`, rayhit.rchit:656
 }
 
 int gsp_abi_version(void) { return GSP_ABI_VERSION; }
@@ -1127,6 +1161,7 @@ static int bake_and_build(gsp_context* ctx, bool refit = false, bool* refitted =
   int rc = build_bvh(st, bi, ctx->bvh, ctx->err);  // (synchronises the stream: inv_t / tri_first may go out of scope)
   if (rc != GSP_OK) {
     (void)hipStreamSynchronize(st);  // ... also on a failed build: the uploads above read host vectors of this frame
+    free_bvh(ctx->bvh);              // whatever the failed build had allocated: nothing of it is counted in ctx->bytes
     return rc;
   }
   ctx->bytes += ctx->bvh.bytes;
@@ -1409,7 +1444,7 @@ static RenderConsts render_consts(const gsp_context* ctx) {
   rcst.max_depth = rp->max_depth;
   rcst.rr_start_depth = rp->rr_start_depth;
   rcst.clamp = rp->clamp;
-  rcst.nee = rp->nee != 0 ? 1u : 0u;
+  rcst.nee = rp->disable_nee != 0 ? 0u : 1u;
   // raygen.rgen:22, tan() evaluated once on the host
   rcst.zplane = (std::max((float)ctx->width, (float)ctx->height) / 2.0f) / tanf(ctx->camera.fov / 2.0f);
   for (int i = 0; i < 16; ++i) rcst.cam_to_world[i] = ctx->camera.to_world[i];
@@ -1457,15 +1492,8 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays, nullptr, nullptr, &ctx->dstats.p->lds_nodes};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays, &ctx->dstats.p->sh_occluded,
                             &ctx->dstats.p->sh_occluded_nodes, &ctx->dstats.p->sh_lds_nodes};
-  if (rp->collect_traversal_stats >= 2) {  // per-record visit counts of the closest-hit rays (measurement hook)
-    const size_t nn = std::max<size_t>(ctx->bvh.num_nodes, 1), ns = (size_t)ctx->bvh.num_tris + ctx->bvh.first_slot + kWide;
-    if (ctx->node_hist.count < nn || ctx->tri_hist.count < ns) {
-      CTX_TRY(ctx, ctx->node_hist.ensure(nn, &ctx->bytes));
-      CTX_TRY(ctx, ctx->tri_hist.ensure(ns, &ctx->bytes));
-      CTX_TRY(ctx, hipMemsetAsync(ctx->node_hist.p, 0, ctx->node_hist.count * sizeof(uint32_t), st));
-      CTX_TRY(ctx, hipMemsetAsync(ctx->tri_hist.p, 0, ctx->tri_hist.count * sizeof(uint32_t), st));
-    }
-    so_ext.node_hist = ctx->node_hist.p;
+  if (rp->collect_traversal_stats >= 2) {  // per-record visit counts of the closest-hit rays (measurement hook; the two
+    so_ext.node_hist = ctx->node_hist.p;   // histograms are allocated and zeroed by gsp_render before any lane runs)
     so_ext.tri_hist = ctx->tri_hist.p;
   }
   const uint64_t n = P.n;  // exact, or an upper bound of what this iteration traces
@@ -1743,7 +1771,7 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   if (ctx->pipe_active &&
       (ctx->pipe_params.max_depth != rp->max_depth || ctx->pipe_params.rr_start_depth != rp->rr_start_depth ||
        ctx->pipe_params.clamp != rp->clamp || ctx->pipe_params.timestamps_in_flight != rp->timestamps_in_flight ||
-       (ctx->pipe_params.nee != 0) != (rp->nee != 0))) {
+       (ctx->pipe_params.disable_nee != 0) != (rp->disable_nee != 0))) {
     int rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
   }
@@ -1816,6 +1844,18 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     ctx->pipe_active = true;
   }
   ctx->pipe_params = *rp;  // (stats / timing flags may change from call to call)
+  if (rp->collect_traversal_stats >= 2) {
+    // the visit histograms belong to the context, every lane's k_trace adds to them on its own stream: allocate and zero them
+    // here, on the context's stream, and wait -- not on the stream of whichever lane happens to enqueue first
+    const size_t nn = std::max<size_t>(ctx->bvh.num_nodes, 1), ns = (size_t)ctx->bvh.num_tris + ctx->bvh.first_slot + kWide;
+    if (ctx->node_hist.count < nn || ctx->tri_hist.count < ns) {
+      CTX_TRY(ctx, ctx->node_hist.ensure(nn, &ctx->bytes));
+      CTX_TRY(ctx, ctx->tri_hist.ensure(ns, &ctx->bytes));
+      CTX_TRY(ctx, hipMemsetAsync(ctx->node_hist.p, 0, ctx->node_hist.count * sizeof(uint32_t), ctx->stream));
+      CTX_TRY(ctx, hipMemsetAsync(ctx->tri_hist.p, 0, ctx->tri_hist.count * sizeof(uint32_t), ctx->stream));
+      CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
   for (uint32_t l = 0; l < ctx->num_lanes; ++l) {
     gsp_context::Pipeline& P = ctx->lanes[l].pipe;
     if (!P.active) continue;
@@ -1825,6 +1865,15 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
   return pipeline_run(ctx, false);
 }
 
+#ifdef GSP_SHADE_PROFILE
+// measurement build only (scripts/shade_lane_profile.py): read and clear the lane profile of k_shade
+extern "C" void gsp_debug_shade_profile(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsp::g_shade_profile), PR_COUNT * 4 * sizeof(unsigned long long));
+  static const unsigned long long zero[PR_COUNT * 4] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(gsp::g_shade_profile), zero, sizeof(zero));
+}
+#endif
 #ifdef GSP_WAVE_PROFILE
 extern "C" void gsp_debug_wave_profile(unsigned long long* out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsp::g_wave_profile), 16 * sizeof(unsigned long long));

@@ -17,6 +17,43 @@
 
 namespace gsp {
 
+// ---- lane profile of k_shade (measurement build only: -DGSP_SHADE_PROFILE, scripts/shade_lane_profile.py) -----------------
+// A REGION is a stretch of code entered and left by the same lanes of a wave; at its end the first active lane adds
+// {1, lanes enabled, shader cycles, cycles x lanes} to the block's LDS table (flushed to g_shade_profile by k_shade).
+// Regions nest; cycles are the wave's wall time in the region (its own issue + whatever it waited for).
+enum ShadeRegion {
+  PR_TILE = 0, PR_LOADSORT, PR_FETCH, PR_VERTEX, PR_PACKET, PR_SAMPLE, PR_LIGHT, PR_EVAL, PR_TAIL, PR_COMPACT, PR_WRITE, PR_MISS,
+  PR_SAMPLE_T0 = 16,  // + BSDF type (8)
+  PR_EVAL_T0 = 24,    // + BSDF type (8)
+  PR_TYPES_IN_WAVE = 32,  // + distinct sort keys in the wave (1..10): entries only
+  PR_COUNT = 48
+};
+#if defined(GSP_SHADE_PROFILE) && defined(__HIPCC__)
+__device__ __forceinline__ unsigned long long* gsp_prof_table() {
+  __shared__ unsigned long long s_prof[PR_COUNT * 4];
+  return s_prof;
+}
+__device__ __forceinline__ void gsp_prof_end(int id, unsigned long long t0) {
+  const unsigned long long dt = __builtin_readcyclecounter() - t0;
+  const unsigned long long m = __ballot(1);
+  const unsigned long long n = (unsigned long long)__popcll(m);
+  if ((int)(threadIdx.x & 63) == __ffsll(m) - 1) {
+    unsigned long long* p = gsp_prof_table() + 4 * id;
+    atomicAdd(p, 1ull);
+    atomicAdd(p + 1, n);
+    atomicAdd(p + 2, dt);
+    atomicAdd(p + 3, dt * n);
+  }
+}
+#define GSP_PROF_BEGIN(id) const unsigned long long prof_t0_##id = __builtin_readcyclecounter()
+#define GSP_PROF_END(id) gsp_prof_end(id, prof_t0_##id)
+#define GSP_PROF_END_T(id, base, type) gsp_prof_end((base) + (int)(type), prof_t0_##id)
+#else
+#define GSP_PROF_BEGIN(id) ((void)0)
+#define GSP_PROF_END(id) ((void)0)
+#define GSP_PROF_END_T(id, base, type) ((void)0)
+#endif
+
 // ---- RNG -------------------------------------------------------------------
 GSP_HD uint32_t pcg_output(uint32_t state) {
   uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
@@ -341,11 +378,14 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
   wi = mk3(0.0f, 0.0f, 1.0f);
   switch (handle >> 16) {
     case GSP_BSDF_DIFFUSE: {  // :341-349
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       wi = sample_cosine_hemisphere(rng);
       r.f = (kd_on ? kd : ld3(T.diffuse[i].reflectance)) / kPi;
       r.pdf = cosine_pdf(wi);
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_DIFFUSE);
     } break;
     case GSP_BSDF_SMOOTH_DIELECTRIC: {  // :362-398
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_smooth_dielectric_bsdf b = T.smooth_dielectric[i];
       bool entering = wo.z > 0.0f;
       float no = entering ? b.ior_out : b.ior_in;
@@ -362,6 +402,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
         wi = mirror(wo);
         r.f = 1.0f * splat(1.0f / gabs(cosTho));
         r.pdf = 1.0f;
+        GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_SMOOTH_DIELECTRIC);
         break;
       }
       float cosTht = gsqrt(sqrtTerm);
@@ -378,16 +419,20 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
         r.f = splat((((no * no) / (nt * nt)) * (1.0f - Fr)) / gabs(wt.z));
         r.pdf = 1.0f - Fr;
       }
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_SMOOTH_DIELECTRIC);
     } break;
     case GSP_BSDF_SMOOTH_CONDUCTOR: {  // :406-418
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_smooth_conductor_bsdf b = T.smooth_conductor[i];
       float Fr = b.ior_in == 0.0f ? 1.0f : fresnel_wo(wo, b.ior_out, b.ior_in);
       wi = mirror(wo);
       r.f = Fr * splat(1.0f / gabs(wo.z));
       r.delta = true;
       r.pdf = 1.0f;
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_SMOOTH_CONDUCTOR);
     } break;
     case GSP_BSDF_SMOOTH_PLASTIC: {  // :461-491
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_smooth_plastic_bsdf b = T.smooth_plastic[i];
       float u = rand_uniform(rng);
       float no = b.ior_out, nt = b.ior_in;
@@ -407,8 +452,10 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
         r.f = ((((kD * eta) * eta) * (1.0f - Fri)) * (1.0f - Fro)) / (kPi * (1.0f - kD * Ri));
         r.pdf = (1.0f - Fri) * cosine_pdf(wi);
       }
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_SMOOTH_PLASTIC);
     } break;
     case GSP_BSDF_ROUGH_CONDUCTOR: {  // :508-520
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_rough_conductor_bsdf b = T.rough_conductor[i];
       f3 Fr = fresnel_conductor(ld3(b.eta), ld3(b.k), gabs(wo.z));
       f3 wh = sample_half_beckmann(rng, b.alpha);
@@ -416,8 +463,10 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       r.f = ((((kd_on ? kd : ld3(b.reflectance)) * Fr) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
             ((4.0f * gabs(wi.z)) * gabs(wo.z));
       r.pdf = (beckmann_d(wh, b.alpha) * gabs(wh.z)) / (4.0f * gabs(dot(wo, wh)));
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_ROUGH_CONDUCTOR);
     } break;
     case GSP_BSDF_SMOOTH_FLOOR: {  // :428-449
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_smooth_floor_bsdf b = T.smooth_floor[i];
       float Fr = schlick(b.r0, gabs(wo.z));
       float u = rand_uniform(rng);
@@ -431,18 +480,23 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
         r.f = ld3(b.diffuse) * coupled_diffuse(b.r0, gabs(wo.z), gabs(wi.z));
         r.pdf = (1.0f - Fr) * cosine_pdf(wi);
       }
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_SMOOTH_FLOOR);
     } break;
     case GSP_BSDF_ROUGH_FLOOR: {  // :583-604
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_rough_floor_bsdf b = T.rough_floor[i];
       wi = sample_half_or_cosine(rng, wo, b.alpha);
       rough_floor_value(b, wo, wi, r);
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_ROUGH_FLOOR);
     } break;
     case GSP_BSDF_ROUGH_PLASTIC: {  // :532-563
+      GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_rough_plastic_bsdf b = T.rough_plastic[i];
       wi = sample_half_or_cosine(rng, wo, b.alpha);
       f3 wh;
       rough_plastic_value(b, wo, wi, wh, r.f, kd_on, kd);
       r.pdf = microfacet_pdf_half(wo, wh, b.alpha) + 0.5f * cosine_pdf(wi);
+      GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_ROUGH_PLASTIC);
     } break;
     default: break;
   }
@@ -455,16 +509,19 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
   r.pdf = 0.0f;
   r.delta = false;
   switch (handle >> 16) {
-    case GSP_BSDF_DIFFUSE:  // :351-358
+    case GSP_BSDF_DIFFUSE: {  // :351-358
+      GSP_PROF_BEGIN(PR_EVAL_T0);
       r.f = (kd_on ? kd : ld3(T.diffuse[i].reflectance)) / kPi;
       r.pdf = cosine_pdf(wi);
-      break;
+      GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_DIFFUSE);
+    } break;
     case GSP_BSDF_SMOOTH_DIELECTRIC:  // :400-404
     case GSP_BSDF_SMOOTH_CONDUCTOR:   // :420-426
       r.pdf = 1.0f;
       r.delta = true;
       break;
     case GSP_BSDF_SMOOTH_PLASTIC: {  // :493-506
+      GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_smooth_plastic_bsdf b = T.smooth_plastic[i];
       float no = b.ior_out, nt = b.ior_in;
       float Fri = fresnel_cos(gabs(wo.z), no, nt);
@@ -472,30 +529,39 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
       float Ri = escape_fraction(b.r0, no, nt);
       r.f = plastic_diffuse(ld3(b.diffuse), Fri, Fro, no / nt, Ri);
       r.pdf = (1.0f - Fri) * cosine_pdf(wi);
+      GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_SMOOTH_PLASTIC);
     } break;
     case GSP_BSDF_ROUGH_CONDUCTOR: {  // :522-530
+      GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_rough_conductor_bsdf b = T.rough_conductor[i];
       f3 Fr = fresnel_conductor(ld3(b.eta), ld3(b.k), gabs(wo.z));
       f3 wh = normalize(wo + wi);
       r.f = (((Fr * (kd_on ? kd : ld3(b.reflectance))) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
             ((4.0f * gabs(wi.z)) * gabs(wo.z));
       r.pdf = (beckmann_d(wh, b.alpha) * gabs(wh.z)) / (4.0f * gabs(dot(wo, wh)));
+      GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_ROUGH_CONDUCTOR);
     } break;
     case GSP_BSDF_SMOOTH_FLOOR: {  // :451-458
+      GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_smooth_floor_bsdf b = T.smooth_floor[i];
       float Fr = schlick(b.r0, gabs(wo.z));
       r.f = ld3(b.diffuse) * coupled_diffuse(b.r0, gabs(wo.z), gabs(wi.z));
       r.pdf = (1.0f - Fr) * cosine_pdf(wi);
+      GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_SMOOTH_FLOOR);
     } break;
-    case GSP_BSDF_ROUGH_FLOOR:  // :606-617
+    case GSP_BSDF_ROUGH_FLOOR: {  // :606-617
+      GSP_PROF_BEGIN(PR_EVAL_T0);
       rough_floor_value(T.rough_floor[i], wo, wi, r);
-      break;
+      GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_ROUGH_FLOOR);
+    } break;
     case GSP_BSDF_ROUGH_PLASTIC: {  // :565-582
+      GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_rough_plastic_bsdf b = T.rough_plastic[i];
       f3 wh;
       rough_plastic_value(b, wo, wi, wh, r.f, kd_on, kd);
       r.pdf = (0.5f * gmax(beckmann_d(wh, b.alpha) * gabs(wh.z), 0.01f)) / (4.0f * gabs(dot(wo, wh))) +
               0.5f * cosine_pdf(wi);
+      GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_ROUGH_PLASTIC);
     } break;
     default: break;
   }

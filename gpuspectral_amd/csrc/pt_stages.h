@@ -114,6 +114,7 @@ template <bool TEX = false>
 GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathState& in, const HitRec& hit,
                          ShadeOut& out) {
   uint32_t rng = in.seed;                                                 // rchit:668
+  GSP_PROF_BEGIN(PR_PACKET);
   const q4* sp = S.tri_shade + 4ll * hit.slot;
   const q4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
   const uint32_t material = f2u(s0.w);                                    // :672 (instance record, baked per triangle)
@@ -148,7 +149,11 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   }
   BsdfResult bs;
   f3 wi_l;
+  GSP_PROF_END(PR_PACKET);
+  GSP_PROF_BEGIN(PR_SAMPLE);
   bsdf_sample(S.bsdf, bsdf, rng, wo, wi_l, bs, kd_on, kd);           // :716
+  GSP_PROF_END(PR_SAMPLE);
+  GSP_PROF_BEGIN(PR_LIGHT);
   const float NoW = gabs(wi_l.z);                                         // :717
   const f3 wi = to_world(onb, wi_l);                                      // :718
 
@@ -160,7 +165,11 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   const float NoL = gabs(dot(SN, L));                                     // :725
   const float lightPdf = ls.pdf;
   BsdfResult lb;
+  GSP_PROF_END(PR_LIGHT);
+  GSP_PROF_BEGIN(PR_EVAL);
   bsdf_eval(S.bsdf, bsdf, wo, wL, lb, kd_on, kd);                    // :729
+  GSP_PROF_END(PR_EVAL);
+  GSP_PROF_BEGIN(PR_TAIL);
 
   const bool transmits = bsdf_transmits(bsdf);
   const float NdotV = dot(N, -rayDir);
@@ -220,6 +229,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
     out.shadow.sid = in.sid;
     out.shadow.next = -1;
   }
+  GSP_PROF_END(PR_TAIL);
 }
 
 // dormant-feature extension: a path that leaves the scene (miss.rmiss:15-18 ends it) first picks up the environment

@@ -193,10 +193,12 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   // the top of the tree: every ray starts there, and a fetch from LDS is not one of the divergent 16-B requests of which
   // the vector-memory path takes one per cycle and CU (scripts/microbench/lane_fetch.hip) -- the rate both traversal
   // kernels run at
-  // (r04: a quad-major copy -- quad k of node n at lds_top[k * kTopNodes + n], so that lanes reading the same quad of different
-  // nodes spread over all 32 banks instead of 2 of the 8 four-bank groups -- halves SQ_LDS_BANK_CONFLICT (1.89e8 -> 0.90e8 per
-  // closest-hit launch, 6.6e7 -> 1.2e7 any-hit) and changes the closest-hit kernel by nothing, the any-hit kernel by +2.5 %
-  // (one more address op per LDS node step): the replays are hidden behind the other six waves.  profiles/r04_ab_lds_layout.txt)
+  // The copy is RECORD-major (node n = lds_top[4 n .. 4 n + 3], read with four ds_read_b128 at one address + offsets).  A
+  // quad-major copy (quad k of node n at lds_top[k * kTopNodes + n], so that lanes reading the same quad of different nodes
+  // spread over all 32 banks instead of 2 of the 8 four-bank groups) was tried in r04 and NOT kept: it halves
+  // SQ_LDS_BANK_CONFLICT (1.89e8 -> 0.90e8 per closest-hit launch, 6.6e7 -> 1.2e7 any-hit), changes the closest-hit kernel by
+  // nothing and makes the any-hit kernel 2.5 % slower (one more address op per LDS node step): the replays are hidden behind
+  // the other six waves.  profiles/r04_ab_lds_layout.txt
   __shared__ q4 lds_top[kTopNodes > 0 ? kTopNodes * kNodeQuads : 1];
   for (uint32_t i = threadIdx.x; i < kTopNodes * kNodeQuads; i += kTraceBlock) lds_top[i] = nodes[i];
   __syncthreads();

@@ -103,6 +103,10 @@ void PathTracer::check(int rc, const char* what) {
 
 // PathTracer.cpp:5-7
 void PathTracer::setup() {
+  // gsp_render_params / gsp_stats carry no struct_size: the header this file was compiled against must be the library's
+  if (gsp_abi_version() != GSP_ABI_VERSION)
+    throw std::runtime_error("libgpuspectral_pt.so has ABI " + std::to_string(gsp_abi_version()) + ", this host was built against ABI " +
+                             std::to_string(GSP_ABI_VERSION));
   int rc = gsp_ctx_create_ex(device, &options, &ctx);
   if (rc != GSP_OK) throw std::runtime_error(std::string("gsp_ctx_create_ex: ") + gsp_last_error(nullptr));
   check(gsp_frame_begin(ctx, width, height, pixelIds.empty() ? nullptr : pixelIds.data(), pixelIds.size()),

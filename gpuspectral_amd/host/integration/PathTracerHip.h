@@ -33,7 +33,7 @@ class PathTracerHip : public RenderPassCreator {
     if (!sameMeshes(scene)) upload(scene);  // meshes -> device once: the reference's BLAS cache (Renderer.cpp:122-131)
     else refresh(scene);                    // what the reference re-reads every frame (PathTracer.cpp:10-19,58-93)
     gsp_render_params p;
-    gsp_default_render_params(&p);          // MAX_DEPTH 50, RR > 10, clamp 20, nee 1
+    gsp_default_render_params(&p);          // MAX_DEPTH 50, RR > 10, clamp 20, NEE on
     p.spp = 1;
     p.first_timestamp = (uint32_t)timestamp++;  // renderState.params.timestamp, PathTracer.cpp:91-92
     check(gsp_render(ctx, &p));
@@ -108,15 +108,23 @@ class PathTracerHip : public RenderPassCreator {
     uploaded = true;
   }
   // Each call returns before any wait when its input equals what the device holds (the library compares), so an unchanged
-  // scene costs three comparisons; tables go first (an edited instance may name a BSDF the new tables add).
+  // scene costs three comparisons.  Tables go first (an edited instance may name a BSDF the new tables add); when the new
+  // tables DROP a record a resident instance still names, the library refuses them, the instances go first and the tables
+  // are sent again; an edit that needs both orders at once is a full upload (as host/PathTracer.cpp::prepareScene does).
   void refresh(const Scene& s) {
     gsp_scene_desc d{};
     fillTables(s, d);
     std::vector<gsp_instance> inst;
     instancesOf(s, inst, nullptr, nullptr);
-    check(gsp_update_tables(ctx, &d));                                          // PathTracer.cpp:74-87
-    check(gsp_update_instances(ctx, inst.data(), (uint32_t)inst.size()));       // PathTracer.cpp:10-19,60-70 (TLAS + Instance records)
-    check(gsp_update_camera(ctx, &d.camera));                                   // PathTracer.cpp:88-90
+    const int rcT = gsp_update_tables(ctx, &d);                                          // PathTracer.cpp:74-87
+    const int rcI = gsp_update_instances(ctx, inst.data(), (uint32_t)inst.size());      // PathTracer.cpp:10-19,60-70 (TLAS + Instance records)
+    if (rcT != GSP_OK && rcI == GSP_OK) check(gsp_update_tables(ctx, &d));
+    else if (rcT != GSP_OK || rcI != GSP_OK) {
+      uploaded = false;
+      upload(s);
+      return;
+    }
+    check(gsp_update_camera(ctx, &d.camera));                                            // PathTracer.cpp:88-90
   }
   void check(int rc) {
     if (rc) throw std::runtime_error(gsp_last_error(ctx));  // the reference's convention: exceptions

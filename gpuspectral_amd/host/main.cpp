@@ -4,7 +4,7 @@
 //   gsp_render [--dormant-features] [--no-nee] [--memory-share F] [--pool-paths N] <scene.xml> <out.pfm> [width height spp [devices]]
 //   devices: "0" (default) or a list "0,1,2,3": the frame is then tiled over those GPUs (MultiGpuPathTracer); an index
 //   may repeat.  --dormant-features: LoadOptions::dormantFeatures (bitmap / checkerboard textures, envmap emitter);
-//   --no-nee: RenderParams.nee = 0; --memory-share / --pool-paths: gsp_ctx_options (how much device memory the path pool takes)
+//   --no-nee: gsp_render_params.disable_nee = 1 (RenderParams.nee = false); --memory-share / --pool-paths: gsp_ctx_options (how much device memory the path pool takes)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
     double s;
     if (devices.size() == 1) {
       PathTracer pt(width, height, devices[0], {}, &ctxOptions);
-      pt.params.nee = nee ? 1u : 0u;
+      pt.params.disable_nee = nee ? 0u : 1u;
       auto t0 = std::chrono::steady_clock::now();
       pt.render(scene, spp);
       img = pt.download();
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
       st = pt.stats();
     } else {
       MultiGpuPathTracer pt(width, height, devices, &ctxOptions);
-      pt.params.nee = nee ? 1u : 0u;
+      pt.params.disable_nee = nee ? 0u : 1u;
       auto t0 = std::chrono::steady_clock::now();
       pt.render(scene, spp);
       img = pt.download();

@@ -134,7 +134,7 @@ def load():
     L.gsp_multi_last_error.argtypes = [vp]
     L.gsp_multi_last_error.restype = C.c_char_p
     v = L.gsp_abi_version()
-    # (exact match: an older library fills arrays of gsp_stats at ITS struct size and knows nothing of gsp_render_params.nee)
+    # (exact match: an older library fills arrays of gsp_stats at ITS struct size and knows nothing of gsp_render_params.disable_nee)
     if v != abi.GSP_ABI_VERSION:
         raise GspError("ABI version mismatch: abi.py is %d, %s is %d" % (abi.GSP_ABI_VERSION, path, v))
     _LIB = L

@@ -57,10 +57,11 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 6 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth;
+#define GSP_ABI_VERSION 7 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth;
                              5: gsp_update_camera / _instances / _tables (+ gsp_multi_*), gsp_ctx_options + gsp_ctx_create_ex /
                                 gsp_multi_create_ex, gsp_render_params.nee, gsp_stats.scene_updates;
-                             6: gsp_update_instances refits the tree (gsp_ctx_options.refit_growth, gsp_stats.scene_refits) */
+                             6: gsp_update_instances refits the tree (gsp_ctx_options.refit_growth, gsp_stats.scene_refits);
+                             7: gsp_render_params.nee -> disable_nee (a zeroed struct is the reference as shipped) */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -245,11 +246,12 @@ typedef struct gsp_render_params {
   uint32_t collect_traversal_stats; /* 1: count BVH nodes / triangles per ray (slower); 2: and per-record visit counts of the
                                        closest-hit rays (gsp_debug_visit_histograms) */
   uint32_t collect_kernel_times;    /* 1: HIP-event time every extend/shade/connect launch (2: and print one line per iteration to stderr) */
-  uint32_t nee;             /* (ABI 5) RenderParams.nee (S/renderer/PathTracer.h:36-41), which the shipped shader replaces by
-                               `#define NEE true` (rayhit.rchit:656).  1 (default) = the reference as shipped.  0 = the other side
-                               of its `if (NEE)` branches (rayhit.rchit:733,763-768): no shadow ray, every emitter met counts
-                               with full weight, directWeight stays 1; the light sample is still DRAWN (rayhit.rchit:720 is
-                               outside the branch), so the random streams of the two settings coincide */
+  uint32_t disable_nee;     /* (ABI 7; ABI 5-6: `nee` with the opposite sense) RenderParams.nee (S/renderer/PathTracer.h:36-41),
+                               which the shipped shader replaces by `#define NEE true` (rayhit.rchit:656).  0 (default, and what a
+                               zero-initialised struct says) = the reference as shipped.  1 = the other side of its `if (NEE)`
+                               branches (rayhit.rchit:733,763-768): no shadow ray, every emitter met counts with full weight,
+                               directWeight stays 1; the light sample is still DRAWN (rayhit.rchit:720 is outside the branch),
+                               so the random streams of the two settings coincide */
 } gsp_render_params;
 
 typedef struct gsp_stats {
@@ -300,7 +302,9 @@ typedef struct gsp_context gsp_context;
 /* Fill `p` with the reference's literals.  */
 void gsp_default_render_params(gsp_render_params* p);
 
-/* ABI version of the loaded library (== GSP_ABI_VERSION of this header). */
+/* ABI version of the loaded library (== GSP_ABI_VERSION of this header).  gsp_render_params and gsp_stats carry no
+ * struct_size: a C host MUST check gsp_abi_version() == GSP_ABI_VERSION once after loading the library (a host built
+ * against an older header would hand gsp_render a shorter struct); gpuspectral_amd/pt.py and host/PathTracer.cpp do. */
 int gsp_abi_version(void);
 
 /* What the loaded library was built from: "arch=gfx950 digest=<sha256[:16] of csrc/{pt_render,pt_bvh,pt_multi}.hip + the

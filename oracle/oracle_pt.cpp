@@ -711,7 +711,7 @@ int oracle_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixe
                   const gsp_render_params* rp, float* accum, int threads, int collect_trav, oracle_stats* out) {
   Oracle* o = (Oracle*)h;
   if (!o || !rp || !accum) return 1;
-  RenderCfg cfg{width, height, rp->max_depth, rp->rr_start_depth, rp->clamp, rp->nee != 0};
+  RenderCfg cfg{width, height, rp->max_depth, rp->rr_start_depth, rp->clamp, rp->disable_nee == 0};
   const uint64_t npix = pixel_ids ? num_pixels : (uint64_t)width * height;
   // raygen.rgen:22  z = (max(size.x,size.y)/2) / tan(fov/2); tan() evaluated on the host
   const float zplane = (gmax((float)width, (float)height) / 2.0f) / tanf(o->S.fov / 2.0f);

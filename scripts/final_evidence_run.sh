@@ -16,6 +16,8 @@ timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_s20_w5.json 2> $O/bench_n1_s20_w5.err
 cp gpurun_out/pmc_${TAG}_s4_w1/summary.txt $O/pmc_summary_s4_w1.txt
 cp gpurun_out/pmc_${TAG}_s20_w5/summary.txt $O/pmc_summary_s20_w5.txt
+cp gpurun_out/pmc_${TAG}_s4_w1/valu_mix_dynamic.json $O/valu_mix_s4_w1.json      # dynamic VALU class mix of the timed launches
+cp gpurun_out/pmc_${TAG}_s20_w5/valu_mix_dynamic.json $O/valu_mix_s20_w5.json
 find gpurun_out/pmc_${TAG}_s4_w1/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_s4_w1.csv \;
 find gpurun_out/pmc_${TAG}_s20_w5/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_s20_w5.csv \;
 SECONDS_=4 timeout 900 python tests/tools/scene_probe.py coffee staircase2 cornell-box living-room interior materials caustics > $O/scene_probe.txt 2>&1

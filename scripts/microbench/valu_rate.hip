@@ -104,6 +104,26 @@ DEFINE_KERNEL(k_dsread_u16, "ds_read_u16 v100, %0\n ds_read_u16 v101, %0 offset:
 DEFINE_KERNEL(k_dswrite_b64, "ds_write_b64 %0, v[100:101]\n ds_write_b64 %0, v[102:103] offset:2048\n ds_write_b64 %0, v[100:101] offset:4096\n ds_write_b64 %0, v[102:103] offset:6144\n")
 DEFINE_KERNEL(k_dsread_b64, "ds_read_b64 v[100:101], %0\n ds_read_b64 v[102:103], %0 offset:2048\n ds_read_b64 v[104:105], %0 offset:4096\n ds_read_b64 v[106:107], %0 offset:6144\n s_waitcnt lgkmcnt(0)\n")
 
+// r05 additions: the rest of the render kernels' opcodes (IEEE division / sqrt expansions of k_shade, the any-hit set-up),
+// so that scripts/valu_class_calib.sh can say which hardware class counter each of them ticks and at what rate it issues
+DEFINE_KERNEL(k_divscale, "v_div_scale_f32 %0, vcc, %0, %4, %5\n v_div_scale_f32 %1, vcc, %1, %4, %5\n v_div_scale_f32 %2, vcc, %2, %4, %5\n v_div_scale_f32 %3, vcc, %3, %4, %5\n")
+K4_3(k_divfmas, "v_div_fmas_f32")
+K4_3(k_divfixup, "v_div_fixup_f32")
+K4_1(k_sqrt, "v_sqrt_f32_e32")
+K4_1(k_rsq, "v_rsq_f32_e32")
+DEFINE_KERNEL(k_cmpclass, "v_cmp_class_f32_e32 vcc, %0, %4\n v_cmp_class_f32_e32 vcc, %1, %4\n v_cmp_class_f32_e32 vcc, %2, %4\n v_cmp_class_f32_e32 vcc, %3, %4\n")
+K4_1(k_rndne, "v_rndne_f32_e32")
+K4_1(k_cvti32, "v_cvt_i32_f32_e32")
+K4_1(k_cvtu32f, "v_cvt_u32_f32_e32")
+DEFINE_KERNEL(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %4, %0\n v_mbcnt_lo_u32_b32 %1, %4, %1\n v_mbcnt_lo_u32_b32 %2, %4, %2\n v_mbcnt_lo_u32_b32 %3, %4, %3\n")
+DEFINE_KERNEL(k_ldexp, "v_ldexp_f32 %0, %0, %4\n v_ldexp_f32 %1, %1, %4\n v_ldexp_f32 %2, %2, %4\n v_ldexp_f32 %3, %3, %4\n")
+K4_3(k_min3f, "v_min3_f32")
+DEFINE_KERNEL(k_cvtscalefp8, "v_cvt_scalef32_pk_f32_fp8 v[100:101], %0, %4\n v_cvt_scalef32_pk_f32_fp8 v[102:103], %1, %4\n v_cvt_scalef32_pk_f32_fp8 v[104:105], %2, %4\n v_cvt_scalef32_pk_f32_fp8 v[106:107], %3, %4\n")
+DEFINE_KERNEL(k_lshladd64, "v_lshl_add_u64 v[100:101], v[102:103], 2, v[104:105]\n v_lshl_add_u64 v[102:103], v[100:101], 2, v[104:105]\n v_lshl_add_u64 v[100:101], v[102:103], 2, v[106:107]\n v_lshl_add_u64 v[102:103], v[100:101], 2, v[106:107]\n")
+DEFINE_KERNEL(k_cmpu64, "v_cmp_lt_u64_e32 vcc, v[100:101], v[102:103]\n v_cmp_lt_u64_e32 vcc, v[104:105], v[106:107]\n v_cmp_lt_u64_e32 vcc, v[100:101], v[102:103]\n v_cmp_lt_u64_e32 vcc, v[104:105], v[106:107]\n")
+K4(k_mulhi, "v_mul_hi_u32")
+K4(k_max3u, "v_max_i32_e32")
+
 typedef void (*kern_t)(int, unsigned long long*, float*);
 struct Entry { const char* name; kern_t k; };
 
@@ -125,7 +145,11 @@ int main() {
                       {"v_fma_mix_f32 (f32 srcs)", k_fmamix}, {"v_fma_mix_f32 (f16 src0 hi/lo)", k_fmamix_hi}, {"v_cvt_pk_f32_fp8", k_cvtpkfp8},
                       {"v_pk_fma_f16", k_pkfmaf16}, {"v_pk_max_f16", k_pkmaxf16}, {"v_pk_min_f16", k_pkminf16}, {"v_mul_lo_u32", k_mullo},
                       {"v_dot2_f32_f16", k_dot2}, {"v_not_b32", k_not}, {"ds_read_u8 (lane-private)", k_dsread_u8}, {"ds_read_u16 (lane-private)", k_dsread_u16},
-                      {"ds_write_b64 (lane-private)", k_dswrite_b64}, {"ds_read_b64 (lane-private)", k_dsread_b64}};
+                      {"ds_write_b64 (lane-private)", k_dswrite_b64}, {"ds_read_b64 (lane-private)", k_dsread_b64},
+                      {"v_div_scale_f32", k_divscale}, {"v_div_fmas_f32", k_divfmas}, {"v_div_fixup_f32", k_divfixup}, {"v_sqrt_f32", k_sqrt}, {"v_rsq_f32", k_rsq},
+                      {"v_cmp_class_f32 -> vcc", k_cmpclass}, {"v_rndne_f32", k_rndne}, {"v_cvt_i32_f32", k_cvti32}, {"v_cvt_u32_f32", k_cvtu32f},
+                      {"v_mbcnt_lo_u32_b32", k_mbcnt}, {"v_ldexp_f32", k_ldexp}, {"v_min3_f32", k_min3f}, {"v_cvt_scalef32_pk_f32_fp8", k_cvtscalefp8},
+                      {"v_lshl_add_u64", k_lshladd64}, {"v_cmp_lt_u64 -> vcc", k_cmpu64}, {"v_mul_hi_u32", k_mulhi}, {"v_max_i32", k_max3u}};
   const int loops = 20000;
   unsigned long long* out; float* sink;
   CHECK(hipMalloc(&out, 1 << 20)); CHECK(hipMalloc(&sink, 4));

@@ -19,6 +19,9 @@ run l2 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
 run sq2 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
 run grbm "GRBM_GUI_ACTIVE"
+# the hardware's VALU class counters: the DYNAMIC instruction mix of the same launches (class membership of every opcode:
+# scripts/valu_class_calib.sh -> profiles/r05_valu_class_calib.txt; issue cost inside a class: lib/valu_mix.json)
+run cls "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
 # kernel-trace only (no counters): the un-serialised durations rocprofv3 sees for the same command
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || echo "trace pass failed"
 # FETCH_SIZE calibration on the traversal's access pattern

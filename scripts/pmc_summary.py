@@ -56,7 +56,7 @@ def read_trace(root, name):
 
 def main(root):
     counters = defaultdict(dict)  # kernel -> counter -> list
-    for p in ("fetch", "write", "l2", "sq1", "sq2", "grbm"):
+    for p in ("fetch", "write", "l2", "sq1", "sq2", "grbm", "cls"):
         for k, cs in read_pass(root, p).items():
             counters[k].update(cs)
     dur = read_trace(root, "trace") or read_trace(root, "grbm")
@@ -124,7 +124,8 @@ def main(root):
             out["bench_config"] = {k: b["config"][k] for k in ("workload", "triangles", "resolution", "spp_per_step", "primary_memo") if k in b["config"]}
             out["steps"], out["warmup"] = b["steps"], b["warmup"]
             out["timed_launches"] = b["roofline"]["launches"]
-            out["library_digest"] = b["config"].get("library_digest")  # bench.py refuses the file for any other build
+            out["library_digest"] = b["config"].get("library_digest")
+            out["kernel_digest"] = b["config"].get("kernel_digest")  # bench.py refuses the file for any other device code
             out["bench_value_under_profiler"] = b["value"]
             print("== bench under the kernel-trace pass: %.1f %s, %d timed k_trace<ExtendIO> launches of %.3f ms (HIP events)" % (
                 b["value"], b["unit"], b["roofline"]["launches"], b["roofline"]["avg_launch_ms"]))
@@ -134,6 +135,34 @@ def main(root):
                 print("   rocprofv3 kernel trace, the same %d launches: avg %.3f ms" % (len(t), sum(t) / len(t) / 1e3))
             break
     json.dump(out, open(os.path.join(root, "pmc_bench.json"), "w"))
+    # ---- dynamic VALU class mix of the timed launches: hardware class counters x issue cost per class
+    mixf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpuspectral_amd", "lib", "valu_mix.json")
+    if os.path.exists(mixf) and out.get("timed_launches"):
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import valu_mix as vmx
+
+        vm = json.load(open(mixf))
+        take = out["timed_launches"]
+        rec = {"source": out["source"], "library_digest": vm.get("library_digest"), "kernel_digest": vm.get("kernel_digest"),
+               "timed_launches": take, "costs_cycles": vm.get("costs_cycles"),
+               "method": "dynamic count per hardware class (rocprofv3 SQ_INSTS_VALU_* summed over the timed launches; OTHER = SQ_INSTS_VALU - the seven) "
+                         "x mean issue cost of the class's instructions in the kernel's binary (scripts/valu_mix.py)", "kernels": {}}
+        print("== dynamic VALU class mix of the timed launches")
+        for kname, k in out["kernels"].items():
+            c = k["counters"]
+            tab = (vm["kernels"].get(kname) or {}).get("classes")
+            if not tab or "SQ_INSTS_VALU_FMA_F32" not in c or len(c.get("SQ_INSTS_VALU", [])) < take:
+                continue
+            total = float(sum(c["SQ_INSTS_VALU"][-take:]))
+            dyn = {cl: float(sum(c.get("SQ_INSTS_VALU_" + cl, [0.0])[-take:])) for cl in vmx.HW_CLASSES[:-1]}
+            cyc, shares = vmx.dynamic_mean_cost(tab, dyn, total)
+            n_static = vm["kernels"][kname]["valu_instructions_static"]
+            rec["kernels"][kname] = {"SQ_INSTS_VALU": total, "mean_issue_cycles_dynamic": cyc, "mean_issue_cycles_static": vm["kernels"][kname]["mean_issue_cycles"],
+                                     "classes": {cl: {"dynamic_share": shares[cl], "static_share": tab[cl]["static"] / n_static,
+                                                      "issue_cycles": tab[cl]["mean_issue_cycles"]} for cl in vmx.HW_CLASSES}}
+            print("   %-16s mean issue cost %.3f cycles (dynamic mix) vs %.3f (static mix of the binary): " % (kname, cyc, vm["kernels"][kname]["mean_issue_cycles"]) +
+                  "  ".join("%s %.1f %% (static %.1f %%)" % (cl, 100 * shares[cl], 100 * tab[cl]["static"] / n_static) for cl in vmx.HW_CLASSES))
+        json.dump(rec, open(os.path.join(root, "valu_mix_dynamic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -297,7 +297,7 @@ int emu_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixel_i
   rc.max_depth = rp->max_depth;
   rc.rr_start_depth = rp->rr_start_depth;
   rc.clamp = rp->clamp;
-  rc.nee = rp->nee != 0 ? 1u : 0u;
+  rc.nee = rp->disable_nee != 0 ? 0u : 1u;
   rc.zplane = (std::max((float)width, (float)height) / 2.0f) / tanf(e->sc.camera.fov / 2.0f);
   for (int i = 0; i < 16; ++i) rc.cam_to_world[i] = e->sc.camera.to_world[i];
   for (int i = 0; i < 3; ++i) rc.cam_origin[i] = e->sc.camera.to_world[12 + i];

@@ -78,7 +78,7 @@ def test_struct_layouts_match_header(tmp_path):
         "sizeof(gsp_scene_desc),sizeof(gsp_render_params),sizeof(gsp_stats),offsetof(gsp_scene_desc,camera),"
         "offsetof(gsp_scene_desc,num_bsdfs));"
         "printf(\"%zu %zu %zu %zu %zu %zu\\n\",sizeof(gsp_ctx_options),offsetof(gsp_ctx_options,memory_share),"
-        "offsetof(gsp_ctx_options,gather_route),offsetof(gsp_render_params,nee),offsetof(gsp_stats,scene_updates),sizeof(gsp_camera));"
+        "offsetof(gsp_ctx_options,gather_route),offsetof(gsp_render_params,disable_nee),offsetof(gsp_stats,scene_updates),sizeof(gsp_camera));"
         "return 0;}\n"
     )
     exe = tmp_path / "sz"
@@ -94,7 +94,7 @@ def test_struct_layouts_match_header(tmp_path):
     # ABI 5
     assert vals[15] == C.sizeof(abi.CtxOptions) and vals[16] == abi.CtxOptions.memory_share.offset
     assert vals[17] == abi.CtxOptions.gather_route.offset
-    assert vals[18] == abi.RenderParams.nee.offset and vals[19] == abi.Stats.scene_updates.offset
+    assert vals[18] == abi.RenderParams.disable_nee.offset and vals[19] == abi.Stats.scene_updates.offset
     assert vals[20] == C.sizeof(abi.Camera)
 
 
@@ -104,9 +104,9 @@ def test_default_params_are_the_reference_literals():
     p = abi.RenderParams()
     pt.load().gsp_default_render_params(C.byref(p))
     assert (p.spp, p.first_timestamp, p.max_depth, p.rr_start_depth, p.clamp) == (1, 0, 50, 10, 20.0)
-    assert p.nee == 1  # `#define NEE true`, rayhit.rchit:656
+    assert p.disable_nee == 0  # `#define NEE true`, rayhit.rchit:656
     q = abi.default_render_params()
-    assert (q.max_depth, q.rr_start_depth, q.clamp, q.nee) == (50, 10, 20.0, 1)
+    assert (q.max_depth, q.rr_start_depth, q.clamp, q.disable_nee) == (50, 10, 20.0, 0)
 
 
 def test_default_ctx_options_and_env_mapping():

@@ -80,6 +80,14 @@ def test_pmc_file_is_refused_for_another_build(tmp_path, monkeypatch):
     assert r["lanes_per_instr"] == pytest.approx(128.0 / 3.0 / 64.0) and r["effective"] == pytest.approx(r["issue_frac"] * r["lanes_per_instr"])
     pmc, src = b.pmc_for_run(cfg, 4, "aaaaaaaaaaaaaaaa")  # another launch count: per-launch averages, said so
     assert pmc["k_trace_extend"]["SQ_INSTS_VALU"] == 6.0 and "scaled" in src
+    # r05: a file that carries the digest of the render kernels' instruction streams belongs to that DEVICE CODE: it survives a
+    # host-only rebuild (another library digest) and is refused for other kernels whatever the library digest says
+    rec["kernel_digest"] = "kkkkkkkkkkkkkkkk"
+    (tmp_path / "pmc_bench_t.json").write_text(json.dumps(rec))
+    pmc, src = b.pmc_for_run(cfg, 2, "bbbbbbbbbbbbbbbb", "kkkkkkkkkkkkkkkk")
+    assert pmc is not None and "kkkkkkkkkkkkkkkk" in src
+    pmc, why = b.pmc_for_run(cfg, 2, "aaaaaaaaaaaaaaaa", "xxxxxxxxxxxxxxxx")
+    assert pmc is None and "stale build" in why
 
 
 def test_committed_counter_files_belong_to_the_library_in_the_tree():
@@ -94,10 +102,16 @@ def test_committed_counter_files_belong_to_the_library_in_the_tree():
     if os.environ.get("GSP_LIB_PATH"):
         pytest.skip("GSP_LIB_PATH points at a build variant")
     digest = g.pt.build_info()["digest"]
+    vm = json.load(open(os.path.join(os.path.dirname(g.lib_path()), "valu_mix.json")))
+    assert vm["library_digest"] == digest, "lib/valu_mix.json is not of this build (make -C gpuspectral_amd/csrc)"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_bench_*.json")))
     assert files
     for f in files:
-        assert json.load(open(f))["library_digest"] == digest, "%s was collected on another build: rerun scripts/final_evidence_run.sh" % os.path.basename(f)
+        rec = json.load(open(f))
+        # r05: the counters belong to the DEVICE CODE of the three render kernels (kernel_digest = sha256 of their instruction
+        # streams, scripts/valu_mix.py), so a host-only change of the library does not invalidate them
+        assert rec.get("kernel_digest") == vm["kernel_digest"] or rec.get("library_digest") == digest, \
+            "%s was collected on other device code: rerun scripts/final_evidence_run.sh" % os.path.basename(f)
 
 
 def test_gpus_defaults_to_world_size(monkeypatch, capsys):

@@ -29,7 +29,7 @@ def test_emu_nee_off_bit_exact(emu, oracle_mod, materials_scene, cornell):
 
     for sc, w, h, spp in ((materials_scene, 48, 48, 6), (cornell, 64, 64, 4)):
         p = abi.default_render_params()
-        p.nee = 0
+        p.disable_nee = 1
         img = emu.scene(sc).render(w, h, spp=spp, params=p)
         ref, st = oracle_mod.Oracle(sc).render(w, h, spp=spp, params=p)
         assert np.array_equal(img, ref)

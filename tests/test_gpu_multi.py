@@ -277,3 +277,105 @@ def test_device_side_gather_pieces_with_torch_on_the_gpu():
     pytest.importorskip("torch")
     r = subprocess.run([sys.executable, "-c", _TORCH_PIECES % ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "torch pieces ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+# ---- N > 1 PHYSICAL GPUs ---------------------------------------------------------------------------
+# Every test above runs on the one GPU of the test pool.  These three need two or more devices and are skipped there (the
+# skip shows up in the suite's summary): the minute a multi-GPU node runs the suite, the real RCCL group over distinct
+# devices and bench.py's one-process-per-GPU path prove themselves against the single-GPU frame, bit for bit.
+def _gpus():
+    import gpuspectral_amd as g
+
+    return g.device_count()
+
+
+needs_two_gpus = pytest.mark.skipif("_gpus() < 2", reason="needs >= 2 physical GPUs (the test pool has one)")
+
+
+@needs_two_gpus
+def test_physical_gpus_rccl_group_materials(materials_scene):
+    """gsp_multi_create_ex(GSP_GATHER_RCCL) over devices 0..n-1: ncclCommInitAll over DISTINCT devices, every share renders on
+    its own GPU, one grouped ncclSend / ncclRecv brings the tiles to device 0 over xGMI; the frame equals one context's."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi, pt
+
+    n = min(_gpus(), 8)
+    W, H, spp = 416, 300, 8
+    with g.Context(0) as ctx:
+        ctx.upload_scene(materials_scene)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        ref = ctx.download()
+        st1 = ctx.stats()
+    with pt.MultiContext(list(range(n)), options=abi.CtxOptions(gather_route=abi.GATHER_RCCL)) as m:
+        assert m.gather_route()[0] == "rccl"
+        m.upload_scene(materials_scene)
+        m.frame_begin(W, H)
+        m.render(spp=spp)
+        img = m.download()
+        route, n_rccl, n_copy = m.gather_route()
+        tot, each = m.stats(per_share=True)
+        assert route == "rccl" and n_rccl >= 1 and n_copy == 0
+        assert np.array_equal(img, ref)
+        assert tot["extension_rays"] == st1["extension_rays"] and tot["shadow_rays"] == st1["shadow_rays"]
+        assert len(each) == n and all(e["samples"] > 0 for e in each)
+        m.frame_begin(W, H)  # a second frame through the same communicator
+        m.render(spp=spp)
+        assert np.array_equal(m.download(), ref)
+    # GSP_GATHER_AUTO over distinct devices takes the RCCL route as well (the copy route is the fallback, not the default)
+    with pt.MultiContext(list(range(n))) as m:
+        assert m.gather_route()[0] == "rccl", m._L.gsp_multi_last_error(m._h).decode()
+
+
+@needs_two_gpus
+def test_physical_gpus_config4_frame():
+    """BASELINE config 4 (bathroom2 stand-in, 1920x1080, image tiles over the GPUs of the node, RCCL gather) at 8 spp on
+    min(devices, 8) physical GPUs: CRC of the gathered frame == the single-GPU frame's."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi, pt, scenes
+
+    n = min(_gpus(), 8)
+    sc = scenes.interior(600_000, seed=7)
+    W, H, spp = 1920, 1080, 8
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        ctx.render(spp=spp)
+        ref = ctx.download()
+        st1 = ctx.stats()
+    with pt.MultiContext(list(range(n)), options=abi.CtxOptions(gather_route=abi.GATHER_RCCL)) as m:
+        m.upload_scene(sc)
+        m.frame_begin(W, H)
+        m.render(spp=spp)
+        img = m.download()
+        tot = m.stats()
+        assert m.gather_route()[0] == "rccl"
+    assert zlib.crc32(img.tobytes()) == zlib.crc32(ref.tobytes())
+    assert tot["extension_rays"] == st1["extension_rays"] and tot["shadow_rays"] == st1["shadow_rays"]
+
+
+@needs_two_gpus
+def test_physical_gpus_bench_over_nccl(tmp_path):
+    """`bench.py --gpus n --backend nccl` (torch.distributed.run, one rank per GPU, RCCL over xGMI) for n = min(devices, 8):
+    the dumped frame equals `--gpus 1`'s, every rank reports its share, and the line carries the gather's own time."""
+    n = min(_gpus(), 8)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "1", "--warmup", "1", "--spp-per-step", "4", "--tris", "60000", "--width", "832", "--height", "480",
+              "--no-cpu-baseline"]
+    f1, f2 = str(tmp_path / "one.npy"), str(tmp_path / "many.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dump", f1] + common, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                         "--master-port", "29677", os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "nccl", "--dump", f2] + common,
+                        env=env, capture_output=True, text=True, timeout=1200)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == n and j2["config"]["collective"].startswith("nccl, %d rank" % n)
+    pr = j2["config"]["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(n)) and sum(p["pixels"] for p in pr) == 832 * 480 and all(p["samples"] > 0 for p in pr)
+    assert j2["config"]["gather_ms"] is not None and j2["config"]["gather_ms"] > 0.0
+    assert j1["config"]["path_segments"] == j2["config"]["path_segments"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]
+    a, b = np.load(f1), np.load(f2)
+    assert a.shape == b.shape == (480, 832, 4) and np.array_equal(a, b)

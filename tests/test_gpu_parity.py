@@ -693,7 +693,7 @@ def test_cpp_cli_options(tmp_path, oracle_mod, cornell):
         f.readline()
         img = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1]
     p = abi.default_render_params()
-    p.nee = 0
+    p.disable_nee = 1
     ref, _ = oracle_mod.Oracle(cornell).render(96, 64, spp=3, params=p)
     assert np.array_equal(img.reshape(-1, 3), ref[:, :3])
     r = subprocess.run([os.path.join(lib, "gsp_render"), "--frobnicate", CORNELL_XML, out], env=env, capture_output=True, text=True, timeout=60)

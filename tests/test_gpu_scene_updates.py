@@ -313,7 +313,7 @@ def test_nee_off_matches_the_oracle(oracle_mod, cornell, materials_scene, which)
     sc = {"materials": materials_scene, "cornell": cornell}.get(which) or scenes.interior(20_000)
     W, H, SPP = 80, 60, 5
     p = abi.default_render_params()
-    p.nee = 0
+    p.disable_nee = 1
     ref, ost = oracle_mod.Oracle(sc).render(W, H, spp=SPP, params=p)
     for finish in (0, 0xFFFFFFFF):
         with g.Context(0, finish_paths=finish) as ctx:

@@ -64,7 +64,7 @@ def check(ctx, oracle_mod, seed, W=40, H=28, spp=3, dormant=False, nee=1):
     ctx.frame_begin(W, H)
     ctx.reset_stats()
     p = abi.default_render_params()
-    p.nee = nee
+    p.disable_nee = 0 if nee else 1
     ctx.render(spp=spp, params=p)
     st = ctx.stats()
     img = ctx.download().reshape(-1, 4)
