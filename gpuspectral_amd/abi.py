@@ -228,6 +228,7 @@ class Stats(C.Structure):
         ("shadow_stat_occluded_nodes", C.c_uint64),
         ("scene_updates", C.c_uint64),
         ("scene_refits", C.c_uint64),  # (ABI 6)
+        ("shadow_stat_no_triangle", C.c_uint64),  # (ABI 7)
     ]
 
     def as_dict(self):

@@ -85,7 +85,7 @@ enum { C_LIVE = 2 * kTailSet, C_READBACK = C_LIVE + kMaxSlots,
 __device__ unsigned long long g_shade_profile[PR_COUNT * 4];
 #endif
 struct DevStats {
-  unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays, sh_occluded, sh_occluded_nodes, lds_nodes, sh_lds_nodes;
+  unsigned long long shaded, nodes, tris, stat_rays, sh_nodes, sh_tris, sh_rays, sh_occluded, sh_occluded_nodes, lds_nodes, sh_lds_nodes, sh_no_tri;
 };
 
 __device__ __forceinline__ q4 mkq(float x, float y, float z, float w) {
@@ -620,6 +620,23 @@ __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_
   }
 }
 
+// ---- resident table records ---------------------------------------------------------------------------------------------
+// once per gsp_upload_scene / gsp_update_tables: what a vertex would compute from its light / diffuse record alone (pt_shading.h)
+__global__ __launch_bounds__(kBlock) void k_bake_tables(gsp_triangle_light* __restrict__ lights, uint32_t num_lights,
+                                                        gsp_diffuse_bsdf* __restrict__ diffuse, uint32_t num_diffuse) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < num_lights) {
+    gsp_triangle_light L = lights[i];
+    bake_light(L);
+    lights[i] = L;
+  }
+  if (i < num_diffuse) {
+    gsp_diffuse_bsdf b = diffuse[i];
+    bake_diffuse(b);
+    diffuse[i] = b;
+  }
+}
+
 // ---- per-slot texture coordinates (dormant-feature extension) -----------------------------------------------------
 // slot -> global triangle (BVH order) -> instance (tri_first is ascending) -> the instance's vertices in the uv array
 __global__ __launch_bounds__(kBlock) void k_gather_uv(uint32_t num_tris, uint32_t first_slot, const uint32_t* __restrict__ slot_to_global,
@@ -814,6 +831,7 @@ struct gsp_context {
     v.tables = tb;
     v.tables_bytes = (uint32_t)tables_bytes;
     v.num_lights = num_lights;
+    v.inv_num_lights = num_lights ? 1.0f / (float)num_lights : 0.0f;
     v.root = bvh.root;
     if (textured) {
       v.tex.tri_uv = num_textures ? tri_uv.p : nullptr;
@@ -1104,6 +1122,14 @@ static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage&
   ctx->tables_bytes = img.total;
   ctx->num_lights = sc->num_lights;
   for (int k = 0; k < GSP_BSDF_TYPE_COUNT; ++k) ctx->num_bsdfs[k] = sc->num_bsdfs[k];
+  // the resident light and diffuse records carry what a vertex would compute from them alone (pt_shading.h bake_light / bake_diffuse)
+  const uint32_t nb = std::max(sc->num_lights, sc->num_bsdfs[GSP_BSDF_DIFFUSE]);
+  if (nb) {
+    hipLaunchKernelGGL(k_bake_tables, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                       (gsp_triangle_light*)(ctx->tables.p + img.off[8]), sc->num_lights,
+                       (gsp_diffuse_bsdf*)(ctx->tables.p + img.off[GSP_BSDF_DIFFUSE]), sc->num_bsdfs[GSP_BSDF_DIFFUSE]);
+    CTX_TRY(ctx, hipGetLastError());
+  }
   return GSP_OK;
 }
 
@@ -1491,7 +1517,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   ShadowQueue SQ{L.S0.p, L.S1.p, L.S3.p};
   TraceStatsOut so_ext{&ctx->dstats.p->nodes, &ctx->dstats.p->tris, &ctx->dstats.p->stat_rays, nullptr, nullptr, &ctx->dstats.p->lds_nodes};
   const TraceStatsOut so_sh{&ctx->dstats.p->sh_nodes, &ctx->dstats.p->sh_tris, &ctx->dstats.p->sh_rays, &ctx->dstats.p->sh_occluded,
-                            &ctx->dstats.p->sh_occluded_nodes, &ctx->dstats.p->sh_lds_nodes};
+                            &ctx->dstats.p->sh_occluded_nodes, &ctx->dstats.p->sh_lds_nodes, &ctx->dstats.p->sh_no_tri};
   if (rp->collect_traversal_stats >= 2) {  // per-record visit counts of the closest-hit rays (measurement hook; the two
     so_ext.node_hist = ctx->node_hist.p;   // histograms are allocated and zeroed by gsp_render before any lane runs)
     so_ext.tri_hist = ctx->tri_hist.p;
@@ -1998,6 +2024,7 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
     ctx->stats.shadow_nodes_from_lds = d.sh_lds_nodes;
     ctx->stats.shadow_stat_occluded = d.sh_occluded;
     ctx->stats.shadow_stat_occluded_nodes = d.sh_occluded_nodes;
+    ctx->stats.shadow_stat_no_triangle = d.sh_no_tri;
   }
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
   ctx->stats.num_triangles = ctx->bvh.num_tris;

@@ -252,6 +252,12 @@ struct BsdfResult {
   float pdf;
   bool delta;
 };
+// What sampleBSDF has computed from (record, wo) alone and evalBSDF of the SAME vertex would compute again, bit for bit:
+// the rough conductor's Fresnel term (rayhit.rchit:509 = :523, ~200 instructions with its six square roots and six
+// divisions), the smooth plastic's Fresnel term at wo (:463 = :495).  bsdf_sample fills it, bsdf_eval reads it (r05).
+struct BsdfCarry {
+  f3 v;
+};
 
 GSP_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
@@ -369,9 +375,10 @@ GSP_HD uint32_t bsdf_texture(const BsdfTables& T, uint32_t handle) {
 }
 
 // kd_on: `kd` (the texel at the hit) stands in for the record's kD
-GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 wo, f3& wi, BsdfResult& r, bool kd_on = false,
-                        f3 kd = f3{}) {
+GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 wo, f3& wi, BsdfResult& r, BsdfCarry& cy,
+                        bool kd_on = false, f3 kd = f3{}) {
   const uint32_t i = handle & 0xffffu;
+  cy.v = splat(0.0f);
   r.f = splat(0.0f);
   r.pdf = 0.0f;
   r.delta = false;
@@ -380,7 +387,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
     case GSP_BSDF_DIFFUSE: {  // :341-349
       GSP_PROF_BEGIN(PR_SAMPLE_T0);
       wi = sample_cosine_hemisphere(rng);
-      r.f = (kd_on ? kd : ld3(T.diffuse[i].reflectance)) / kPi;
+      r.f = kd_on ? kd / kPi : ld3(T.diffuse[i].reflectance);  // (the resident record holds reflectance / pi: bake_diffuse)
       r.pdf = cosine_pdf(wi);
       GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_DIFFUSE);
     } break;
@@ -437,6 +444,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       float u = rand_uniform(rng);
       float no = b.ior_out, nt = b.ior_in;
       float Fri = fresnel_cos(gabs(wo.z), no, nt);
+      cy.v.x = Fri;
       if (u < Fri) {
         wi = mirror(wo);
         r.f = Fri * splat(1.0f / gabs(wo.z));
@@ -458,6 +466,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_rough_conductor_bsdf b = T.rough_conductor[i];
       f3 Fr = fresnel_conductor(ld3(b.eta), ld3(b.k), gabs(wo.z));
+      cy.v = Fr;
       f3 wh = sample_half_beckmann(rng, b.alpha);
       wi = reflect_about(wo, wh);
       r.f = ((((kd_on ? kd : ld3(b.reflectance)) * Fr) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
@@ -503,7 +512,9 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
 }
 
 // evalBSDF, rayhit.rchit:643-654
-GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfResult& r, bool kd_on = false, f3 kd = f3{}) {
+// cy: what bsdf_sample left for THIS vertex (same handle, same wo)
+GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfResult& r, const BsdfCarry& cy, bool kd_on = false,
+                      f3 kd = f3{}) {
   const uint32_t i = handle & 0xffffu;
   r.f = splat(0.0f);
   r.pdf = 0.0f;
@@ -511,7 +522,7 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
   switch (handle >> 16) {
     case GSP_BSDF_DIFFUSE: {  // :351-358
       GSP_PROF_BEGIN(PR_EVAL_T0);
-      r.f = (kd_on ? kd : ld3(T.diffuse[i].reflectance)) / kPi;
+      r.f = kd_on ? kd / kPi : ld3(T.diffuse[i].reflectance);  // (reflectance / pi: bake_diffuse)
       r.pdf = cosine_pdf(wi);
       GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_DIFFUSE);
     } break;
@@ -524,7 +535,7 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
       GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_smooth_plastic_bsdf b = T.smooth_plastic[i];
       float no = b.ior_out, nt = b.ior_in;
-      float Fri = fresnel_cos(gabs(wo.z), no, nt);
+      float Fri = cy.v.x;  // = fresnel_cos(gabs(wo.z), no, nt), :495
       float Fro = fresnel_cos(gabs(wi.z), no, nt);
       float Ri = escape_fraction(b.r0, no, nt);
       r.f = plastic_diffuse(ld3(b.diffuse), Fri, Fro, no / nt, Ri);
@@ -534,7 +545,7 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
     case GSP_BSDF_ROUGH_CONDUCTOR: {  // :522-530
       GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_rough_conductor_bsdf b = T.rough_conductor[i];
-      f3 Fr = fresnel_conductor(ld3(b.eta), ld3(b.k), gabs(wo.z));
+      f3 Fr = cy.v;  // = fresnel_conductor(eta, k, |wo.z|), :523
       f3 wh = normalize(wo + wi);
       r.f = (((Fr * (kd_on ? kd : ld3(b.reflectance))) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) /
             ((4.0f * gabs(wi.z)) * gabs(wo.z));
@@ -569,14 +580,39 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
 
 GSP_HD bool bsdf_transmits(uint32_t handle) { return (handle >> 16) == GSP_BSDF_SMOOTH_DIELECTRIC; }  // :620-627
 
+// ---- resident ("baked") table records (r05) -----------------------------------------------------------------------------------
+// Some of what a shaded vertex computes depends on its table record ALONE: sampleLight's triangle normal and area
+// (rayhit.rchit:131-134: two cross products, two square roots and a division per vertex), the diffuse BSDF's reflectance / pi
+// (:345,:354: three IEEE divisions in sampleBSDF and three more in evalBSDF).  The resident copies of those two tables carry
+// these values in place -- the light's normal in the unused w components of its positions and its area in radiance.w, the
+// diffuse record reflectance / pi instead of reflectance -- computed ONCE per upload by k_bake_tables with the very
+// expressions the shader states, so every vertex reads the bits it would have computed.  (The host keeps the records as
+// the caller gave them: gsp_update_tables compares those.)
+GSP_HD void bake_light(gsp_triangle_light& L) {
+  const f3 v0 = ld3(L.positions[0]), v1 = ld3(L.positions[1]), v2 = ld3(L.positions[2]);
+  const float A = 0.5f * gabs(length(cross(v2 - v0, v1 - v0)));  // :132
+  const f3 normal = normalize(cross(v1 - v0, v2 - v0));          // :133
+  L.positions[0][3] = normal.x;
+  L.positions[1][3] = normal.y;
+  L.positions[2][3] = normal.z;
+  L.radiance[3] = A;
+}
+GSP_HD void bake_diffuse(gsp_diffuse_bsdf& b) {
+  const f3 f = ld3(b.reflectance) / kPi;  // :345 = :354
+  b.reflectance[0] = f.x;
+  b.reflectance[1] = f.y;
+  b.reflectance[2] = f.z;
+}
+
 // ---- light sampling (rayhit.rchit:123-153) ---------------------------------------
 struct LightSample {
   f3 position;
   f3 emission;
   float pdf;
 };
-// Draws R (index), U (e1), U (e2) -- always three draws.
-GSP_HD LightSample sample_light(const gsp_triangle_light* lights, uint32_t num_lights, uint32_t& rng, f3 pos) {
+// Draws R (index), U (e1), U (e2) -- always three draws.  `lights` = BAKED records (bake_light);
+// inv_num_lights = 1.0f / (float)num_lights (:151), formed once on the host.
+GSP_HD LightSample sample_light(const gsp_triangle_light* lights, uint32_t num_lights, float inv_num_lights, uint32_t& rng, f3 pos) {
   LightSample ls;
   uint32_t r = pcg_next(rng);
   float e1 = rand_uniform(rng);
@@ -595,8 +631,8 @@ GSP_HD LightSample sample_light(const gsp_triangle_light* lights, uint32_t num_l
   f3 v0 = ld3(L->positions[0]);
   f3 v1 = ld3(L->positions[1]);
   f3 v2 = ld3(L->positions[2]);
-  float A = 0.5f * gabs(length(cross(v2 - v0, v1 - v0)));
-  f3 normal = normalize(cross(v1 - v0, v2 - v0));
+  float A = L->radiance[3];                                                         // baked: 0.5 |cross(v2 - v0, v1 - v0)|
+  f3 normal = mk3(L->positions[0][3], L->positions[1][3], L->positions[2][3]);     // baked: normalize(cross(v1 - v0, v2 - v0))
   f3 lightPos = (u * v0 + v * v1) + w * v2;
   f3 toL = lightPos - pos;
   float ldist = length(toL);
@@ -605,7 +641,7 @@ GSP_HD LightSample sample_light(const gsp_triangle_light* lights, uint32_t num_l
   ls.position = lightPos;
   ls.emission = ld3(L->radiance) * (c > 0.0f ? 1.0f : 0.0f);
   ls.pdf = (ldist * ldist) / (gabs(c) * A);
-  ls.pdf = ls.pdf * (1.0f / (float)num_lights);
+  ls.pdf = ls.pdf * inv_num_lights;
   return ls;
 }
 

@@ -41,8 +41,9 @@ struct SceneView {
   const q4* tri_isect;  // 3 quads per slot
   const q4* tri_shade;  // 4 quads per slot: {N, bits(bsdf | twofaced << 31)}, {n0, emission.r}, {n1, .g}, {n2, .b}
   BsdfTables bsdf;
-  const gsp_triangle_light* lights;
+  const gsp_triangle_light* lights;  // baked records (pt_shading.h bake_light), as is the diffuse table (bake_diffuse)
   uint32_t num_lights;
+  float inv_num_lights = 0.0f;       // 1.0f / (float)num_lights (rayhit.rchit:151), formed once on the host
   int32_t root;
   const uint8_t* tables = nullptr;  // the BSDF tables + lights back to back (device: one allocation), for LDS staging
   uint32_t tables_bytes = 0;
@@ -151,13 +152,14 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   f3 wi_l;
   GSP_PROF_END(PR_PACKET);
   GSP_PROF_BEGIN(PR_SAMPLE);
-  bsdf_sample(S.bsdf, bsdf, rng, wo, wi_l, bs, kd_on, kd);           // :716
+  BsdfCarry cy;
+  bsdf_sample(S.bsdf, bsdf, rng, wo, wi_l, bs, cy, kd_on, kd);       // :716
   GSP_PROF_END(PR_SAMPLE);
   GSP_PROF_BEGIN(PR_LIGHT);
   const float NoW = gabs(wi_l.z);                                         // :717
   const f3 wi = to_world(onb, wi_l);                                      // :718
 
-  const LightSample ls = sample_light(S.lights, S.num_lights, rng, position);  // :720
+  const LightSample ls = sample_light(S.lights, S.num_lights, S.inv_num_lights, rng, position);  // :720
   const f3 toL = ls.position - position;
   const f3 L = normalize(toL);                                            // :722
   const f3 wL = to_local(onb, L);                                         // :723
@@ -167,7 +169,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   BsdfResult lb;
   GSP_PROF_END(PR_LIGHT);
   GSP_PROF_BEGIN(PR_EVAL);
-  bsdf_eval(S.bsdf, bsdf, wo, wL, lb, kd_on, kd);                    // :729
+  bsdf_eval(S.bsdf, bsdf, wo, wL, lb, cy, kd_on, kd);                // :729
   GSP_PROF_END(PR_EVAL);
   GSP_PROF_BEGIN(PR_TAIL);
 

@@ -154,6 +154,7 @@ struct TraceStatsOut {
   unsigned long long* hits = nullptr;       // rays that ended with a hit (any-hit: occluded shadow rays)
   unsigned long long* hit_nodes = nullptr;  // node records those rays read
   unsigned long long* lds_nodes = nullptr;  // node records served by the block's LDS copy of the top of the tree
+  unsigned long long* no_tri = nullptr;     // rays that ended without one triangle test
   uint32_t* node_hist = nullptr;            // visits per node index / tests per triangle slot (collect_traversal_stats = 2):
   uint32_t* tri_hist = nullptr;             // which records would an LDS copy have to hold?
 };
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   h.t = 0.0f;
   h.u = h.v = 0.0f;
   h.slot = -1;
-  uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0, c_hit_nodes = 0, ray_nodes = 0, c_lds = 0;  // (STATS instantiations only)
+  uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0, c_hit_nodes = 0, ray_nodes = 0, c_lds = 0, c_notri = 0, ray_tris = 0;  // (STATS instantiations only)
 
 #ifdef GSP_WAVE_PROFILE
   unsigned long long wp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
               ++c_hits;
               c_hit_nodes += ray_nodes;
             }
+            if (STATS && ray_tris == 0) ++c_notri;
           }
         }
       }
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           if (STATS) {
             ++c_rays;
             ray_nodes = 0;
+            ray_tris = 0;
           }
         }
         const uint32_t want = (uint32_t)__popcll(idle_m);
@@ -433,6 +436,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
       }
       if (STATS) {
         c_tris += act ? 1u : 0u;
+        ray_tris += act ? 1u : 0u;
         if (act && so.tri_hist) atomicAdd(so.tri_hist + slot, 1u);
       }
       if (ANY) {  // the first accepted triangle ends the ray
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 #endif
   if (STATS) {
     const unsigned long long a = wave_sum_u64(c_nodes), b = wave_sum_u64(c_tris), c = wave_sum_u64(c_rays);
-    const unsigned long long d = wave_sum_u64(c_hits), e = wave_sum_u64(c_hit_nodes), f = wave_sum_u64(c_lds);
+    const unsigned long long d = wave_sum_u64(c_hits), e = wave_sum_u64(c_hit_nodes), f = wave_sum_u64(c_lds), g = wave_sum_u64(c_notri);
     if (lane == 0) {
       atomicAdd(so.nodes, a);
       atomicAdd(so.tris, b);
@@ -472,6 +476,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
       if (so.lds_nodes) atomicAdd(so.lds_nodes, f);
       if (so.hits) atomicAdd(so.hits, d);
       if (so.hit_nodes) atomicAdd(so.hit_nodes, e);
+      if (so.no_tri) atomicAdd(so.no_tri, g);
     }
   }
 }

@@ -33,6 +33,8 @@ def load():
     L.gsph_load_scene.argtypes = [C.c_char_p, C.c_char_p]
     L.gsph_load_scene_ex.restype = vp
     L.gsph_load_scene_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.gsph_load_scene_opts.restype = vp
+    L.gsph_load_scene_opts.argtypes = [C.c_char_p, C.c_char_p, C.c_uint]
     L.gsph_load_bitmap.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp]
     L.gsph_load_hdr_bitmap.argtypes = [C.c_char_p, C.POINTER(u32), C.POINTER(u32), vp]
     L.gsph_scene_free.argtypes = [vp]
@@ -89,12 +91,15 @@ def _view(ptr, count, dtype):
 class Scene:
     """A C++ GPUSpectral::Scene produced by loadScene (S/engine/Loader.cpp:253-349)."""
 
-    def __init__(self, path, asset_dir=None, dormant_features=False, srgb_textures=True):
-        """dormant_features: LoadOptions::dormantFeatures (textures / environment map, SURVEY 8(f).3); the default is the
-        reference's behaviour."""
+    def __init__(self, path, asset_dir=None, dormant_features=False, srgb_textures=True, builtin_shapes=False):
+        """dormant_features: LoadOptions::dormantFeatures (textures / environment map, SURVEY 8(f).3); builtin_shapes:
+        LoadOptions::builtinShapes (`disk` and `sphere` shapes are built instead of skipped, SURVEY 8(f).1); the defaults are
+        the reference's behaviour."""
         self._L = load()
         ad = asset_dir.encode() if asset_dir else None
-        if dormant_features:
+        if builtin_shapes:
+            self._h = self._L.gsph_load_scene_opts(path.encode(), ad, (1 if dormant_features else 0) | (2 if srgb_textures else 0) | 4)
+        elif dormant_features:
             self._h = self._L.gsph_load_scene_ex(path.encode(), ad, 1, 1 if srgb_textures else 0)
         else:
             self._h = self._L.gsph_load_scene(path.encode(), ad)

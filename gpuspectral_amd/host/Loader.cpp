@@ -371,6 +371,65 @@ MeshPtr builtinQuadMesh(uint32_t id, bool box) {
   return std::make_shared<Mesh>(id, std::move(v));
 }
 
+// LoadOptions::builtinShapes.  Points of the unit circle / sphere come from repeated NORMALISED MIDPOINTS of the four axis
+// points / the octahedron -- float32 additions, multiplications, one square root and three divisions per point, all correctly
+// rounded on every IEEE machine and commutative where two triangles share an edge (watertight), so that the numpy
+// restatement (oracle/mitsuba_loader.py builtin_disk / builtin_sphere) produces the same bits.
+static vec3 unitMid(const vec3& a, const vec3& b) {
+  const float x = a.x + b.x, y = a.y + b.y, z = a.z + b.z;
+  const float l = std::sqrt((x * x + y * y) + z * z);
+  return vec3{x / l, y / l, z / l};
+}
+MeshPtr builtinDiskMesh(uint32_t id) {
+  constexpr int N = 64;
+  vec3 p[N];
+  p[0] = vec3{1, 0, 0}, p[N / 4] = vec3{0, 1, 0}, p[N / 2] = vec3{-1, 0, 0}, p[3 * N / 4] = vec3{0, -1, 0};
+  for (int step = N / 4; step > 1; step /= 2)
+    for (int i = 0; i < N; i += step) p[i + step / 2] = unitMid(p[i], p[(i + step) % N]);
+  std::vector<Mesh::Vertex> v;
+  for (int k = 0; k < N; ++k) {  // fan, counter-clockwise seen from +z: the geometric normal is +z (an area emitter shines that way)
+    const vec3 c[3] = {vec3{0, 0, 0}, p[k], p[(k + 1) % N]};
+    for (const vec3& q : c) {
+      Mesh::Vertex x;
+      x.pos = q;
+      x.normal = vec3{0, 0, 1};
+      x.uv = vec2{0.5f + 0.5f * q.x, 0.5f + 0.5f * q.y};
+      v.push_back(x);
+    }
+  }
+  return std::make_shared<Mesh>(id, std::move(v));
+}
+MeshPtr builtinSphereMesh(uint32_t id) {
+  struct Tri {
+    vec3 a, b, c;
+  };
+  const vec3 px{1, 0, 0}, nx{-1, 0, 0}, py{0, 1, 0}, ny{0, -1, 0}, pz{0, 0, 1}, nz{0, 0, -1};
+  // the octahedron, every face counter-clockwise seen from outside
+  std::vector<Tri> t = {{px, py, pz}, {py, nx, pz}, {nx, ny, pz}, {ny, px, pz}, {py, px, nz}, {nx, py, nz}, {ny, nx, nz}, {px, ny, nz}};
+  for (int level = 0; level < 3; ++level) {
+    std::vector<Tri> n;
+    n.reserve(t.size() * 4);
+    for (const Tri& f : t) {
+      const vec3 ab = unitMid(f.a, f.b), bc = unitMid(f.b, f.c), ca = unitMid(f.c, f.a);
+      n.push_back({f.a, ab, ca});
+      n.push_back({ab, f.b, bc});
+      n.push_back({ca, bc, f.c});
+      n.push_back({ab, bc, ca});
+    }
+    t.swap(n);
+  }
+  std::vector<Mesh::Vertex> v;
+  for (const Tri& f : t)
+    for (const vec3& q : {f.a, f.b, f.c}) {
+      Mesh::Vertex x;
+      x.pos = q;
+      x.normal = q;  // unit sphere: the smooth normal is the position
+      x.uv = vec2{0.5f + 0.5f * q.x, 0.5f + 0.5f * q.y};
+      v.push_back(x);
+    }
+  return std::make_shared<Mesh>(id, std::move(v));
+}
+
 struct LoadContext {
   std::string parentPath;
   LoadOptions options;
@@ -602,7 +661,9 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg, const L
     auto it = meshCache.find(objPath);
     if (it != meshCache.end()) return it->second;
     MeshPtr m;
-    if (builtin && !fileExists(objPath)) m = builtinQuadMesh(nextMeshId++, builtin == 2);
+    if (builtin == 3) m = builtinDiskMesh(nextMeshId++);
+    else if (builtin == 4) m = builtinSphereMesh(nextMeshId++);
+    else if (builtin && !fileExists(objPath)) m = builtinQuadMesh(nextMeshId++, builtin == 2);
     else m = loadMesh(objPath, nextMeshId++);
     meshCache.emplace(objPath, m);
     return m;
@@ -616,7 +677,10 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg, const L
       if (pt == "obj") filename = joinPath(parentPath, obj->string("filename"));
       else if (pt == "rectangle") { filename = joinPath(assetDir, "rect.obj"); builtin = 1; }
       else if (pt == "cube") { filename = joinPath(assetDir, "box.obj"); builtin = 2; }
-      else if (pt == "disk") filename = joinPath(assetDir, "disk.obj");  // (no such asset in the reference tree: skipped below)
+      else if (pt == "disk") {
+        filename = joinPath(assetDir, "disk.obj");  // Loader.cpp:276 (no such asset in the reference tree: skipped below by default)
+        if (options.builtinShapes && !fileExists(filename)) { filename = "<builtin disk>"; builtin = 3; }
+      } else if (pt == "sphere" && options.builtinShapes) { filename = "<builtin sphere>"; builtin = 4; }
       else {
         outScene.warnings.push_back("unsupported shape type '" + pt + "' skipped");
         continue;
@@ -638,6 +702,11 @@ Scene loadScene(const std::string& path, const std::string& assetDirArg, const L
         matrix[3][1] = ce->second.v[1];
         matrix[3][2] = ce->second.v[2];
         matrix[3][3] = 1.0f;
+      }
+      if (builtin == 4) {  // (extension: the reference never reads `radius`) the unit sphere scaled about its centre
+        const float r = obj->number("radius", 1.0f);
+        for (int c = 0; c < 3; ++c)
+          for (int k = 0; k < 3; ++k) matrix[c][k] = matrix[c][k] * r;
       }
       bool emitting = false;
       RenderObject renderObject;

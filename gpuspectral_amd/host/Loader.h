@@ -17,6 +17,14 @@ namespace GPUSpectral {
 struct LoadOptions {
   bool dormantFeatures = false;
   bool srgbTextures = true;
+  // `<shape type="disk">` maps to assets/disk.obj in the reference (Loader.cpp:276), a file its checkout does
+  // not hold, and `sphere` falls through to an empty file name (:278): both shapes are skipped with a warning by default,
+  // as they are there -- which leaves `living-room` without its only emitters and `staircase2` without five of its lights.
+  // builtinShapes = true builds them instead: Mitsuba's unit disk (z = 0, radius 1, normal +z; 64 fan triangles) and unit
+  // sphere (octahedron subdivided three times, 512 triangles, smooth normals), tessellated with float32 + * / sqrt only
+  // (no libm: oracle/mitsuba_loader.py builds the same floats).  `to_world` and `center` as for every shape
+  // (Loader.cpp:284-293); `radius` -- which the reference never reads -- scales the sphere.
+  bool builtinShapes = false;
 };
 
 // assetDir: where rect.obj / box.obj / disk.obj live (Engine::assetPath); "" = the

@@ -63,6 +63,24 @@ void* gsph_load_scene_ex(const char* path, const char* asset_dir, int dormant, i
   }
   return b;
 }
+// flags: 1 = LoadOptions::dormantFeatures, 2 = srgbTextures, 4 = builtinShapes (disk / sphere)
+void* gsph_load_scene_opts(const char* path, const char* asset_dir, unsigned flags) {
+  SceneBox* b = nullptr;
+  int rc = guard([&] {
+    b = new SceneBox();
+    LoadOptions opt;
+    opt.dormantFeatures = (flags & 1u) != 0;
+    opt.srgbTextures = (flags & 2u) != 0;
+    opt.builtinShapes = (flags & 4u) != 0;
+    b->scene = loadScene(path, asset_dir ? asset_dir : "", opt);
+    flattenScene(b->scene, b->flat);
+  });
+  if (rc) {
+    delete b;
+    return nullptr;
+  }
+  return b;
+}
 void gsph_scene_free(void* s) { delete (SceneBox*)s; }
 
 // Image.h readers.  Two calls: texels == NULL returns the size, the second call fills width * height RGBA8 words

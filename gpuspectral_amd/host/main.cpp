@@ -1,9 +1,10 @@
 // main.cpp -- headless counterpart of the reference's S/main.cpp:15-30:
 //   Engine + PathTracer + loadScene + Window::run(frame loop)
 // becomes: load the Mitsuba XML, render N samples per pixel, write the HDR framebuffer.
-//   gsp_render [--dormant-features] [--no-nee] [--memory-share F] [--pool-paths N] <scene.xml> <out.pfm> [width height spp [devices]]
+//   gsp_render [--dormant-features] [--builtin-shapes] [--no-nee] [--memory-share F] [--pool-paths N] <scene.xml> <out.pfm> [width height spp [devices]]
 //   devices: "0" (default) or a list "0,1,2,3": the frame is then tiled over those GPUs (MultiGpuPathTracer); an index
 //   may repeat.  --dormant-features: LoadOptions::dormantFeatures (bitmap / checkerboard textures, envmap emitter);
+//   --builtin-shapes: LoadOptions::builtinShapes (`disk` / `sphere` shapes are tessellated instead of skipped);
 //   --no-nee: gsp_render_params.disable_nee = 1 (RenderParams.nee = false); --memory-share / --pool-paths: gsp_ctx_options (how much device memory the path pool takes)
 #include <chrono>
 #include <cstdio>
@@ -26,6 +27,7 @@ int main(int argc, char** argv) {
     const std::string flag = argv[1];
     int used = 1;
     if (flag == "--dormant-features") options.dormantFeatures = true;
+    else if (flag == "--builtin-shapes") options.builtinShapes = true;
     else if (flag == "--no-nee") nee = false;
     else if (flag == "--memory-share" && argc > 2) ctxOptions.memory_share = std::atof(argv[2]), used = 2;
     else if (flag == "--pool-paths" && argc > 2) ctxOptions.pool_paths = std::strtoull(argv[2], nullptr, 10), used = 2;
@@ -37,7 +39,7 @@ int main(int argc, char** argv) {
     argv += used;
   }
   if (argc < 3) {
-    std::fprintf(stderr, "usage: gsp_render [--dormant-features] [--no-nee] [--memory-share F] [--pool-paths N] scene.xml out.pfm [width height spp [device | d0,d1,...]]\n");
+    std::fprintf(stderr, "usage: gsp_render [--dormant-features] [--builtin-shapes] [--no-nee] [--memory-share F] [--pool-paths N] scene.xml out.pfm [width height spp [device | d0,d1,...]]\n");
     return 2;
   }
   const uint32_t width = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 500;  // S/main.cpp:17: 500x500 window

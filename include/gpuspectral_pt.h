@@ -61,7 +61,8 @@ extern "C" {
                              5: gsp_update_camera / _instances / _tables (+ gsp_multi_*), gsp_ctx_options + gsp_ctx_create_ex /
                                 gsp_multi_create_ex, gsp_render_params.nee, gsp_stats.scene_updates;
                              6: gsp_update_instances refits the tree (gsp_ctx_options.refit_growth, gsp_stats.scene_refits);
-                             7: gsp_render_params.nee -> disable_nee (a zeroed struct is the reference as shipped) */
+                             7: gsp_render_params.nee -> disable_nee (a zeroed struct is the reference as shipped),
+                                gsp_stats.shadow_stat_no_triangle */
 
 /* ---- status codes (0 = ok); the message is at gsp_last_error(ctx) ---- */
 #define GSP_OK 0
@@ -295,6 +296,8 @@ typedef struct gsp_stats {
   uint64_t scene_updates;    /* (ABI 5) gsp_update_camera / _instances / _tables calls that changed something since the last
                                 gsp_upload_scene (a test hook: which path did the host layer take?) */
   uint64_t scene_refits;     /* (ABI 6) of those, gsp_update_instances calls that kept the tree's topology (refit) */
+  uint64_t shadow_stat_no_triangle; /* (ABI 7, stats mode) shadow rays of shadow_stat_rays that ended without ONE triangle test
+                                       (the ray's shear constants Sx, Sy were computed for nothing: VERDICT r04 item 7) */
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;

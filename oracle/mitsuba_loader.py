@@ -292,7 +292,11 @@ class _Builder:
         if path in self.meshes:
             return self.meshes[path]
         base = os.path.basename(path)
-        if not os.path.exists(path) and base == "rect.obj":
+        if path == "<builtin disk>":
+            pos, nrm, uv = builtin_disk()
+        elif path == "<builtin sphere>":
+            pos, nrm, uv = builtin_sphere()
+        elif not os.path.exists(path) and base == "rect.obj":
             pos, nrm, uv = rect_mesh(True)
         elif not os.path.exists(path) and base == "box.obj":
             pos, nrm, uv = box_mesh(True)
@@ -388,9 +392,53 @@ class _Builder:
                 self.load_material(mat, child)
 
 
-def load_scene(path, asset_dir=None, dormant_features=False, srgb_textures=True):
+def _unit_mid(a, b):
+    """normalised midpoint in float32: + * sqrt / only, correctly rounded everywhere (host/Loader.cpp unitMid)"""
+    x, y, z = F(a[0] + b[0]), F(a[1] + b[1]), F(a[2] + b[2])
+    l = np.sqrt(F(F(F(x * x) + F(y * y)) + F(z * z)))
+    return (F(x / l), F(y / l), F(z / l))
+
+
+def builtin_disk():
+    """LoadOptions::builtinShapes: Mitsuba's unit disk (z = 0, radius 1, normal +z) as 64 fan triangles
+    -> (positions, normals, uvs) of the de-indexed mesh, the floats of host/Loader.cpp builtinDiskMesh"""
+    N = 64
+    p = [None] * N
+    p[0], p[N // 4], p[N // 2], p[3 * N // 4] = (F(1), F(0), F(0)), (F(0), F(1), F(0)), (F(-1), F(0), F(0)), (F(0), F(-1), F(0))
+    step = N // 4
+    while step > 1:
+        for i in range(0, N, step):
+            p[i + step // 2] = _unit_mid(p[i], p[(i + step) % N])
+        step //= 2
+    pos = []
+    for k in range(N):
+        pos += [(F(0), F(0), F(0)), p[k], p[(k + 1) % N]]
+    pos = np.array(pos, F)
+    nrm = np.tile(np.array([0, 0, 1], F), (len(pos), 1))
+    uv = (F(0.5) + F(0.5) * pos[:, :2]).astype(F)
+    return pos, nrm, uv
+
+
+def builtin_sphere():
+    """LoadOptions::builtinShapes: the unit sphere as an octahedron subdivided three times (512 triangles), smooth normals
+    -> (positions, normals, uvs), the floats of host/Loader.cpp builtinSphereMesh"""
+    px, nx, py, ny, pz, nz = [(F(a), F(b), F(c)) for a, b, c in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1))]
+    t = [(px, py, pz), (py, nx, pz), (nx, ny, pz), (ny, px, pz), (py, px, nz), (nx, py, nz), (ny, nx, nz), (px, ny, nz)]
+    for _ in range(3):
+        n = []
+        for a, b, c in t:
+            ab, bc, ca = _unit_mid(a, b), _unit_mid(b, c), _unit_mid(c, a)
+            n += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+        t = n
+    pos = np.array([q for f in t for q in f], F)
+    uv = (F(0.5) + F(0.5) * pos[:, :2]).astype(F)
+    return pos, pos.copy(), uv
+
+
+def load_scene(path, asset_dir=None, dormant_features=False, srgb_textures=True, builtin_shapes=False):
     """Loader.cpp:253-349 -> abi.SceneArrays.  dormant_features: LoadOptions::dormantFeatures of the product's loader
-    (the texture and envmap branches the reference keeps commented out, Loader.cpp:122-143,338-346)."""
+    (the texture and envmap branches the reference keeps commented out, Loader.cpp:122-143,338-346); builtin_shapes:
+    LoadOptions::builtinShapes (`disk` / `sphere` tessellated instead of skipped, SURVEY 8(f).1)."""
     parent = os.path.dirname(os.path.abspath(path))
     asset_dir = asset_dir or parent
     root = ET.parse(path).getroot()
@@ -411,10 +459,14 @@ def load_scene(path, asset_dir=None, dormant_features=False, srgb_textures=True)
                 filename = os.path.join(asset_dir, "box.obj")
             elif pt == "disk":
                 filename = os.path.join(asset_dir, "disk.obj")
+                if builtin_shapes and not os.path.exists(filename):
+                    filename = "<builtin disk>"
+            elif pt == "sphere" and builtin_shapes:
+                filename = "<builtin sphere>"
             else:
                 b.warnings.append("unsupported shape type '%s' skipped" % pt)
                 continue
-            if not (os.path.exists(filename) or (pt != "obj" and os.path.basename(filename) in ("rect.obj", "box.obj"))):
+            if not (os.path.exists(filename) or filename.startswith("<builtin") or (pt != "obj" and os.path.basename(filename) in ("rect.obj", "box.obj"))):
                 b.warnings.append("missing mesh '%s' skipped" % filename)
                 continue
             first, count = b.mesh(filename)
@@ -424,6 +476,10 @@ def load_scene(path, asset_dir=None, dormant_features=False, srgb_textures=True)
             c = obj.props.get("center")
             if c and c[0] == "vector":  # Loader.cpp:288-293
                 matrix[12:16] = np.array([c[1][0], c[1][1], c[1][2], 1.0], F)
+            if filename == "<builtin sphere>":  # (extension: the reference never reads `radius`)
+                r = obj.number("radius") if obj.has("radius") else F(1.0)
+                m3 = matrix.reshape(4, 4)
+                m3[:3, :3] = (m3[:3, :3] * F(r)).astype(F)
             mat = {"emission": np.zeros(3, F), "twofaced": 0, "bsdf": 0}
             emitting = False
             for child in obj.children:

@@ -210,6 +210,7 @@ struct Emu {
     view.bsdf.rough_plastic = b7.data();
     view.lights = lights.data();
     view.num_lights = sc.num_lights;
+    view.inv_num_lights = sc.num_lights ? 1.0f / (float)sc.num_lights : 0.0f;
     view.root = 0;
     if (textured) {  // what gsp_context::view() fills
       view.tex.tri_uv = textures.empty() ? nullptr : tri_uv.data();
@@ -264,6 +265,8 @@ void* emu_create(const gsp_scene_desc* sc) {
   copyv(e->b6, sc->rough_floor_bsdfs, sc->num_bsdfs[6]);
   copyv(e->b7, sc->rough_plastic_bsdfs, sc->num_bsdfs[7]);
   copyv(e->lights, sc->lights, sc->num_lights);
+  for (gsp_triangle_light& L : e->lights) bake_light(L);  // the resident records, as k_bake_tables leaves them
+  for (gsp_diffuse_bsdf& b : e->b0) bake_diffuse(b);
   e->inv_t.resize(16ull * sc->num_instances);
   for (uint32_t i = 0; i < sc->num_instances; ++i) {
     float tr[16];
@@ -376,7 +379,8 @@ void emu_bsdf_sample(void* h, uint32_t handle, const float* wo, uint32_t seed, f
   uint32_t rng = seed;
   f3 wi;
   BsdfResult r;
-  bsdf_sample(e->view.bsdf, handle, rng, mk3(wo[0], wo[1], wo[2]), wi, r);
+  BsdfCarry cy;
+  bsdf_sample(e->view.bsdf, handle, rng, mk3(wo[0], wo[1], wo[2]), wi, r, cy);
   out9[0] = wi.x;
   out9[1] = wi.y;
   out9[2] = wi.z;
@@ -390,7 +394,16 @@ void emu_bsdf_sample(void* h, uint32_t handle, const float* wo, uint32_t seed, f
 void emu_bsdf_eval(void* h, uint32_t handle, const float* wo, const float* wi, float* out5) {
   Emu* e = (Emu*)h;
   BsdfResult r;
-  bsdf_eval(e->view.bsdf, handle, mk3(wo[0], wo[1], wo[2]), mk3(wi[0], wi[1], wi[2]), r);
+  // evalBSDF of a vertex reads what sampleBSDF of the SAME vertex (same record, same wo) left behind (BsdfCarry, pt_shading.h):
+  // run the sampler first, with any random stream
+  BsdfCarry cy;
+  {
+    uint32_t rng = 1u;
+    f3 wi0;
+    BsdfResult r0;
+    bsdf_sample(e->view.bsdf, handle, rng, mk3(wo[0], wo[1], wo[2]), wi0, r0, cy);
+  }
+  bsdf_eval(e->view.bsdf, handle, mk3(wo[0], wo[1], wo[2]), mk3(wi[0], wi[1], wi[2]), r, cy);
   out5[0] = r.f.x;
   out5[1] = r.f.y;
   out5[2] = r.f.z;
@@ -400,7 +413,7 @@ void emu_bsdf_eval(void* h, uint32_t handle, const float* wo, const float* wi, f
 void emu_sample_light(void* h, const float* pos, uint32_t seed, float* out8) {
   Emu* e = (Emu*)h;
   uint32_t rng = seed;
-  LightSample r = sample_light(e->view.lights, e->view.num_lights, rng, mk3(pos[0], pos[1], pos[2]));
+  LightSample r = sample_light(e->view.lights, e->view.num_lights, e->view.inv_num_lights, rng, mk3(pos[0], pos[1], pos[2]));
   out8[0] = r.position.x;
   out8[1] = r.position.y;
   out8[2] = r.position.z;

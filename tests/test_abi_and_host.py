@@ -439,6 +439,83 @@ def test_cpp_loader_on_reference_scenes(name):
     _check_reference_scene(xml, name)
 
 
+def test_builtin_disk_and_sphere_meshes():
+    """LoadOptions::builtinShapes (SURVEY 8(f).1): Mitsuba's unit disk and unit sphere, tessellated with float32 + * / sqrt
+    only.  Geometry: every rim / surface point on the unit circle / sphere to an ulp, the disk's normal +z and its area
+    that of the inscribed 64-gon, the sphere closed (every edge in exactly two triangles, opposite directions) and wound
+    outward."""
+    from oracle import mitsuba_loader as ml
+
+    pos, nrm, uv = ml.builtin_disk()
+    assert pos.shape == (192, 3) and (pos[:, 2] == 0).all() and (nrm == [0, 0, 1]).all()
+    rim = pos.reshape(-1, 3, 3)[:, 1:, :]
+    assert np.abs(np.linalg.norm(rim.astype(np.float64), axis=2) - 1.0).max() < 2e-7 and (pos.reshape(-1, 3, 3)[:, 0] == 0).all()
+    t = pos.reshape(-1, 3, 3).astype(np.float64)
+    cr = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+    assert (cr[:, 2] > 0).all()  # counter-clockwise seen from +z: an area emitter on it shines along +z
+    assert abs(0.5 * cr[:, 2].sum() - 32.0 * np.sin(2 * np.pi / 64)) < 1e-6
+    pos, nrm, uv = ml.builtin_sphere()
+    assert pos.shape == (1536, 3) and np.array_equal(pos, nrm)
+    assert np.abs(np.linalg.norm(pos.astype(np.float64), axis=1) - 1.0).max() < 2e-7
+    t = pos.reshape(-1, 3, 3)
+    t64 = t.astype(np.float64)
+    assert (np.einsum("ij,ij->i", np.cross(t64[:, 1] - t64[:, 0], t64[:, 2] - t64[:, 0]), t64.mean(1)) > 0).all()  # outward
+    edges = {}
+    for f in t:
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            edges[(f[a].tobytes(), f[b].tobytes())] = edges.get((f[a].tobytes(), f[b].tobytes()), 0) + 1
+    assert len(edges) == 1536 and all(n == 1 and edges.get((b, a)) == 1 for (a, b), n in edges.items())  # watertight, bit for bit
+    assert abs(0.5 * np.linalg.norm(np.cross(t64[:, 1] - t64[:, 0], t64[:, 2] - t64[:, 0]), axis=1).sum() / (4 * np.pi) - 1.0) < 0.02
+
+
+def test_cpp_loader_builtin_shapes_on_staircase2(staircase2_xml):
+    """The five `<shape type="disk">` ceiling lights of 'Modern Hall', which the reference maps to an assets/disk.obj its
+    checkout does not hold (Loader.cpp:276): skipped with a warning by default (the reference's behaviour, the test above),
+    BUILT with LoadOptions::builtinShapes -- 5 x 64 triangles and as many triangle lights more, the same arrays from the C++
+    loader, the numpy restatement and the fixture the GPU tests use."""
+    from gpuspectral_amd import abi, host
+    from oracle import mitsuba_loader as ml
+
+    s = host.Scene(staircase2_xml, builtin_shapes=True)
+    a, b = s.arrays(), ml.load_scene(staircase2_xml, builtin_shapes=True)
+    same_scene(a, b)
+    assert a.num_triangles == 30927 + 5 * 64 and len(a.lights) == 16 + 5 * 64 and len(a.instances) == 32
+    assert not any("disk" in w for w in s.warnings)
+    cached = abi.SceneArrays.load(os.path.join(os.path.dirname(os.path.dirname(CORNELL_XML)), "ref_scenes", "staircase2_shapes.npz"))
+    same_scene(a, cached)
+    # the disks are ceiling lights: their +z (the side an area emitter on Mitsuba's disk shines from) maps to world -y, and
+    # so do the geometric normals of their 320 triangle lights
+    disks = a.instances[a.instances["vertex_count"] == 192]
+    assert len(disks) == 5 and (disks["transform"][:, 9] < -0.1).all() and (np.abs(disks["transform"][:, [8, 10]]) < 1e-6).all()
+    lp = a.lights["positions"][:, :, :3].astype(np.float64)
+    n = np.cross(lp[:, 1] - lp[:, 0], lp[:, 2] - lp[:, 0])
+    area = 0.5 * np.linalg.norm(n, axis=1)
+    small = np.abs(area - 0.5 * np.sin(2 * np.pi / 64) * 0.104916 ** 2) < 1e-7
+    assert small.sum() == 320 and (n[small, 1] < 0).all() and (np.abs(n[small][:, [0, 2]]).max(1) < 1e-5 * np.abs(n[small, 1])).all()
+    d = host.Scene(staircase2_xml)  # default: skipped, said so
+    assert d.arrays().num_triangles == 30927 and sum("disk.obj" in w for w in d.warnings) == 5
+
+
+def test_cpp_loader_builtin_shapes_on_living_room():
+    """'The Modern Living Room' with its sphere light BUILT (radius 0.164 about `center`): 512 triangles and lights more;
+    C++ loader == numpy restatement == the GPU tests' fixture.  Needs the reference tree (build container)."""
+    from gpuspectral_amd import abi, host
+    from oracle import mitsuba_loader as ml
+
+    xml = os.path.join(REF_SCENES, "living-room", "scene.xml")
+    if not os.path.exists(xml):
+        pytest.skip("reference tree not available")
+    s = host.Scene(xml, builtin_shapes=True)
+    a, b = s.arrays(), ml.load_scene(xml, builtin_shapes=True)
+    same_scene(a, b)
+    assert a.num_triangles == 295904 + 512 and len(a.lights) == 512 and len(a.instances) == 29
+    cached = abi.SceneArrays.load(os.path.join(os.path.dirname(os.path.dirname(CORNELL_XML)), "ref_scenes", "living-room_shapes.npz"))
+    same_scene(a, cached)
+    lp = a.lights["positions"][:, :, :3].astype(np.float64)
+    c = np.array([-4.50891, 1.81441, -3.77121])
+    assert np.abs(np.linalg.norm(lp - c, axis=2) - 0.164157).max() < 1e-5
+
+
 def test_tone_map_and_ppm(tmp_path):
     """Presentation step: gamma 2.2 (ldrfilm) and the reference's dormant ACES fit (common.glsl:74-82)."""
     from gpuspectral_amd import host

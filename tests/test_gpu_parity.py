@@ -251,6 +251,32 @@ def test_render_interior_parity_with_oracle(ctx, oracle_mod):
     assert (got["t"][hit] == want["t"][hit]).all()
 
 
+@pytest.mark.parametrize("name,tris,lights", [("living-room_shapes", 296416, 512), ("staircase2_shapes", 31247, 336)])
+def test_reference_scenes_with_builtin_shapes(ctx, oracle_mod, name, tris, lights):
+    """SURVEY 8(f).1 finished: the two shipped scenes whose emitters sit on `sphere` / `disk` shapes,
+    loaded with LoadOptions::builtinShapes (tests/golden/ref_scenes/*_shapes.npz = the C++ loader's output, pinned against
+    the numpy restatement in tests/test_abi_and_host.py).  'The Modern Living Room' is LIT now (its frame was black), 'Modern
+    Hall' has its five ceiling disks: frames and ray counts equal the oracle's bit for bit."""
+    from conftest import GOLDEN
+    from gpuspectral_amd import abi
+
+    sc = abi.SceneArrays.load(os.path.join(GOLDEN, "ref_scenes", name + ".npz"))
+    assert sc.num_triangles == tris and len(sc.lights) == lights
+    ctx.upload_scene(sc)
+    o = oracle_mod.Oracle(sc)
+    W, H, spp = 256, 144, 3
+    ctx.frame_begin(W, H)
+    ctx.reset_stats()
+    ctx.render(spp=spp)
+    img = ctx.download().reshape(-1, 4)
+    st = ctx.stats()
+    ref, ost = o.render(W, H, spp=spp)
+    assert np.array_equal(img, ref)
+    assert st["extension_rays"] == ost["extension_rays"] and st["shadow_rays"] == ost["shadow_rays"] > W * H
+    lit = (img[:, :3] > 0).any(1).mean()
+    assert lit > 0.5, "only %.0f %% of the pixels received light" % (100 * lit)
+
+
 def test_living_room_reference_scene(ctx, oracle_mod):
     """SURVEY 8(f).1, the third of the reference's large shipped scenes: 'The Modern Living Room' as the product's C++
     loader flattens it (tests/golden/ref_scenes/living-room.npz: 295 904 triangles, 28 instances; diffuse, dielectric,

@@ -1,6 +1,7 @@
 """Per-scene throughput + traversal statistics on the GPU (no oracle): Mrays/s over >= ~4 s of work, kernel time split,
 BVH nodes / triangles per ray.  Scenes: the reference's shipped ones (tests/golden/ref_scenes/*.npz) and the generated
-stand-ins.   python tests/tools/scene_probe.py [coffee staircase2 cornell-box interior materials caustics]"""
+stand-ins.   python tests/tools/scene_probe.py [coffee staircase2 cornell-box interior materials caustics living-room_shapes staircase2_shapes]
+(`*_shapes`: the same scene loaded with LoadOptions::builtinShapes -- its `disk` / `sphere` emitters built instead of skipped)"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,6 +50,8 @@ with g.Context(0) as ctx:
                               shadow_tris_per_ray=round(s0["shadow_tris_tested"] / max(1, s0["shadow_stat_rays"]), 2),
                               # any-hit rays by verdict (is an occluder cache worth building?)
                               shadow_occluded_share=round(s0["shadow_stat_occluded"] / max(1, s0["shadow_stat_rays"]), 3),
+                              # shadow rays that never reached a triangle test (would a lazy shear set-up pay?)
+                              shadow_no_triangle_share=round(s0["shadow_stat_no_triangle"] / max(1, s0["shadow_stat_rays"]), 3),
                               occluded_nodes_per_ray=round(s0["shadow_stat_occluded_nodes"] / max(1, s0["shadow_stat_occluded"]), 2),
                               unoccluded_nodes_per_ray=round((s0["shadow_nodes_visited"] - s0["shadow_stat_occluded_nodes"]) /
                                                              max(1, s0["shadow_stat_rays"] - s0["shadow_stat_occluded"]), 2))), flush=True)
