@@ -457,8 +457,47 @@ struct Wide {
   bool quantised = false;
 };
 
+// r05: what would planes stored as FP8 E4M3 cost in node visits?  gfx950 converts TWO fp8 values per
+// half-rate instruction (v_cvt_scalef32_pk_f32_fp8: 12 instead of the node step's 24 v_cvt_f32_ubyte).  Encoding probed
+// (QUANT=fp8): `lo` planes as e4m3 offsets UP from the node's low corner, `hi` planes as e4m3 offsets DOWN from the node's high
+// reference corner lo + 256 * scale (scale = the power of two with extent <= 256 * scale), both rounded towards zero = outward.
+// E4M3 holds integers exactly up to 16 and then in steps of 2 / 4 / 8 / 16 up to 256: a plane q grid units from its corner
+// moves outward by up to q / 16 units (8 bits: never more than one unit).
+static float e4m3_floor(float v) {  // largest e4m3 value (OCP "fn": 3 mantissa bits, subnormal step 2^-9, max 448) <= v, v >= 0
+  if (!(v > 0.0f)) return 0.0f;
+  if (v >= 448.0f) return 448.0f;
+  int e;
+  (void)frexpf(v, &e);                        // v = f * 2^e, f in [0.5, 1)
+  float step = ldexpf(1.0f, std::max(e - 4, -9));  // 3 mantissa bits below the leading one; subnormals: 2^-9
+  return floorf(v / step) * step;
+}
+static void quantise_fp8(WNode& nd) {
+  Box b;
+  for (int k = 0; k < nd.n; ++k) b.grow(nd.c[k].box);
+  float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z}, sc[3];
+  for (int a = 0; a < 3; ++a) {
+    float ext = hi[a] - lo[a];
+    int ex = -100;
+    if (ext > 0) (void)frexpf(ext / 256.0f, &ex);
+    sc[a] = ldexpf(1.0f, ex);
+    while (lo[a] + 256.0f * sc[a] < hi[a]) sc[a] *= 2;
+  }
+  for (int k = 0; k < nd.n; ++k) {
+    float* cl = &nd.c[k].box.lo.x;
+    float* ch = &nd.c[k].box.hi.x;
+    for (int a = 0; a < 3; ++a) {
+      const float ref = lo[a] + 256.0f * sc[a];
+      const float ql = e4m3_floor(std::max(0.0f, (cl[a] - lo[a]) / sc[a]));
+      const float qh = e4m3_floor(std::max(0.0f, (ref - ch[a]) / sc[a]));
+      cl[a] = lo[a] + ql * sc[a];
+      ch[a] = ref - qh * sc[a];
+    }
+  }
+}
+
 // quantise the child boxes of a node to an 8-bit grid of the node box (outward), like encode_node4
 static void quantise(WNode& nd) {
+  if (getenv("QUANT") && !strcmp(getenv("QUANT"), "fp8")) return quantise_fp8(nd);
   Box b;
   for (int k = 0; k < nd.n; ++k) b.grow(nd.c[k].box);
   float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z}, sc[3];
