@@ -622,9 +622,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve(uint32_t num_pixels, uint32_
 
 // ---- resident table records ---------------------------------------------------------------------------------------------
 // once per gsp_upload_scene / gsp_update_tables: what a vertex would compute from its light / diffuse record alone (pt_shading.h)
+struct BakeTables {  // the resident BSDF tables: records of type t at rec[t] (stride rec_bytes[t]), their derived quads in front (derived_of)
+  uint8_t* rec[GSP_BSDF_TYPE_COUNT];
+  uint32_t rec_bytes[GSP_BSDF_TYPE_COUNT], num[GSP_BSDF_TYPE_COUNT];
+};
 __global__ __launch_bounds__(kBlock) void k_bake_tables(gsp_triangle_light* __restrict__ lights, uint32_t num_lights,
-                                                        gsp_diffuse_bsdf* __restrict__ diffuse, uint32_t num_diffuse) {
+                                                        gsp_diffuse_bsdf* __restrict__ diffuse, uint32_t num_diffuse, BakeTables bt) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  for (uint32_t t = 0; t < GSP_BSDF_TYPE_COUNT; ++t)  // (before the diffuse record is rewritten: bake_bsdf reads records as uploaded)
+    if (i < bt.num[t]) ((q4s*)bt.rec[t])[-1 - (int32_t)i] = bake_bsdf(t, bt.rec[t] + (size_t)i * bt.rec_bytes[t]);
   if (i < num_lights) {
     gsp_triangle_light L = lights[i];
     bake_light(L);
@@ -1104,6 +1110,9 @@ static int pack_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& i
       ctx->err = "null array with non-zero count";
       return GSP_ERR_SCENE;
     }
+    // a BSDF table is preceded by one derived quad per record (pt_shading.h derived_of / bake_bsdf; zero in the host image,
+    // filled on the device by k_bake_tables): off[k] is the table's FIRST RECORD
+    if (k < GSP_BSDF_TYPE_COUNT) img.total += 16 * (size_t)counts[k];
     img.off[k] = img.total;
     img.total += (bytes[k] + 15) & ~(size_t)15;
   }
@@ -1123,11 +1132,21 @@ static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage&
   ctx->num_lights = sc->num_lights;
   for (int k = 0; k < GSP_BSDF_TYPE_COUNT; ++k) ctx->num_bsdfs[k] = sc->num_bsdfs[k];
   // the resident light and diffuse records carry what a vertex would compute from them alone (pt_shading.h bake_light / bake_diffuse)
-  const uint32_t nb = std::max(sc->num_lights, sc->num_bsdfs[GSP_BSDF_DIFFUSE]);
+  uint32_t nb = sc->num_lights;
+  BakeTables bt;
+  const uint32_t rec_bytes[GSP_BSDF_TYPE_COUNT] = {sizeof(gsp_diffuse_bsdf), sizeof(gsp_smooth_dielectric_bsdf), sizeof(gsp_smooth_conductor_bsdf),
+                                                   sizeof(gsp_smooth_plastic_bsdf), sizeof(gsp_rough_conductor_bsdf), sizeof(gsp_smooth_floor_bsdf),
+                                                   sizeof(gsp_rough_floor_bsdf), sizeof(gsp_rough_plastic_bsdf)};
+  for (uint32_t t = 0; t < GSP_BSDF_TYPE_COUNT; ++t) {
+    bt.rec[t] = ctx->tables.p + img.off[t];
+    bt.rec_bytes[t] = rec_bytes[t];
+    bt.num[t] = sc->num_bsdfs[t];
+    nb = std::max(nb, sc->num_bsdfs[t]);
+  }
   if (nb) {
     hipLaunchKernelGGL(k_bake_tables, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
                        (gsp_triangle_light*)(ctx->tables.p + img.off[8]), sc->num_lights,
-                       (gsp_diffuse_bsdf*)(ctx->tables.p + img.off[GSP_BSDF_DIFFUSE]), sc->num_bsdfs[GSP_BSDF_DIFFUSE]);
+                       (gsp_diffuse_bsdf*)(ctx->tables.p + img.off[GSP_BSDF_DIFFUSE]), sc->num_bsdfs[GSP_BSDF_DIFFUSE], bt);
     CTX_TRY(ctx, hipGetLastError());
   }
   return GSP_OK;

@@ -170,6 +170,10 @@ GSP_HD float power_heuristic(float fPdf, float gPdf) {  // :206-210 with nf = ng
   return (f * f) / (f * f + g * g);
 }
 
+struct q4s {  // 16-byte quad (layout of pt_trace.h's q4; this header comes first)
+  float x, y, z, w;
+};
+
 // ---- Fresnel terms ------------------------------------------------------------
 GSP_HD float fresnel_polarized(float no, float cosTho, float nt, float cosTht) {  // :218-226
   float a = nt * cosTho - no * cosTht;
@@ -185,6 +189,18 @@ GSP_HD float fresnel_from_sin(float sinTho, float cosTho, float no, float nt) {
   float sqrtTerm = 1.0f - ((no * no) / (nt * nt)) * (sinTho * sinTho);
   if (sqrtTerm <= 0.0f) return 1.0f;
   return fresnel_polarized(no, cosTho, nt, gsqrt(sqrtTerm));
+}
+// ... with r2 = (no * no) / (nt * nt) taken from the record's derived quad (bake_bsdf): the same bits, no division
+GSP_HD float fresnel_from_sin_r2(float sinTho, float cosTho, float no, float nt, float r2) {
+  float sqrtTerm = 1.0f - r2 * (sinTho * sinTho);
+  if (sqrtTerm <= 0.0f) return 1.0f;
+  return fresnel_polarized(no, cosTho, nt, gsqrt(sqrtTerm));
+}
+GSP_HD float fresnel_wo_r2(f3 wo, float no, float nt, float r2) {
+  return fresnel_from_sin_r2(gsqrt(gmax(wo.x * wo.x + wo.y * wo.y, 0.0f)), gabs(wo.z), no, nt, r2);
+}
+GSP_HD float fresnel_cos_r2(float cosTho, float no, float nt, float r2) {
+  return fresnel_from_sin_r2(gsqrt(gmax(1.0f - cosTho * cosTho, 0.0f)), cosTho, no, nt, r2);
 }
 GSP_HD float fresnel_wo(f3 wo, float no, float nt) {  // :228-237
   return fresnel_from_sin(gsqrt(gmax(wo.x * wo.x + wo.y * wo.y, 0.0f)), gabs(wo.z), no, nt);
@@ -207,6 +223,14 @@ GSP_HD f3 fresnel_conductor(f3 eta, f3 k, float c) {  // FresnelDieletricConduct
   f3 t4 = t2 * s2;
   f3 Rp = (Rs * (t3 - t4)) / (t3 + t4);
   return 0.5f * (Rp + Rs);
+}
+GSP_HD float coupled_diffuse_k(float R0) { return 21.0f / ((20.0f * kPi) * (1.0f - R0)); }  // :302, record-only: bake_bsdf
+GSP_HD float coupled_diffuse_with(float k, float cosTho, float cosThi) {
+  float a = 1.0f - cosTho;
+  float b = 1.0f - cosThi;
+  float a5 = a * a * a * a * a;
+  float b5 = b * b * b * b * b;
+  return (k * (1.0f - a5)) * (1.0f - b5);
 }
 GSP_HD float coupled_diffuse(float R0, float cosTho, float cosThi) {  // :301-308
   float k = 21.0f / ((20.0f * kPi) * (1.0f - R0));
@@ -236,6 +260,9 @@ GSP_HD float schlick(float R0, float cosTho) {  // :326-330
 }
 
 // ---- BSDF records ----------------------------------------------------------------
+// r05: every resident BSDF table is PRECEDED by one derived quad per record (bake_bsdf below), in reverse order -- the quad of
+// record i of a table sits 16 (i + 1) bytes in front of the table's first record -- so that no kernel argument is spent on them
+GSP_HD q4s derived_of(const void* table, uint32_t i) { return ((const q4s*)table)[-1 - (int32_t)i]; }
 struct BsdfTables {
   const gsp_diffuse_bsdf* diffuse;
   const gsp_smooth_dielectric_bsdf* smooth_dielectric;
@@ -334,13 +361,14 @@ GSP_HD f3 plastic_diffuse(f3 kD, float Fri, float Fro, float eta, float Ri) {
   return ((((kD * (1.0f - Fri)) * (1.0f - Fro)) * eta) * eta) / (kPi * (1.0f - kD * Ri));
 }
 
-GSP_HD void rough_plastic_value(const gsp_rough_plastic_bsdf& b, f3 wo, f3 wi, f3& wh, f3& f, bool kd_on = false, f3 kd = f3{}) {
+// dv = the record's derived quad {r2, eta, Ri} (bake_bsdf)
+GSP_HD void rough_plastic_value(const gsp_rough_plastic_bsdf& b, const q4s& dv, f3 wo, f3 wi, f3& wh, f3& f, bool kd_on = false, f3 kd = f3{}) {
   float no = b.ior_out, nt = b.ior_in;
-  float eta = no / nt;
+  float eta = dv.y;  // no / nt
   wh = normalize(wi + wo);
-  float Fri = fresnel_cos(gabs(dot(wh, wo)), no, nt);
-  float Fro = fresnel_cos(gabs(dot(wh, wi)), no, nt);
-  float Ri = escape_fraction(b.r0, no, nt);
+  float Fri = fresnel_cos_r2(gabs(dot(wh, wo)), no, nt, dv.x);
+  float Fro = fresnel_cos_r2(gabs(dot(wh, wi)), no, nt, dv.x);
+  float Ri = dv.z;   // escape_fraction(b.r0, no, nt)
   f3 spec = ((splat(Fri) * ggx_d(wh, b.alpha)) * ggx_g(wo, wi, b.alpha)) / ((4.0f * gabs(wo.z)) * gabs(wi.z));
   f = plastic_diffuse(kd_on ? kd : ld3(b.diffuse), Fri, Fro, eta, Ri) + spec;
 }
@@ -394,9 +422,12 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
     case GSP_BSDF_SMOOTH_DIELECTRIC: {  // :362-398
       GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_smooth_dielectric_bsdf b = T.smooth_dielectric[i];
+      const q4s dv = derived_of(T.smooth_dielectric, i);
       bool entering = wo.z > 0.0f;
       float no = entering ? b.ior_out : b.ior_in;
       float nt = entering ? b.ior_in : b.ior_out;
+      const float r2 = entering ? dv.x : dv.y;   // (no * no) / (nt * nt)
+      const float eta = entering ? dv.z : dv.w;  // no / nt
       float cosTho = wo.z;
       r.delta = true;
       // refractRay (:290-299) against n = faceforward(+z, -wo, +z)
@@ -404,7 +435,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       // the sign of zero components of wt)
       const bool keep = -wo.z < 0.0f;
       float sinTho = gsqrt(gmax(wo.x * wo.x + wo.y * wo.y, 0.0f));
-      float sqrtTerm = 1.0f - ((no * no) / (nt * nt)) * (sinTho * sinTho);
+      float sqrtTerm = 1.0f - r2 * (sinTho * sinTho);
       if (sqrtTerm <= 0.0f) {  // total internal reflection
         wi = mirror(wo);
         r.f = 1.0f * splat(1.0f / gabs(cosTho));
@@ -414,7 +445,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       }
       float cosTht = gsqrt(sqrtTerm);
       f3 n = keep ? mk3(0.0f, 0.0f, 1.0f) : mk3(-0.0f, -0.0f, -1.0f);
-      f3 wt = (no / nt) * (-wo) + ((no / nt) * dot(wo, n) - cosTht) * n;
+      f3 wt = eta * (-wo) + (eta * dot(wo, n) - cosTht) * n;
       float Fr = fresnel_polarized(no, gabs(cosTho), nt, gabs(wt.z));
       float u = rand_uniform(rng);
       if (u < Fr) {
@@ -423,7 +454,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
         r.pdf = Fr;
       } else {
         wi = wt;
-        r.f = splat((((no * no) / (nt * nt)) * (1.0f - Fr)) / gabs(wt.z));
+        r.f = splat((r2 * (1.0f - Fr)) / gabs(wt.z));
         r.pdf = 1.0f - Fr;
       }
       GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_SMOOTH_DIELECTRIC);
@@ -431,7 +462,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
     case GSP_BSDF_SMOOTH_CONDUCTOR: {  // :406-418
       GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_smooth_conductor_bsdf b = T.smooth_conductor[i];
-      float Fr = b.ior_in == 0.0f ? 1.0f : fresnel_wo(wo, b.ior_out, b.ior_in);
+      float Fr = b.ior_in == 0.0f ? 1.0f : fresnel_wo_r2(wo, b.ior_out, b.ior_in, derived_of(T.smooth_conductor, i).x);
       wi = mirror(wo);
       r.f = Fr * splat(1.0f / gabs(wo.z));
       r.delta = true;
@@ -442,8 +473,9 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       GSP_PROF_BEGIN(PR_SAMPLE_T0);
       const gsp_smooth_plastic_bsdf b = T.smooth_plastic[i];
       float u = rand_uniform(rng);
+      const q4s dv = derived_of(T.smooth_plastic, i);
       float no = b.ior_out, nt = b.ior_in;
-      float Fri = fresnel_cos(gabs(wo.z), no, nt);
+      float Fri = fresnel_cos_r2(gabs(wo.z), no, nt, dv.x);
       cy.v.x = Fri;
       if (u < Fri) {
         wi = mirror(wo);
@@ -452,9 +484,9 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
         r.delta = true;
       } else {
         wi = sample_cosine_hemisphere(rng);
-        float Fro = fresnel_cos(gabs(wi.z), no, nt);
-        float Ri = escape_fraction(b.r0, no, nt);
-        float eta = no / nt;
+        float Fro = fresnel_cos_r2(gabs(wi.z), no, nt, dv.x);
+        float Ri = dv.z;   // escape_fraction(b.r0, no, nt)
+        float eta = dv.y;  // no / nt
         f3 kD = ld3(b.diffuse);
         // sample-side association differs from eval (:484 vs :500)
         r.f = ((((kD * eta) * eta) * (1.0f - Fri)) * (1.0f - Fro)) / (kPi * (1.0f - kD * Ri));
@@ -481,12 +513,12 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       float u = rand_uniform(rng);
       if (u < Fr) {
         wi = mirror(wo);
-        r.f = ld3(b.diffuse) * coupled_diffuse(b.r0, gabs(wo.z), gabs(wi.z)) + Fr * splat(1.0f / gabs(wo.z));
+        r.f = ld3(b.diffuse) * coupled_diffuse_with(derived_of(T.smooth_floor, i).x, gabs(wo.z), gabs(wi.z)) + Fr * splat(1.0f / gabs(wo.z));
         r.pdf = Fr;
         r.delta = true;
       } else {
         wi = sample_cosine_hemisphere(rng);
-        r.f = ld3(b.diffuse) * coupled_diffuse(b.r0, gabs(wo.z), gabs(wi.z));
+        r.f = ld3(b.diffuse) * coupled_diffuse_with(derived_of(T.smooth_floor, i).x, gabs(wo.z), gabs(wi.z));
         r.pdf = (1.0f - Fr) * cosine_pdf(wi);
       }
       GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_SMOOTH_FLOOR);
@@ -503,7 +535,7 @@ GSP_HD void bsdf_sample(const BsdfTables& T, uint32_t handle, uint32_t& rng, f3 
       const gsp_rough_plastic_bsdf b = T.rough_plastic[i];
       wi = sample_half_or_cosine(rng, wo, b.alpha);
       f3 wh;
-      rough_plastic_value(b, wo, wi, wh, r.f, kd_on, kd);
+      rough_plastic_value(b, derived_of(T.rough_plastic, i), wo, wi, wh, r.f, kd_on, kd);
       r.pdf = microfacet_pdf_half(wo, wh, b.alpha) + 0.5f * cosine_pdf(wi);
       GSP_PROF_END_T(PR_SAMPLE_T0, PR_SAMPLE_T0, GSP_BSDF_ROUGH_PLASTIC);
     } break;
@@ -535,10 +567,11 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
       GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_smooth_plastic_bsdf b = T.smooth_plastic[i];
       float no = b.ior_out, nt = b.ior_in;
+      const q4s dv = derived_of(T.smooth_plastic, i);
       float Fri = cy.v.x;  // = fresnel_cos(gabs(wo.z), no, nt), :495
-      float Fro = fresnel_cos(gabs(wi.z), no, nt);
-      float Ri = escape_fraction(b.r0, no, nt);
-      r.f = plastic_diffuse(ld3(b.diffuse), Fri, Fro, no / nt, Ri);
+      float Fro = fresnel_cos_r2(gabs(wi.z), no, nt, dv.x);
+      float Ri = dv.z;     // escape_fraction(b.r0, no, nt)
+      r.f = plastic_diffuse(ld3(b.diffuse), Fri, Fro, dv.y, Ri);
       r.pdf = (1.0f - Fri) * cosine_pdf(wi);
       GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_SMOOTH_PLASTIC);
     } break;
@@ -556,7 +589,7 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
       GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_smooth_floor_bsdf b = T.smooth_floor[i];
       float Fr = schlick(b.r0, gabs(wo.z));
-      r.f = ld3(b.diffuse) * coupled_diffuse(b.r0, gabs(wo.z), gabs(wi.z));
+      r.f = ld3(b.diffuse) * coupled_diffuse_with(derived_of(T.smooth_floor, i).x, gabs(wo.z), gabs(wi.z));
       r.pdf = (1.0f - Fr) * cosine_pdf(wi);
       GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_SMOOTH_FLOOR);
     } break;
@@ -569,7 +602,7 @@ GSP_HD void bsdf_eval(const BsdfTables& T, uint32_t handle, f3 wo, f3 wi, BsdfRe
       GSP_PROF_BEGIN(PR_EVAL_T0);
       const gsp_rough_plastic_bsdf b = T.rough_plastic[i];
       f3 wh;
-      rough_plastic_value(b, wo, wi, wh, r.f, kd_on, kd);
+      rough_plastic_value(b, derived_of(T.rough_plastic, i), wo, wi, wh, r.f, kd_on, kd);
       r.pdf = (0.5f * gmax(beckmann_d(wh, b.alpha) * gabs(wh.z), 0.01f)) / (4.0f * gabs(dot(wo, wh))) +
               0.5f * cosine_pdf(wi);
       GSP_PROF_END_T(PR_EVAL_T0, PR_EVAL_T0, GSP_BSDF_ROUGH_PLASTIC);
@@ -602,6 +635,47 @@ GSP_HD void bake_diffuse(gsp_diffuse_bsdf& b) {
   b.reflectance[0] = f.x;
   b.reflectance[1] = f.y;
   b.reflectance[2] = f.z;
+}
+
+// One derived quad per BSDF record: what sampleBSDF / evalBSDF compute from the record alone, with the shader's expressions
+//   smooth dielectric  {r2 entering, r2 leaving, eta entering, eta leaving}: r2 = (no no) / (nt nt), eta = no / nt  (:372,:290-299,:390)
+//   smooth conductor   {r2}                                                  with no = ior_out, nt = ior_in          (:228-237)
+//   smooth plastic, rough plastic  {r2, eta = no / nt, Ri = internalScatterEscapeFraction(r0, no, nt)}              (:239-247,:320-324)
+//   smooth floor       {k of coupledDiffuse = 21 / (20 pi (1 - R0))}                                                 (:302)
+// (escape_fraction and the Fresnel helpers are defined above; rough conductor / rough floor / diffuse: nothing here)
+GSP_HD q4s bake_bsdf(uint32_t type, const void* rec) {
+  q4s d{0.0f, 0.0f, 0.0f, 0.0f};
+  switch (type) {
+    case GSP_BSDF_SMOOTH_DIELECTRIC: {
+      const gsp_smooth_dielectric_bsdf& b = *(const gsp_smooth_dielectric_bsdf*)rec;
+      d.x = (b.ior_out * b.ior_out) / (b.ior_in * b.ior_in);  // entering: no = ior_out, nt = ior_in
+      d.y = (b.ior_in * b.ior_in) / (b.ior_out * b.ior_out);
+      d.z = b.ior_out / b.ior_in;
+      d.w = b.ior_in / b.ior_out;
+    } break;
+    case GSP_BSDF_SMOOTH_CONDUCTOR: {
+      const gsp_smooth_conductor_bsdf& b = *(const gsp_smooth_conductor_bsdf*)rec;
+      d.x = (b.ior_out * b.ior_out) / (b.ior_in * b.ior_in);
+    } break;
+    case GSP_BSDF_SMOOTH_PLASTIC: {
+      const gsp_smooth_plastic_bsdf& b = *(const gsp_smooth_plastic_bsdf*)rec;
+      d.x = (b.ior_out * b.ior_out) / (b.ior_in * b.ior_in);
+      d.y = b.ior_out / b.ior_in;
+      d.z = escape_fraction(b.r0, b.ior_out, b.ior_in);
+    } break;
+    case GSP_BSDF_ROUGH_PLASTIC: {
+      const gsp_rough_plastic_bsdf& b = *(const gsp_rough_plastic_bsdf*)rec;
+      d.x = (b.ior_out * b.ior_out) / (b.ior_in * b.ior_in);
+      d.y = b.ior_out / b.ior_in;
+      d.z = escape_fraction(b.r0, b.ior_out, b.ior_in);
+    } break;
+    case GSP_BSDF_SMOOTH_FLOOR: {
+      const gsp_smooth_floor_bsdf& b = *(const gsp_smooth_floor_bsdf*)rec;
+      d.x = coupled_diffuse_k(b.r0);
+    } break;
+    default: break;
+  }
+  return d;
 }
 
 // ---- light sampling (rayhit.rchit:123-153) ---------------------------------------

@@ -38,14 +38,30 @@ struct Emu {
   gsp_scene_desc sc;
   std::vector<gsp_instance> instances;
   std::vector<float> positions, normals, inv_t;
-  std::vector<gsp_diffuse_bsdf> b0;
-  std::vector<gsp_smooth_dielectric_bsdf> b1;
-  std::vector<gsp_smooth_conductor_bsdf> b2;
-  std::vector<gsp_smooth_plastic_bsdf> b3;
-  std::vector<gsp_rough_conductor_bsdf> b4;
-  std::vector<gsp_smooth_floor_bsdf> b5;
-  std::vector<gsp_rough_floor_bsdf> b6;
-  std::vector<gsp_rough_plastic_bsdf> b7;
+  // A resident BSDF table = one derived quad per record, in reverse order, in FRONT of the records (pt_shading.h derived_of):
+  // n quads, then the n records; data() points at the first record.
+  template <class R>
+  struct Table {
+    std::vector<q4s> store;
+    size_t n = 0;
+    void assign(const R* src, size_t count, uint32_t type) {
+      n = count;
+      store.assign(n + (n * sizeof(R) + 15) / 16 + 1, q4s{});
+      if (n) std::memcpy((void*)data(), src, n * sizeof(R));
+      for (size_t i = 0; i < n; ++i) store[n - 1 - i] = bake_bsdf(type, data() + i);  // as k_bake_tables (records as uploaded)
+    }
+    R* data() { return (R*)(store.data() + n); }
+    R* begin() { return data(); }
+    R* end() { return data() + n; }
+  };
+  Table<gsp_diffuse_bsdf> b0;
+  Table<gsp_smooth_dielectric_bsdf> b1;
+  Table<gsp_smooth_conductor_bsdf> b2;
+  Table<gsp_smooth_plastic_bsdf> b3;
+  Table<gsp_rough_conductor_bsdf> b4;
+  Table<gsp_smooth_floor_bsdf> b5;
+  Table<gsp_rough_floor_bsdf> b6;
+  Table<gsp_rough_plastic_bsdf> b7;
   std::vector<gsp_triangle_light> lights;
   std::vector<q4> nodes, isect, shade;
   std::vector<uint32_t> slot_to_global;
@@ -256,14 +272,14 @@ void* emu_create(const gsp_scene_desc* sc) {
   copyv(e->instances, sc->instances, sc->num_instances);
   copyv(e->positions, sc->positions, 3 * (size_t)sc->num_vertices);
   copyv(e->normals, sc->normals, 3 * (size_t)sc->num_vertices);
-  copyv(e->b0, sc->diffuse_bsdfs, sc->num_bsdfs[0]);
-  copyv(e->b1, sc->smooth_dielectric_bsdfs, sc->num_bsdfs[1]);
-  copyv(e->b2, sc->smooth_conductor_bsdfs, sc->num_bsdfs[2]);
-  copyv(e->b3, sc->smooth_plastic_bsdfs, sc->num_bsdfs[3]);
-  copyv(e->b4, sc->rough_conductor_bsdfs, sc->num_bsdfs[4]);
-  copyv(e->b5, sc->smooth_floor_bsdfs, sc->num_bsdfs[5]);
-  copyv(e->b6, sc->rough_floor_bsdfs, sc->num_bsdfs[6]);
-  copyv(e->b7, sc->rough_plastic_bsdfs, sc->num_bsdfs[7]);
+  e->b0.assign(sc->diffuse_bsdfs, sc->num_bsdfs[0], 0);
+  e->b1.assign(sc->smooth_dielectric_bsdfs, sc->num_bsdfs[1], 1);
+  e->b2.assign(sc->smooth_conductor_bsdfs, sc->num_bsdfs[2], 2);
+  e->b3.assign(sc->smooth_plastic_bsdfs, sc->num_bsdfs[3], 3);
+  e->b4.assign(sc->rough_conductor_bsdfs, sc->num_bsdfs[4], 4);
+  e->b5.assign(sc->smooth_floor_bsdfs, sc->num_bsdfs[5], 5);
+  e->b6.assign(sc->rough_floor_bsdfs, sc->num_bsdfs[6], 6);
+  e->b7.assign(sc->rough_plastic_bsdfs, sc->num_bsdfs[7], 7);
   copyv(e->lights, sc->lights, sc->num_lights);
   for (gsp_triangle_light& L : e->lights) bake_light(L);  // the resident records, as k_bake_tables leaves them
   for (gsp_diffuse_bsdf& b : e->b0) bake_diffuse(b);
