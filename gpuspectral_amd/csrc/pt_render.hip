@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
                                                       uint32_t first_timestamp,
                                                       const uint32_t* __restrict__ pixel_ids, PathQueue q,
                                                       uint32_t offset, uint32_t sid_base, const q4* __restrict__ memo,
-                                                      q4* __restrict__ hits, uint32_t lane, uint32_t lanes) {
+                                                      q4* __restrict__ hits, uint32_t lane, uint32_t lanes, uint32_t ver_bits) {
   // num_pixels = pixels of this pipeline lane: owned pixel lp * lanes + lane for lp in [0, num_pixels)
   const uint64_t total = (uint64_t)num_pixels * K;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kBlock) {
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
     const uint32_t sid = sid_base + (uint32_t)i;
     PathState p;
     generate_path(rc, gid, first_timestamp + k, sid, p);
+    p.flags |= ver_bits;  // the version of the BSDF / light tables this sample belongs to (pt_stages.h kVerMask)
     const uint64_t j = offset + i;
     qst(&q.P0[j], mkq(p.o.x, p.o.y, p.o.z, p.d.x));
     qst(&q.P1[j], mkq(p.d.y, p.d.z, ub(p.seed), ub(p.sid)));
@@ -278,7 +279,9 @@ constexpr int kShadeWaves = kShadeBlock / 64;
 // scripts/experiments/r04_shade_pipeline_lds_dma.patch): what the prefetch hides, the two extra gathers cost.
 // TEX: scene with textures / an environment map (dormant-feature extension): a second instantiation, so that the code
 // of the reference's path (TEX = false) is what it was
-template <bool TEX>
+// VER: tables of several versions are live (gsp_update_tables while samples were in flight): every vertex reads the version its
+// path carries, from HBM / L2 (no LDS copy: it would have to hold every live version)
+template <bool TEX, bool VER>
 __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(SceneView S, RenderConsts rc, const uint32_t* __restrict__ n_ptr, PathQueue cur,
                                                         const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
                                                         q4* __restrict__ result, uint32_t* __restrict__ tails,
@@ -290,8 +293,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   // fetches into them (material record after the shading packet, light record after the RNG draw): staged into LDS
   // once per block those become ~64-cycle reads instead of L2 round trips in a kernel whose 4 waves per SIMD cannot
   // hide them.
-  __shared__ uint4 s_tables[kShadeTableBytes / 16];
-  if (S.tables_bytes <= (uint32_t)kShadeTableBytes) {
+  __shared__ uint4 s_tables[VER ? 1 : kShadeTableBytes / 16];
+  if (!VER && S.tables_bytes <= (uint32_t)kShadeTableBytes) {
     const uint4* src = (const uint4*)S.tables;
     for (uint32_t k = threadIdx.x; k < S.tables_bytes / 16; k += kShadeBlock) s_tables[k] = src[k];
     const uint8_t* lb = (const uint8_t*)s_tables;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
         in.weight = mk3(p2.x, p2.y, p2.z);
         in.directWeight = p2.w;
         in.flags = fl;
-        shade_vertex<TEX>(S, rc, in, h, out);
+        shade_vertex<TEX, VER>(S, rc, in, h, out);
         alive = out.alive;
         has_shadow = out.has_shadow;
         ++shaded;
@@ -528,7 +531,7 @@ struct FinishStack {
   __device__ __forceinline__ uint32_t pop() { return col[(--top) * kBlock]; }
 };
 
-template <bool TEX>
+template <bool TEX, bool VER>
 __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc, uint32_t n, PathQueue q,
                                                     q4* __restrict__ result, uint32_t* __restrict__ tails,
                                                     uint32_t* __restrict__ live,
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
         break;
       }
       ShadeOut out;
-      shade_vertex<TEX>(S, rc, in, h, out);
+      shade_vertex<TEX, VER>(S, rc, in, h, out);
       ++shaded;
       if (!out.has_shadow) {
         add_emitted(rc.clamp, out.emitted, res);
@@ -715,9 +718,17 @@ struct gsp_context {
   DeviceBvh bvh;
   // the eight BSDF tables and the light table live back to back in ONE allocation (16-B aligned each), so that a kernel
   // can stage all of them into LDS with one cooperative copy when they are small (k_shade)
+  // r05: `tables` is a RING of kTableVersions slots of tab_slot_bytes each; version v of the tables sits in slot
+  // (v - tab_rot) % kTableVersions.  A sample carries its slot in its path flags, so gsp_update_tables need not wait for the
+  // samples in flight (they finish on the version they started with) as long as the new tables have the layout of the old ones
+  // and a slot is free.  While only ONE version is live it sits in slot 0 (tab_rot == tab_ver) and the flags field is 0.
   DevBuf<uint8_t> tables;
-  size_t table_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets: BSDF types 0..7, then the lights
+  size_t table_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets inside a slot: BSDF types 0..7, then the lights
   size_t tables_bytes = 0;
+  size_t tab_slot_bytes = 0;
+  uint32_t tab_ver = 0;  // version the next sample is generated under (monotonic)
+  uint32_t tab_rot = 0;  // version that slot 0 / flags field 0 stand for
+  uint32_t tab_slot(uint32_t v) const { return (v - tab_rot) % kTableVersions; }
   uint32_t num_lights = 0;
   gsp_camera camera{};
   double bvh_build_ms = 0.0;
@@ -760,6 +771,7 @@ struct gsp_context {
   // Streaming pipeline state: survives across gsp_render calls, drained by gsp_sync & friends.
   struct Batch {
     uint32_t t0, kb, slot;
+    uint32_t ver;  // table version its samples were generated under
   };
   struct Pipeline {
     bool active = false;
@@ -819,12 +831,22 @@ struct gsp_context {
   double memory_share = 0.4;        // of the free device memory, for the path pool + result ring (gsp_ctx_options.memory_share)
   bool pipe_active = false;
 
-  SceneView view() const {
+  // oldest table version a sample in flight may carry (= tab_ver when none is)
+  uint32_t oldest_live_version() const {
+    uint32_t o = tab_ver;
+    for (uint32_t l = 0; l < num_lanes; ++l)
+      if (lanes[l].pipe.active && !lanes[l].pipe.inflight.empty()) o = std::min(o, lanes[l].pipe.inflight.front().ver);
+    return o;
+  }
+  // versioned == false: the tables of the current version (all samples in flight belong to it); true: slot 0 of the ring +
+  // the stride, for the <VER> instantiations
+  SceneView view(bool versioned = false) const {
     SceneView v;
     v.nodes = bvh.nodes;
     v.tri_isect = bvh.tri_isect;
     v.tri_shade = bvh.tri_shade;
-    const uint8_t* tb = tables.p;
+    const uint8_t* tb = tables.p;  // slot 0: the one live version (versioned == false), or the base the <VER> kernels add their offset to
+    v.ver_stride = versioned ? (uint32_t)tab_slot_bytes : 0u;
     v.bsdf.diffuse = (const gsp_diffuse_bsdf*)(tb + table_off[0]);
     v.bsdf.smooth_dielectric = (const gsp_smooth_dielectric_bsdf*)(tb + table_off[1]);
     v.bsdf.smooth_conductor = (const gsp_smooth_conductor_bsdf*)(tb + table_off[2]);
@@ -1122,11 +1144,23 @@ static int pack_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& i
     if (bytes[k]) std::memcpy(img.bytes.data() + TableImage::kHead + img.off[k], src[k], bytes[k]);
   return GSP_OK;
 }
-// image -> device (queued on the context's stream; the image becomes the context's host copy, so the source stays alive)
-static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& img) {
-  CTX_TRY(ctx, ctx->tables.ensure(std::max<size_t>(img.total, 16), &ctx->bytes));
+// image -> device, as the NEXT version of the tables (queued on the context's stream; the image becomes the context's host copy,
+// so the source stays alive).  next_version == false: the pipeline is drained -- the ring is (re)allocated if the layout has
+// changed and the image becomes version tab_ver; true (gsp_update_tables with samples in flight, same layout, a free slot): the
+// image goes into the slot of tab_ver + 1, which no sample in flight reads, and becomes current.
+static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& img, bool next_version = false) {
+  const size_t slot = (std::max<size_t>(img.total, 16) + 255) & ~(size_t)255;
+  if (!next_version && (slot != ctx->tab_slot_bytes || !ctx->tables.p)) {
+    if (ctx->tables.p) ctx->bytes -= ctx->tables.count;
+    ctx->tables.release();
+    CTX_TRY(ctx, ctx->tables.ensure(slot * kTableVersions, &ctx->bytes));
+    ctx->tab_slot_bytes = slot;
+  }
+  if (next_version) ++ctx->tab_ver;
+  else ctx->tab_rot = ctx->tab_ver;  // nothing in flight: the tables go into slot 0
+  uint8_t* const base = ctx->tables.p + (size_t)ctx->tab_slot(ctx->tab_ver) * ctx->tab_slot_bytes;
   ctx->h_tables.swap(img.bytes);
-  CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->h_tables.data() + TableImage::kHead, std::max<size_t>(img.total, 16), hipMemcpyHostToDevice, ctx->stream));
+  CTX_TRY(ctx, hipMemcpyAsync(base, ctx->h_tables.data() + TableImage::kHead, std::max<size_t>(img.total, 16), hipMemcpyHostToDevice, ctx->stream));
   for (int k = 0; k < 9; ++k) ctx->table_off[k] = img.off[k];
   ctx->tables_bytes = img.total;
   ctx->num_lights = sc->num_lights;
@@ -1138,15 +1172,15 @@ static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage&
                                                    sizeof(gsp_smooth_plastic_bsdf), sizeof(gsp_rough_conductor_bsdf), sizeof(gsp_smooth_floor_bsdf),
                                                    sizeof(gsp_rough_floor_bsdf), sizeof(gsp_rough_plastic_bsdf)};
   for (uint32_t t = 0; t < GSP_BSDF_TYPE_COUNT; ++t) {
-    bt.rec[t] = ctx->tables.p + img.off[t];
+    bt.rec[t] = base + img.off[t];
     bt.rec_bytes[t] = rec_bytes[t];
     bt.num[t] = sc->num_bsdfs[t];
     nb = std::max(nb, sc->num_bsdfs[t]);
   }
   if (nb) {
     hipLaunchKernelGGL(k_bake_tables, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
-                       (gsp_triangle_light*)(ctx->tables.p + img.off[8]), sc->num_lights,
-                       (gsp_diffuse_bsdf*)(ctx->tables.p + img.off[GSP_BSDF_DIFFUSE]), sc->num_bsdfs[GSP_BSDF_DIFFUSE], bt);
+                       (gsp_triangle_light*)(base + img.off[8]), sc->num_lights,
+                       (gsp_diffuse_bsdf*)(base + img.off[GSP_BSDF_DIFFUSE]), sc->num_bsdfs[GSP_BSDF_DIFFUSE], bt);
     CTX_TRY(ctx, hipGetLastError());
   }
   return GSP_OK;
@@ -1397,9 +1431,20 @@ int gsp_update_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
   rc = pack_tables(ctx, sc, img);
   if (rc != GSP_OK) return rc;
   if (img.bytes == ctx->h_tables) return GSP_OK;  // same counts, same bytes: nothing to do, nothing to wait for
-  rc = pipeline_drain(ctx);
-  if (rc != GSP_OK) return rc;
-  rc = upload_tables(ctx, sc, img);  // (k_shade stages the tables per launch: nothing else holds a copy)
+  // r05: NO DRAIN when the new tables have the layout of the resident ones (same record counts: an edited colour, IOR, radiance
+  // -- what a per-frame edit is) and the version ring has a free slot: the samples in flight carry their version in the path
+  // flags and finish on the tables they started with, the next gsp_render generates under the new version.  (PathTracer.cpp:74-87
+  // re-reads the tables every frame; a host that edits a material every frame keeps the path pool full now,
+  // profiles/r05_update_latency.txt.)  Otherwise -- another layout, or kTableVersions edits within the life of one sample --
+  // the queued samples finish first, as until r04.
+  bool same_layout = ctx->pipe_active && sc->num_lights == ctx->num_lights && img.total == ctx->tables_bytes && ctx->tables.p != nullptr;
+  for (int k = 0; k < GSP_BSDF_TYPE_COUNT && same_layout; ++k) same_layout = sc->num_bsdfs[k] == ctx->num_bsdfs[k];
+  const bool in_place = same_layout && ctx->tab_ver + 1 - ctx->oldest_live_version() < kTableVersions;
+  if (!in_place) {
+    rc = pipeline_drain(ctx);
+    if (rc != GSP_OK) return rc;
+  }
+  rc = upload_tables(ctx, sc, img, in_place);  // (k_shade stages the tables per launch: nothing else holds a copy)
   if (rc != GSP_OK) {
     ctx->have_scene = false;
     return rc;
@@ -1545,6 +1590,20 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   const int cur = P.cur;
   gsp_context::Lane::Iter& I = L.it[t];
   I = gsp_context::Lane::Iter{};
+  // do the samples in flight belong to more than one version of the BSDF / light tables?  (only after a gsp_update_tables
+  // that did not drain: then k_shade / k_finish read every vertex's tables through the version its path carries)
+  const bool multi_version = ctx->oldest_live_version() != ctx->tab_ver;
+  if (!multi_version && ctx->tab_rot != ctx->tab_ver) {
+    // the edits are over and the samples of the older versions have ended: the one live version moves into slot 0 and the
+    // version field of the paths goes back to 0 (the <VER = false> kernels write 0).  Nothing reads slot 0 any more -- it held a
+    // version whose last sample the host has seen end -- and nothing but the launches queued from here on reads the new copy.
+    CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->tables.p + (size_t)ctx->tab_slot(ctx->tab_ver) * ctx->tab_slot_bytes, ctx->tab_slot_bytes,
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tab_rot = ctx->tab_ver;
+  }
+  const SceneView vview = multi_version ? ctx->view(true) : view;
+  const uint32_t gen_ver_bits = ctx->tab_slot(ctx->tab_ver) << kVerShift;  // (0 unless an edit is in flight)
 
   CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
   const bool use_memo = ctx->primary_memo && !stats_mode;
@@ -1566,12 +1625,20 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       ctx->bvh.depth + 2 <= kFinishLevels) {
     // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
     // on its own lane (not when gsp_render merely queues work: those paths ride along with the next call's)
-    if (ctx->textured)
-      hipLaunchKernelGGL(k_finish<true>, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
-                       L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+    const dim3 fgrid((uint32_t)((n + kBlock - 1) / kBlock));
+    if (multi_version) {
+      if (ctx->textured)
+        hipLaunchKernelGGL((k_finish<true, true>), fgrid, dim3(kBlock), 0, st, vview, rcst, (uint32_t)n, Q[cur], L.result.p, tails_out, live,
+                           (uint32_t)batch_paths, ctx->dstats.p);
+      else
+        hipLaunchKernelGGL((k_finish<false, true>), fgrid, dim3(kBlock), 0, st, vview, rcst, (uint32_t)n, Q[cur], L.result.p, tails_out, live,
+                           (uint32_t)batch_paths, ctx->dstats.p);
+    } else if (ctx->textured)
+      hipLaunchKernelGGL((k_finish<true, false>), fgrid, dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], L.result.p, tails_out, live,
+                         (uint32_t)batch_paths, ctx->dstats.p);
     else
-      hipLaunchKernelGGL(k_finish<false>, dim3((uint32_t)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur],
-                       L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+      hipLaunchKernelGGL((k_finish<false, false>), fgrid, dim3(kBlock), 0, st, view, rcst, (uint32_t)n, Q[cur], L.result.p, tails_out, live,
+                         (uint32_t)batch_paths, ctx->dstats.p);
     CTX_TRY(ctx, hipGetLastError());
     I.finish = true;
   } else {
@@ -1592,13 +1659,13 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       if (slot == P.num_slots || n + inj + paths > P.cap) break;
       hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
                          ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur ^ 1], (uint32_t)inj, (uint32_t)(slot * batch_paths),
-                         use_memo ? L.memo.p : (const q4*)nullptr, L.hits[cur ^ 1].p, L.index, ctx->num_lanes);
+                         use_memo ? L.memo.p : (const q4*)nullptr, L.hits[cur ^ 1].p, L.index, ctx->num_lanes, gen_ver_bits);
       CTX_TRY(ctx, hipGetLastError());
       CTX_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(live + slot), (int)paths, 1, st));
       L.h_live[slot] = (uint32_t)paths;
       L.live_since[slot] = L.enq;  // read-backs of earlier iterations still show the slot's previous state
       P.slot_used[slot] = 1;
-      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot});
+      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot, ctx->tab_ver});
       inj += paths;
       P.next_ts += kb;
       P.remaining -= kb;
@@ -1627,11 +1694,18 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       const uint32_t shade_grid = (uint32_t)std::max<uint64_t>(
           1, std::min<uint64_t>((std::max<uint64_t>(n, 1) + kShadeBlock - 1) / kShadeBlock,
                                 (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (GSP_SHADE_MINWAVES * 256 / kShadeBlock)));  // the resident blocks
-      if (ctx->textured)
-        hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
+      if (multi_version) {  // samples of several table versions in flight (gsp_update_tables without a drain)
+        if (ctx->textured)
+          hipLaunchKernelGGL((k_shade<true, true>), dim3(shade_grid), dim3(kShadeBlock), 0, st, vview, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
+                             L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+        else
+          hipLaunchKernelGGL((k_shade<false, true>), dim3(shade_grid), dim3(kShadeBlock), 0, st, vview, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
+                             L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+      } else if (ctx->textured)
+        hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
                            L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
       else
-        hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
+        hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
                            L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
       CTX_TRY(ctx, hipGetLastError());
       if (timing) CTX_TRY(ctx, hipEventRecord(ev[2], st));
@@ -1855,12 +1929,15 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       uint64_t ring_bytes = ctx->opt.ring_bytes;  // (default 16 GiB)
       {
         // Several contexts may share one GPU (the shares of gsp_multi on a test box, two viewers, ...): this pipeline
-        // takes at most gsp_ctx_options.memory_share (default 40 %) of the memory that is free now (plus what the lane already holds).  208 B of queues per
+        // takes at most gsp_ctx_options.memory_share (default 40 %) of the device's memory (plus what the lane already holds).  208 B of queues per
         // path of capacity (2 x 64-B path records, 2 x 16-B hit, 48-B shadow record), capacity = 2 x the pool target.
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
           const uint64_t have = L.pool_cap * 208ull + L.result_cap * sizeof(q4);
-          const uint64_t budget = (uint64_t)((double)free_b * ctx->memory_share) + have;
+          // r05: the share is of the device's TOTAL memory (two contexts created one after the other get the same budget --
+          // until r04 it was a share of what was FREE at that moment, so the second one sized itself by the first), and never
+          // more than 90 % of what is free now
+          const uint64_t budget = std::min((uint64_t)((double)total_b * ctx->memory_share), (uint64_t)((double)free_b * 0.9)) + have;
           const uint64_t queues = (2 * P.pool_target + P.batch_paths) * 208ull;
           if (queues > budget / 2) {
             const uint64_t fit = budget / 2 / 208ull;  // paths of capacity that fit

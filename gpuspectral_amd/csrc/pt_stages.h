@@ -47,13 +47,20 @@ struct SceneView {
   int32_t root;
   const uint8_t* tables = nullptr;  // the BSDF tables + lights back to back (device: one allocation), for LDS staging
   uint32_t tables_bytes = 0;
+  uint32_t ver_stride = 0;          // <VER = true> instantiations: bytes between two versions of the tables (slot 0 is what the pointers name)
   TextureView tex;                  // dormant-feature extension; read only by the <TEX = true> instantiations
 };
 
-// path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9
+// path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9 | table version << 10 [10,15]
 GSP_HD uint32_t pack_flags(uint32_t depth, uint32_t wasDelta, uint32_t countEmitted) {
   return depth | (wasDelta << 8) | (countEmitted << 9);
 }
+// r05: a path carries the VERSION of the BSDF / light tables it was generated under (gsp_update_tables without a drain: the
+// samples in flight finish on the tables they started with, new samples read the new ones; the versions live in a ring of
+// kTableVersions slots, SceneView::ver_stride bytes apart).  Stamped by k_generate, handed on by shade_vertex<VER = true>.
+// While every sample in flight belongs to ONE version -- always, for a scene that is not being edited -- that version sits in
+// slot 0, the field is 0 and the <VER = false> kernels neither read nor write it: their code is what it was before versions existed.
+constexpr uint32_t kVerShift = 10, kTableVersions = 64, kVerMask = (kTableVersions - 1u) << kVerShift;
 
 struct PathState {
   f3 o, d;
@@ -111,10 +118,28 @@ struct ShadeOut {
 // TEX: the scene carries textures (include/gpuspectral_pt.h, dormant-feature extension).  The reference's shader
 // passes uv = vec2(0) and never reads a texture (rayhit.rchit:716,729): TEX = false is that code, instruction for
 // instruction; TEX = true interpolates the hit's uv and, for a record with has_texture, takes kD from the texture.
-template <bool TEX = false>
+// VER: tables of several versions are live (an edit through gsp_update_tables while samples were in flight): the vertex reads
+// the version its path carries.  VER = false is the code of a scene that is not being edited, instruction for instruction.
+template <bool TEX = false, bool VER = false>
 GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathState& in, const HitRec& hit,
                          ShadeOut& out) {
   uint32_t rng = in.seed;                                                 // rchit:668
+  BsdfTables Tv;  // (VER only: this lane's version of the tables)
+  const gsp_triangle_light* lights_v = nullptr;
+  if (VER) {
+    const size_t voff = (size_t)((in.flags & kVerMask) >> kVerShift) * S.ver_stride;
+    Tv.diffuse = (const gsp_diffuse_bsdf*)((const char*)S.bsdf.diffuse + voff);
+    Tv.smooth_dielectric = (const gsp_smooth_dielectric_bsdf*)((const char*)S.bsdf.smooth_dielectric + voff);
+    Tv.smooth_conductor = (const gsp_smooth_conductor_bsdf*)((const char*)S.bsdf.smooth_conductor + voff);
+    Tv.smooth_plastic = (const gsp_smooth_plastic_bsdf*)((const char*)S.bsdf.smooth_plastic + voff);
+    Tv.rough_conductor = (const gsp_rough_conductor_bsdf*)((const char*)S.bsdf.rough_conductor + voff);
+    Tv.smooth_floor = (const gsp_smooth_floor_bsdf*)((const char*)S.bsdf.smooth_floor + voff);
+    Tv.rough_floor = (const gsp_rough_floor_bsdf*)((const char*)S.bsdf.rough_floor + voff);
+    Tv.rough_plastic = (const gsp_rough_plastic_bsdf*)((const char*)S.bsdf.rough_plastic + voff);
+    lights_v = (const gsp_triangle_light*)((const char*)S.lights + voff);
+  }
+  const BsdfTables& T = VER ? Tv : S.bsdf;
+  const gsp_triangle_light* lights = VER ? lights_v : S.lights;
   GSP_PROF_BEGIN(PR_PACKET);
   const q4* sp = S.tri_shade + 4ll * hit.slot;
   const q4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
@@ -138,7 +163,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   bool kd_on = false;
   f3 kd = splat(0.0f);
   if (TEX) {
-    const uint32_t tid = bsdf_texture(S.bsdf, bsdf);
+    const uint32_t tid = bsdf_texture(T, bsdf);
     if (tid != 0u && tid <= S.tex.num_textures && S.tex.tri_uv != nullptr) {
       const q4* uv = (const q4*)S.tex.tri_uv + 2ll * hit.slot;  // {u0 v0 u1 v1}, {u2 v2 - -}
       const q4 ua = uv[0], ub2 = uv[1];
@@ -153,13 +178,13 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   GSP_PROF_END(PR_PACKET);
   GSP_PROF_BEGIN(PR_SAMPLE);
   BsdfCarry cy;
-  bsdf_sample(S.bsdf, bsdf, rng, wo, wi_l, bs, cy, kd_on, kd);       // :716
+  bsdf_sample(T, bsdf, rng, wo, wi_l, bs, cy, kd_on, kd);            // :716
   GSP_PROF_END(PR_SAMPLE);
   GSP_PROF_BEGIN(PR_LIGHT);
   const float NoW = gabs(wi_l.z);                                         // :717
   const f3 wi = to_world(onb, wi_l);                                      // :718
 
-  const LightSample ls = sample_light(S.lights, S.num_lights, S.inv_num_lights, rng, position);  // :720
+  const LightSample ls = sample_light(lights, S.num_lights, S.inv_num_lights, rng, position);  // :720
   const f3 toL = ls.position - position;
   const f3 L = normalize(toL);                                            // :722
   const f3 wL = to_local(onb, L);                                         // :723
@@ -169,7 +194,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   BsdfResult lb;
   GSP_PROF_END(PR_LIGHT);
   GSP_PROF_BEGIN(PR_EVAL);
-  bsdf_eval(S.bsdf, bsdf, wo, wL, lb, cy, kd_on, kd);                // :729
+  bsdf_eval(T, bsdf, wo, wL, lb, cy, kd_on, kd);                     // :729
   GSP_PROF_END(PR_EVAL);
   GSP_PROF_BEGIN(PR_TAIL);
 
@@ -215,7 +240,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   }
   if (depth > rc.max_depth) alive = false;                                // rgen:73-75
   if (done) alive = false;                                                // rgen:77-78
-  nx.flags = pack_flags(depth + 1u, bs.delta ? 1u : 0u, 0u);              // rgen:80, rchit:792,796
+  nx.flags = pack_flags(depth + 1u, bs.delta ? 1u : 0u, 0u) | (VER ? (in.flags & kVerMask) : 0u);  // rgen:80, rchit:792,796; VER: the version rides along
 
   out.alive = alive;
   out.next = nx;

@@ -338,8 +338,9 @@ typedef struct gsp_ctx_options {
   uint32_t lanes;            /* independent pipelines per context, 1 (default) or 2                                   */
   uint64_t pool_paths;       /* paths in flight the pool aims at (default 96 Mi; at most 192 per owned pixel)         */
   uint64_t ring_bytes;       /* upper bound of the sample-result ring (default 16 GiB)                                */
-  double memory_share;       /* share of the device memory that is FREE when a render starts which path pool + ring
-                                may take, 0.01 .. 0.9 (default 0.4): what to lower when several contexts share a GPU  */
+  double memory_share;       /* share of the device's TOTAL memory which path pool + ring may take (r05; until r04: of the
+                                memory FREE when a render starts, so contexts sized themselves by creation order), never
+                                more than 90 % of what is free; 0.01 .. 0.9 (default 0.4): lower it when contexts share a GPU */
   uint32_t primary_memo;     /* 0 default (on), 1 on, 2 off: trace the camera ray of a pixel once per frame           */
   uint32_t finish_paths;     /* k_finish takes over a drain below this many live paths; 0 default (262144),
                                 0xffffffff = never                                                                    */

@@ -136,7 +136,7 @@ def instruction_stream(body):
 
 # the three render kernels as bench.py names them -> substring of the mangled symbol (non-STATS, non-TEX instantiations)
 RENDER_KERNELS = {"k_trace_extend": "k_traceILb0ELb0ENS_12_GLOBAL__N_18ExtendIO", "k_trace_connect": "k_traceILb1ELb0ENS_12_GLOBAL__N_19ConnectIO",
-                  "k_shade": "k_shadeILb0E"}
+                  "k_shade": "k_shadeILb0ELb0E"}
 
 
 def dynamic_mean_cost(classes, dyn, total):

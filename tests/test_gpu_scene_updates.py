@@ -383,3 +383,65 @@ def test_random_edits_fuzz(oracle_mod):
         for seed in range(7100, 7110):
             ok, ndiff, tris = fuzz_parity.check(ctx, oracle_mod, seed, nee=0)
             assert ok, "seed %d with nee = 0: %d pixels differ (%d triangles)" % (seed, ndiff, tris)
+
+
+@pytest.mark.parametrize("which", ["cornell", "materials"])
+def test_table_edits_every_frame_without_a_drain(oracle_mod, cornell, materials_scene, which):
+    """(r05) gsp_update_tables with samples IN FLIGHT keeps them in flight: a sample carries the version of
+    the BSDF / light tables it was generated under and finishes on it (a ring of 64 versions; an edit that changes the record
+    counts, or the 64th edit within the life of one sample, still drains).  One sample per frame, a reflectance and the light's
+    radiance edited before EVERY frame, 150 frames without a sync: more than two rounds of the ring, paths of a dozen versions in
+    one launch.  The accumulate buffer must equal the oracle's running mean over the same sequence of scenes, bit for bit --
+    and after the edits stop, the frames of the single surviving version too (the <VER = false> kernels again)."""
+    import copy
+
+    import gpuspectral_amd as g
+
+    sc = copy.deepcopy(cornell if which == "cornell" else materials_scene)
+    W, H = (48, 40) if which == "cornell" else (40, 32)
+    frames = 150 if which == "cornell" else 70
+
+    def edit(k):
+        bs = [b.copy() for b in sc.bsdfs]
+        n = len(bs[0])
+        bs[0]["reflectance"][k % n] = (0.1 + 0.8 * ((k * 7) % 11) / 11.0, 0.2 + 0.6 * ((k * 3) % 5) / 5.0, 0.9 - 0.7 * ((k * 5) % 7) / 7.0)
+        if which == "materials" and len(bs[4]):
+            bs[4]["alpha"][k % len(bs[4])] = np.float32(0.05 + 0.02 * (k % 9))
+        sc.bsdfs = bs
+        lights = sc.lights.copy()
+        lights["radiance"][:, :3] = np.array([17.0, 12.0, 4.0], np.float32) * np.float32(0.5 + 0.1 * (k % 6))
+        sc.lights = lights
+
+    acc = None
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        for k in range(frames):
+            edit(k)
+            ctx.update_tables(sc)  # no sync anywhere in this loop
+            ctx.render(spp=1, first_timestamp=k)
+            acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+        img = ctx.download().reshape(-1, 4)
+        assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(1).sum())
+        assert ctx.stats()["scene_updates"] == frames
+        # the edits are over: more samples of the last version (the pipeline goes back to one version in slot 0), then one more
+        # edit with nothing but that version in flight
+        ctx.render(spp=3, first_timestamp=frames)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=3, first_timestamp=frames, accum=acc)
+        edit(frames + 1)
+        ctx.update_tables(sc)
+        ctx.render(spp=2, first_timestamp=frames + 3)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=2, first_timestamp=frames + 3, accum=acc)
+        assert np.array_equal(ctx.download().reshape(-1, 4), acc)
+        # a layout change (one more diffuse record) with samples in flight takes the old road: drain, then upload
+        ctx.render(spp=1, first_timestamp=frames + 5)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=frames + 5, accum=acc)
+        bs = [b.copy() for b in sc.bsdfs]
+        extra = bs[0][:1].copy()
+        extra["reflectance"][0] = (0.3, 0.3, 0.3)
+        bs[0] = np.concatenate([bs[0], extra])
+        sc.bsdfs = bs
+        ctx.update_tables(sc)
+        ctx.render(spp=2, first_timestamp=frames + 6)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=2, first_timestamp=frames + 6, accum=acc)
+        assert np.array_equal(ctx.download().reshape(-1, 4), acc)
