@@ -149,6 +149,12 @@ struct RayShearRot {
   float Sx, Sy, Sz;
 };
 GSP_HD float bit_select(uint32_t m, float a, float b) {  // m ? a : b, bitwise
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (m & a) | (~m & b) as ONE v_bitop3_b32 (truth table 0xCA), which issues at full rate; the compiler's own choice for this
+  // pattern is v_bfi_b32 -- half rate on gfx950 (4.24 vs 2.69 cycles, profiles/r05_valu_rate.txt), 27 of them per leaf step
+  // (r05: closest-hit kernel -0.5 %, profiles/r05_ab_bitop3.txt)
+  return __uint_as_float(__builtin_amdgcn_bitop3_b32(m, __float_as_uint(a), __float_as_uint(b), 0xCA));
+#else
   uint32_t ua, ub;
   __builtin_memcpy(&ua, &a, 4);
   __builtin_memcpy(&ub, &b, 4);
@@ -156,6 +162,7 @@ GSP_HD float bit_select(uint32_t m, float a, float b) {  // m ? a : b, bitwise
   float f;
   __builtin_memcpy(&f, &r, 4);
   return f;
+#endif
 }
 // (x, y, z) -> (component kx, ky, kz): kz by the masks, kx = kz + 1, ky = kz + 2 (mod 3), exchanged where ms is set
 GSP_HD f3 permute_axes(const RayShearRot& rs, f3 p) {

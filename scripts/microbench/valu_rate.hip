@@ -121,6 +121,7 @@ K4_3(k_min3f, "v_min3_f32")
 DEFINE_KERNEL(k_cvtscalefp8, "v_cvt_scalef32_pk_f32_fp8 v[100:101], %0, %4\n v_cvt_scalef32_pk_f32_fp8 v[102:103], %1, %4\n v_cvt_scalef32_pk_f32_fp8 v[104:105], %2, %4\n v_cvt_scalef32_pk_f32_fp8 v[106:107], %3, %4\n")
 DEFINE_KERNEL(k_lshladd64, "v_lshl_add_u64 v[100:101], v[102:103], 2, v[104:105]\n v_lshl_add_u64 v[102:103], v[100:101], 2, v[104:105]\n v_lshl_add_u64 v[100:101], v[102:103], 2, v[106:107]\n v_lshl_add_u64 v[102:103], v[100:101], 2, v[106:107]\n")
 DEFINE_KERNEL(k_cmpu64, "v_cmp_lt_u64_e32 vcc, v[100:101], v[102:103]\n v_cmp_lt_u64_e32 vcc, v[104:105], v[106:107]\n v_cmp_lt_u64_e32 vcc, v[100:101], v[102:103]\n v_cmp_lt_u64_e32 vcc, v[104:105], v[106:107]\n")
+K4_3(k_bfi, "v_bfi_b32")
 K4(k_mulhi, "v_mul_hi_u32")
 K4(k_max3u, "v_max_i32_e32")
 
@@ -149,7 +150,7 @@ int main() {
                       {"v_div_scale_f32", k_divscale}, {"v_div_fmas_f32", k_divfmas}, {"v_div_fixup_f32", k_divfixup}, {"v_sqrt_f32", k_sqrt}, {"v_rsq_f32", k_rsq},
                       {"v_cmp_class_f32 -> vcc", k_cmpclass}, {"v_rndne_f32", k_rndne}, {"v_cvt_i32_f32", k_cvti32}, {"v_cvt_u32_f32", k_cvtu32f},
                       {"v_mbcnt_lo_u32_b32", k_mbcnt}, {"v_ldexp_f32", k_ldexp}, {"v_min3_f32", k_min3f}, {"v_cvt_scalef32_pk_f32_fp8", k_cvtscalefp8},
-                      {"v_lshl_add_u64", k_lshladd64}, {"v_cmp_lt_u64 -> vcc", k_cmpu64}, {"v_mul_hi_u32", k_mulhi}, {"v_max_i32", k_max3u}};
+                      {"v_lshl_add_u64", k_lshladd64}, {"v_cmp_lt_u64 -> vcc", k_cmpu64}, {"v_bfi_b32", k_bfi}, {"v_mul_hi_u32", k_mulhi}, {"v_max_i32", k_max3u}};
   const int loops = 20000;
   unsigned long long* out; float* sink;
   CHECK(hipMalloc(&out, 1 << 20)); CHECK(hipMalloc(&sink, 4));

@@ -726,6 +726,52 @@ def test_cpp_cli_options(tmp_path, oracle_mod, cornell):
     assert r.returncode == 2 and "unknown option" in r.stderr
 
 
+def test_cpp_cli_builtin_shapes(tmp_path, oracle_mod, staircase2_xml):
+    """`gsp_render --builtin-shapes` (LoadOptions::builtinShapes, r05): the C++ host end to end on 'Modern Hall' with its five
+    `disk` ceiling lights built -- the frame equals the oracle on the numpy loader's arrays of the same options, and differs
+    from the default load (the reference's: disks skipped)."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+    from oracle import mitsuba_loader as ml
+
+    lib = os.path.join(ROOT, "gpuspectral_amd", "lib")
+    env = dict(os.environ, LD_LIBRARY_PATH=lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    imgs = {}
+    for name, flags in (("shapes", ["--builtin-shapes"]), ("plain", [])):
+        out = str(tmp_path / (name + ".pfm"))
+        r = subprocess.run([os.path.join(lib, "gsp_render")] + flags + [staircase2_xml, out, "80", "60", "2"], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        with open(out, "rb") as f:
+            assert f.readline() == b"PF\n"
+            w, h = map(int, f.readline().split())
+            f.readline()
+            imgs[name] = np.frombuffer(f.read(), np.float32).reshape(h, w, 3)[::-1].reshape(-1, 3)
+    ref, _ = oracle_mod.Oracle(ml.load_scene(staircase2_xml, builtin_shapes=True)).render(80, 60, spp=2)
+    assert np.array_equal(imgs["shapes"], ref[:, :3])
+    assert not np.array_equal(imgs["shapes"], imgs["plain"])
+
+
+def test_zeroed_render_params_are_the_reference(ctx, oracle_mod, cornell):
+    """a C host that zero-initialises gsp_render_params and fills the fields it knows must get the reference as
+    shipped (`#define NEE true`): the appended field is `disable_nee`, 0 = on."""
+    from gpuspectral_amd import abi
+
+    p = abi.RenderParams()  # all zero
+    p.spp, p.max_depth, p.rr_start_depth, p.clamp = 2, 50, 10, 20.0
+    assert p.disable_nee == 0
+    ctx.upload_scene(cornell)
+    ctx.frame_begin(64, 48)
+    ctx.reset_stats()
+    ctx.render(spp=2, params=p)
+    img = ctx.download().reshape(-1, 4)
+    st = ctx.stats()
+    ref, ost = oracle_mod.Oracle(cornell).render(64, 48, spp=2)
+    assert np.array_equal(img, ref) and st["shadow_rays"] == ost["shadow_rays"] > 0
+
+
 def test_random_scene_fuzz_matches_oracle(ctx, oracle_mod):
     """tests/tools/fuzz_parity.py: random small scenes with all eight BSDF types at ordinary and extreme parameters,
     mirrored / non-uniformly scaled instances, several lights, random cameras: frames (NaN pixels included) and
