@@ -265,7 +265,10 @@ struct TestIO {  // gsp_trace
 #define GSP_SHADE_BLOCK 256
 #endif
 constexpr int kShadeBlock = GSP_SHADE_BLOCK;
-constexpr int kShadeTableBytes = 8192;  // BSDF + light tables up to this size are staged into LDS by k_shade
+#ifndef GSP_SHADE_TABLE_BYTES
+#define GSP_SHADE_TABLE_BYTES 8192
+#endif
+constexpr int kShadeTableBytes = GSP_SHADE_TABLE_BYTES;  // BSDF + light tables up to this size are staged into LDS by k_shade
 constexpr int kShadeWaves = kShadeBlock / 64;
 #ifndef GSP_SHADE_GRID_MULT
 #define GSP_SHADE_GRID_MULT 1  // grid = exactly the resident blocks, each loops over tiles
