@@ -77,7 +77,9 @@ struct ShadowQueue {
 // (4.2 rays per sample) ran 3 M-path launches in a 32 M-path pool (profiles/r02_scene_probe.txt).
 constexpr int kMaxSlots = 1024;
 constexpr int kTailSet = 32;  // words per tail set
-enum { T_NEXT = 0, T_SHADOW = 1, T_FIN_EXT = 2, T_FIN_SH = 4 };  // within a tail set (the two 64-bit k_finish totals are 8-byte aligned)
+constexpr uint32_t kFillerSid = 0xffffffffu;  // sample-id word of a queue record that is no path (k_shade's chunked reservation)
+enum { T_NEXT = 0, T_SHADOW = 1, T_FIN_EXT = 2, T_FIN_SH = 4,  // within a tail set (the two 64-bit k_finish totals are 8-byte aligned)
+       T_HOLES_NEXT = 6, T_HOLES_SHADOW = 7 };                   // filler records behind the blocks' last chunks (chunked reservation)
 enum { C_LIVE = 2 * kTailSet, C_READBACK = C_LIVE + kMaxSlots,
        C_WORK_EXT = ((C_READBACK + 31) / 32) * 32, C_WORK_SH = C_WORK_EXT + kWorkShards * kWorkStride,
        C_COUNT = C_WORK_SH + kWorkShards * kWorkStride };
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
                                                         const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
                                                         q4* __restrict__ result, uint32_t* __restrict__ tails,
                                                         uint32_t* __restrict__ live,
-                                                        uint32_t slot_paths, DevStats* __restrict__ stats) {
+                                                        uint32_t slot_paths, uint32_t chunk, DevStats* __restrict__ stats) {
   const uint32_t n = *n_ptr;  // written by the previous iteration's k_shade / the host's memset (stream order)
 #ifndef GSP_NO_LDS_TABLES
   // The BSDF and light tables of a scene are a few hundred bytes to a few KB, and every vertex makes two DEPENDENT
@@ -331,7 +333,10 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   __shared__ uint32_t s_bin[12];               // counting sort of the tile by BSDF type: counts, then starts
   __shared__ uint16_t s_order[kShadeBlock];    // sorted position -> thread offset inside the tile
   __shared__ uint32_t s_cnt[2][kShadeWaves];   // per-wave survivor / shadow counts of this iteration
-  __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave start in the global queues
+  __shared__ uint32_t s_base[2][kShadeWaves];  // per-wave first rank among the tile's survivors / shadow rays
+  __shared__ uint32_t s_alloc[2][3];           // where those ranks go: rank r < R ? A + r : B + (r - R)   {A, R, B}
+  __shared__ uint32_t s_room[2][2];            // the block's current chunk of each queue: {next free entry, end}
+  if (threadIdx.x < 4) s_room[threadIdx.x >> 1][threadIdx.x & 1] = 0;
   __shared__ q4 s_hq[kShadeBlock], s_p0[kShadeBlock], s_p1[kShadeBlock], s_p2[kShadeBlock], s_p3[kShadeBlock];
   for (uint32_t k = threadIdx.x; k < (uint32_t)kMaxSlots; k += kShadeBlock) s_dead[k] = 0;
 #ifdef GSP_SHADE_PROFILE
@@ -365,11 +370,13 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
         const q4 hq0 = qld(&hits[i0]);
         s_hq[threadIdx.x] = hq0;
         s_p0[threadIdx.x] = qld(&cur.P0[i0]);
-        s_p1[threadIdx.x] = qld(&cur.P1[i0]);
+        const q4 p1q = qld(&cur.P1[i0]);
+        s_p1[threadIdx.x] = p1q;
         s_p2[threadIdx.x] = qld(&cur.P2[i0]);
         s_p3[threadIdx.x] = qld(&cur.P3[i0]);
         const uint32_t w = fb(hq0.w);
         key = (w == 0xffffffffu) ? 8u : ((w >> 28) & 7u);
+        if (fb(p1q.w) == kFillerSid) key = 9u;  // a filler record behind some block's last chunk: not a path
       }
       const uint32_t rank = atomicAdd(&s_bin[key], 1u);
       __syncthreads();
@@ -401,7 +408,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       if (lane == 0) atomicAdd(gsp_prof_table() + 4 * (PR_TYPES_IN_WAVE + kinds), 1ull);
     }
 #endif
-    if (i < n) {
+    const bool valid = i < n && fb(s_p1[src].w) != kFillerSid;
+    if (valid) {
       GSP_PROF_BEGIN(PR_FETCH);
       const q4 hq = s_hq[src];
       const q4 p0 = s_p0[src], p1 = s_p1[src], p2 = s_p2[src];
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     // reaches 0): summed per block in LDS, flushed once at the end of the kernel
     GSP_PROF_BEGIN(PR_COMPACT);
     {
-      const bool died = (i < n) && !alive;
+      const bool died = valid && !alive;
       uint64_t dm = __ballot(died);
       const uint32_t slot = my_sid / slot_paths;
       while (dm) {  // wave-uniform; lanes of a wave almost always share a slot
@@ -466,18 +474,47 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       s_cnt[1][wave] = (uint32_t)__popcll(sm);
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
-      const int q = threadIdx.x;
-      uint32_t tot = 0;
-      for (int w = 0; w < kShadeWaves; ++w) tot += s_cnt[q][w];
-      uint32_t base = tot ? atomicAdd(&tails[q == 0 ? T_NEXT : T_SHADOW], tot) : 0u;
+    // Room in the two output queues.  Every resident block asks once per tile and waits for the answer at the next barrier,
+    // and one cache line takes 88 M atomic requests per second whatever they carry (scripts/microbench/atomic_rate.hip:
+    // u32, u64, two lanes of one instruction alike; sixteen lines take sixteen times that).  r04: at 70 M tiles per second the
+    // tail line was 79 % busy; r05: 80 M tiles per second, 91 %.  So a block of a large launch takes its room in CHUNKS of
+    // `chunk` entries per queue -- one request per ~chunk / 150 tiles, a 64-bit add when both queues run out at once -- and
+    // fills its chunks densely: a tile that does not fit uses up the old chunk and continues in the new one.  What a block has
+    // left when the kernel ends is filled with records that are no paths (sid / next-path word all ones; rays that start 1e30
+    // away and miss the root) and counted in T_HOLES_*: under 1 % of a queue.  chunk == 0 (small launches, statistics runs):
+    // the tile's exact room, as before, with ONE 64-bit add for both queues.
+    if (threadIdx.x == 0) {
+      static_assert(T_NEXT == 0 && T_SHADOW == 1, "the two tails share one 64-bit word");
+      uint32_t tot[2] = {0, 0};
       for (int w = 0; w < kShadeWaves; ++w) {
-        s_base[q][w] = base;
-        base += s_cnt[q][w];
+        s_base[0][w] = tot[0];
+        s_base[1][w] = tot[1];
+        tot[0] += s_cnt[0][w];
+        tot[1] += s_cnt[1][w];
+      }
+      uint32_t rem[2], want[2];
+      for (int q = 0; q < 2; ++q) {
+        rem[q] = s_room[q][1] - s_room[q][0];
+        want[q] = tot[q] > rem[q] ? (chunk ? chunk : tot[q]) : 0u;
+      }
+      unsigned long long got = 0;
+      if (want[0] | want[1]) got = atomicAdd((unsigned long long*)tails, ((unsigned long long)want[1] << 32) | want[0]);
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t b = q == 0 ? (uint32_t)got : (uint32_t)(got >> 32);
+        s_alloc[q][0] = s_room[q][0];
+        s_alloc[q][1] = want[q] ? rem[q] : 0xffffffffu;
+        s_alloc[q][2] = b;
+        if (want[q]) {
+          s_room[q][0] = b + (tot[q] - rem[q]);
+          s_room[q][1] = b + want[q];
+        } else {
+          s_room[q][0] += tot[q];
+        }
       }
     }
     __syncthreads();
-    const uint32_t j = s_base[0][wave] + (uint32_t)__popcll(am & lt_mask);
+    uint32_t j = s_base[0][wave] + (uint32_t)__popcll(am & lt_mask);
+    j = j < s_alloc[0][1] ? s_alloc[0][0] + j : s_alloc[0][2] + (j - s_alloc[0][1]);
     GSP_PROF_END(PR_COMPACT);
     GSP_PROF_BEGIN(PR_WRITE);
     // both outcomes of a bounce with a shadow ray, by the function k_finish and the host harness apply once the verdict is
@@ -496,7 +533,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       qst(&nxt.P3[j], mkq(clear.x, clear.y, clear.z, ub(p.flags)));  // (clear == sum without a shadow ray)
     }
     if (has_shadow) {
-      const uint32_t s = s_base[1][wave] + (uint32_t)__popcll(sm & lt_mask);
+      uint32_t s = s_base[1][wave] + (uint32_t)__popcll(sm & lt_mask);
+      s = s < s_alloc[1][1] ? s_alloc[1][0] + s : s_alloc[1][2] + (s - s_alloc[1][1]);
       const ShadowRay& r = out.shadow;
       if (!alive) result[my_sid] = mkq(clear.x, clear.y, clear.z, 0.0f);  // the path ended here: its sample, unless occluded
       qst(&sq.S0[s], mkq(r.o.x, r.o.y, r.o.z, r.tmax));
@@ -507,6 +545,20 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     GSP_PROF_END(PR_TILE);
   }
   __syncthreads();
+  // what is left of the block's last chunks: records that are no paths (see the reservation above)
+  {
+    const uint32_t a0 = s_room[0][0], e0 = s_room[0][1], a1 = s_room[1][0], e1 = s_room[1][1];
+    for (uint32_t k = a0 + threadIdx.x; k < e0; k += kShadeBlock) {
+      qst(&nxt.P0[k], mkq(1e30f, 1e30f, 1e30f, 1.0f));
+      qst(&nxt.P1[k], mkq(1.0f, 1.0f, 0.0f, ub(kFillerSid)));
+    }
+    for (uint32_t k = a1 + threadIdx.x; k < e1; k += kShadeBlock) {
+      qst(&sq.S0[k], mkq(1e30f, 1e30f, 1e30f, -1.0f));  // tmax < tmin: the ray is over before the root
+      qst(&sq.S1[k], mkq(1.0f, 1.0f, 1.0f, ub(0xffffffffu)));
+    }
+    if (threadIdx.x == 0 && e0 != a0) atomicAdd(&tails[T_HOLES_NEXT], e0 - a0);
+    if (threadIdx.x == 0 && e1 != a1) atomicAdd(&tails[T_HOLES_SHADOW], e1 - a1);
+  }
 #ifdef GSP_SHADE_PROFILE
   for (uint32_t k = threadIdx.x; k < (uint32_t)PR_COUNT * 4; k += kShadeBlock)
     if (gsp_prof_table()[k]) atomicAdd(&g_shade_profile[k], gsp_prof_table()[k]);
@@ -548,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   unsigned long long ext = 0, sh = 0, shaded = 0;
   uint32_t done_slot = 0xffffffffu;  // sample slot of the path this lane has run to its end (none: beyond the queue)
-  if (i < n) {
+  if (i < n && fb(q.P1[i].w) != kFillerSid) {  // (not a filler record of k_shade's chunked reservation)
     const q4 p0 = q.P0[i], p1 = q.P1[i], p2 = q.P2[i];
     PathState in;
     in.o = mk3(p0.x, p0.y, p0.z);
@@ -815,12 +867,14 @@ struct gsp_context {
     // starts iteration i + 1 the moment iteration i ends instead of waiting for the host to wake up, read 4 KB and launch.
     struct Iter {
       bool traced = false, timing = false, finish = false;
+      uint64_t slack = 0;     // filler records this iteration's k_shade may leave in each output queue (chunked reservation)
       uint64_t injected = 0;  // paths generated into the queue that the following iteration traces
       uint64_t front = 0;     // leading paths of this iteration's queue that were not traced (primary-hit memo)
     } it[2];
     uint32_t queued = 0;       // iterations in flight (0 .. kPipeDepth)
     uint32_t enq = 0, col = 0; // running index of the next iteration to queue / to collect (parity picks the tail set)
-    uint64_t n_in = 0;         // EXACT input size of iteration `col`
+    uint64_t n_in = 0;         // EXACT input size of iteration `col` (queue entries, filler records included)
+    uint64_t holes_in = 0;     // ... of which filler records of k_shade's chunked reservation (no paths, no rays)
     std::vector<uint32_t> h_live;      // host mirror of the slots' live counters
     std::vector<uint32_t> live_since;  // per slot: iteration whose read-back is the first to show the slot's current batch
   };
@@ -1648,7 +1702,22 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
     // ---- inject new batches while there is room: into the next queue, in front of this iteration's survivors ----
     // (the next iteration traces this one's survivors + what is injected now: aim that sum at the pool target with the
     // expected survivors, check the buffers against the upper bound)
-    const double expect = (exact ? (double)n : std::min((double)n, P.n_est)) * P.survive;
+    const double n_guess = exact ? (double)n : std::min((double)n, P.n_est);
+    const double expect = n_guess * P.survive;
+    // k_shade's room in the output queues, taken in chunks when every resident block shades many tiles (see the kernel):
+    // the chunk is sized for ~1 % of filler records, and the queues must hold them
+#ifndef GSP_ROOM_CHUNK
+#define GSP_ROOM_CHUNK 1024
+#endif
+    const uint64_t shade_blocks = (uint64_t)ctx->num_cus * GSP_SHADE_GRID_MULT * (GSP_SHADE_MINWAVES * 256 / kShadeBlock);
+    uint32_t room_chunk = 0;
+    if (!stats_mode && GSP_ROOM_CHUNK >= kShadeBlock) {
+      room_chunk = GSP_ROOM_CHUNK;
+      while (room_chunk >= (uint32_t)kShadeBlock && (double)room_chunk > 0.036 * n_guess / (double)shade_blocks) room_chunk >>= 1;
+      if (room_chunk < (uint32_t)kShadeBlock || n + shade_blocks * room_chunk > P.cap) room_chunk = 0;
+    }
+    const uint64_t slack = shade_blocks * room_chunk;
+    I.slack = slack;
     uint64_t inj = 0;
     while (P.remaining > 0 && expect + (double)inj < (double)P.pool_target) {
       const uint32_t kb = (uint32_t)std::min<uint64_t>(P.Kb, P.remaining);
@@ -1659,7 +1728,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
           break;
         }
       const uint64_t paths = (uint64_t)kb * npix;
-      if (slot == P.num_slots || n + inj + paths > P.cap) break;
+      if (slot == P.num_slots || n + inj + paths + slack > P.cap) break;
       hipLaunchKernelGGL(k_generate, dim3(ctx->grid_for(paths)), dim3(kBlock), 0, st, rcst, (uint32_t)npix, kb, P.next_ts,
                          ctx->subset ? ctx->pixel_ids.p : nullptr, Q[cur ^ 1], (uint32_t)inj, (uint32_t)(slot * batch_paths),
                          use_memo ? L.memo.p : (const q4*)nullptr, L.hits[cur ^ 1].p, L.index, ctx->num_lanes, gen_ver_bits);
@@ -1700,16 +1769,16 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       if (multi_version) {  // samples of several table versions in flight (gsp_update_tables without a drain)
         if (ctx->textured)
           hipLaunchKernelGGL((k_shade<true, true>), dim3(shade_grid), dim3(kShadeBlock), 0, st, vview, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
-                             L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+                             L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, room_chunk, ctx->dstats.p);
         else
           hipLaunchKernelGGL((k_shade<false, true>), dim3(shade_grid), dim3(kShadeBlock), 0, st, vview, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
-                             L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+                             L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, room_chunk, ctx->dstats.p);
       } else if (ctx->textured)
         hipLaunchKernelGGL((k_shade<true, false>), dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
-                           L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+                           L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, room_chunk, ctx->dstats.p);
       else
         hipLaunchKernelGGL((k_shade<false, false>), dim3(shade_grid), dim3(kShadeBlock), 0, st, view, rcst, (const uint32_t*)(tails_in + T_NEXT), Q[cur],
-                           L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, ctx->dstats.p);
+                           L.hits[cur].p, Q[cur ^ 1], SQ, L.result.p, tails_out, live, (uint32_t)batch_paths, room_chunk, ctx->dstats.p);
       CTX_TRY(ctx, hipGetLastError());
       if (timing) CTX_TRY(ctx, hipEventRecord(ev[2], st));
       {
@@ -1738,7 +1807,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   ++L.enq;
   P.cur ^= 1;
   P.front = use_memo && !I.finish ? I.injected : 0;
-  P.n = (I.finish ? 0 : n) + I.injected;  // survivors <= n: an upper bound of the next iteration's input until the read-back says more
+  P.n = (I.finish ? 0 : n + I.slack) + I.injected;  // survivors <= n: an upper bound of the next iteration's input until the read-back says more
   P.n_est = (I.finish ? 0.0 : (exact ? (double)n : std::min((double)n, P.n_est)) * P.survive) + (double)I.injected;
   return GSP_OK;
 }
@@ -1760,9 +1829,9 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
       ctx->stats.extension_rays += (uint64_t)tails[T_FIN_EXT] | ((uint64_t)tails[T_FIN_EXT + 1] << 32);
       ctx->stats.shadow_rays += (uint64_t)tails[T_FIN_SH] | ((uint64_t)tails[T_FIN_SH + 1] << 32);
     } else if (I.traced) {
-      ctx->stats.extension_rays += n_traced;  // path segments; I.front of them were answered from the memo
+      ctx->stats.extension_rays += n_traced - L.holes_in;  // path segments; I.front of them were answered from the memo
       ctx->stats.memoised_rays += I.front;
-      ctx->stats.shadow_rays += tails[T_SHADOW];
+      ctx->stats.shadow_rays += tails[T_SHADOW] - tails[T_HOLES_SHADOW];
     }
     const uint32_t bounce = P.iteration++;
     if (I.timing) {
@@ -1780,17 +1849,18 @@ static int lane_collect(gsp_context* ctx, gsp_context::Lane& L) {
                 L.index, bounce, (unsigned long long)n_traced, tails[T_SHADOW], (unsigned long long)I.injected, P.inflight.size(), e_ms, s_ms, ms);
     }
     // the input size of the next iteration, exactly: injected paths + survivors
-    if (I.traced && n_traced > 0) {
-      const double r = ((double)tails[T_NEXT] - (double)I.injected) / (double)n_traced;
+    if (I.traced && n_traced > L.holes_in) {
+      const double r = ((double)tails[T_NEXT] - (double)tails[T_HOLES_NEXT] - (double)I.injected) / (double)(n_traced - L.holes_in);
       P.survive = 0.5 * P.survive + 0.5 * std::min(1.0, std::max(0.0, r));
     }
     L.n_in = tails[T_NEXT];
+    L.holes_in = I.traced ? tails[T_HOLES_NEXT] : 0;
     for (const gsp_context::Batch& b : P.inflight)
       if (L.live_since[b.slot] <= L.col) L.h_live[b.slot] = rb[C_LIVE + b.slot];
     ++L.col;
     --L.queued;
     // what the next iteration to be QUEUED will trace: exact if nothing is in flight, else bounded through the one that is
-    P.n = L.queued ? L.n_in + L.it[L.col & 1u].injected : L.n_in;
+    P.n = L.queued ? L.n_in + L.it[L.col & 1u].slack + L.it[L.col & 1u].injected : L.n_in;
     P.n_est = L.queued ? (double)L.n_in * P.survive + (double)L.it[L.col & 1u].injected : (double)L.n_in;
   }
   while (!P.inflight.empty() && L.h_live[P.inflight.front().slot] == 0) {
