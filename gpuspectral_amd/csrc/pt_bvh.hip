@@ -887,9 +887,11 @@ inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kB
 }  // namespace
 
 void free_bvh(DeviceBvh& b) {
-  (void)hipFree(b.nodes);
-  (void)hipFree(b.tri_isect);
-  (void)hipFree(b.tri_shade);
+  if (!b.arrays_external) {
+    (void)hipFree(b.nodes);
+    (void)hipFree(b.tri_isect);
+    (void)hipFree(b.tri_shade);
+  }
   (void)hipFree(b.slot_to_global);
   (void)hipFree(b.rf_leaf_lo);
   (void)hipFree(b.rf_leaf_hi);

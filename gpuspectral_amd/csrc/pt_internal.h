@@ -26,6 +26,7 @@ struct DeviceBvh {
   q4* tri_isect = nullptr;  // 3 quads per slot
   q4* tri_shade = nullptr;  // 4 quads per slot
   uint32_t* slot_to_global = nullptr;
+  bool arrays_external = false;  // nodes / tri_isect / tri_shade are a slot of the context's geometry ring (pt_render.hip): not free_bvh's
   int32_t root = 0;
   uint32_t num_tris = 0;   // real triangles (0 allowed)
   uint32_t first_slot = 0; // triangle slots in use: [first_slot, first_slot + num_tris); the leading ones are all-zero triangles

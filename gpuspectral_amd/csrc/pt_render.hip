@@ -158,6 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
 // ---- extend / connect / test hook: ray sources and result sinks of k_trace -----------------
 struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
   static constexpr float kTmin = 0.0f, kTmax = 1e10f;
+  static constexpr bool kVersioned = false;
   PathQueue q;
   q4* hits;
   __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax, uint32_t& pay) const {
@@ -181,6 +182,7 @@ struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
 // traced rays (bench.py's Mrays/s leaves them out).
 struct MemoIO {
   static constexpr float kTmin = 0.0f, kTmax = 1e10f;
+  static constexpr bool kVersioned = false;
   RenderConsts rc;
   const uint32_t* pixel_ids;
   uint32_t lane, lanes;
@@ -201,6 +203,7 @@ struct MemoIO {
 
 struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any hit
   static constexpr float kTmin = 0.01f, kTmax = -1.0f;
+  static constexpr bool kVersioned = false;
   ShadowQueue sq;
   q4* next_P2;
   q4* next_P3;
@@ -233,8 +236,42 @@ struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any h
   }
 };
 
+// The same two sources while samples of several GEOMETRY versions are in flight (gsp_update_instances without a drain,
+// pt_stages.h): a path's stamp sits in its flags word, a shadow ray's in the top three bits of the word that names the
+// continuing path (queues hold fewer than 2^29 entries then: lane_enqueue).  `nodes` / `tris` of the launch are slot 0 of the ring.
+struct GeoRing {
+  uint32_t geo;      // pt_stages.h pack_geo
+  uint32_t top_off;  // node-record byte offset of the newest version
+  __device__ __forceinline__ void offsets(uint32_t stamp, uint32_t& node_off, uint32_t& tri_base) const {
+    tri_base = geo_slot_offset(geo, stamp);
+    node_off = tri_base * kNodeBytes;
+  }
+};
+constexpr uint32_t kNextBits = 29, kNoNext = (1u << kNextBits) - 1u;  // <VER> shadow records: index of the continuing path | stamp << 29
+struct ExtendVerIO : ExtendIO {
+  static constexpr bool kVersioned = true;
+  GeoRing g;
+  __device__ __forceinline__ uint32_t top_offset() const { return g.top_off; }
+  __device__ __forceinline__ void geometry(uint32_t i, uint32_t, uint32_t& node_off, uint32_t& tri_base) const {
+    g.offsets(geo_stamp(((const uint32_t*)&q.P3[i])[3]), node_off, tri_base);
+  }
+};
+struct ConnectVerIO : ConnectIO {
+  static constexpr bool kVersioned = true;
+  GeoRing g;
+  __device__ __forceinline__ uint32_t top_offset() const { return g.top_off; }
+  __device__ __forceinline__ void geometry(uint32_t, uint32_t pay, uint32_t& node_off, uint32_t& tri_base) const {
+    g.offsets(pay >> kNextBits, node_off, tri_base);
+  }
+  __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux, uint32_t pay) const {
+    const uint32_t nx = pay & kNoNext;
+    ConnectIO::store(i, h, aux, nx == kNoNext ? 0xffffffffu : nx);
+  }
+};
+
 struct TestIO {  // gsp_trace
   static constexpr float kTmin = -1.0f, kTmax = -1.0f;
+  static constexpr bool kVersioned = false;
   const float* rays;
   q4* hits;
   const uint32_t* slot_to_global;
@@ -538,7 +575,8 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       const ShadowRay& r = out.shadow;
       if (!alive) result[my_sid] = mkq(clear.x, clear.y, clear.z, 0.0f);  // the path ended here: its sample, unless occluded
       qst(&sq.S0[s], mkq(r.o.x, r.o.y, r.o.z, r.tmax));
-      qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(alive ? j : 0xffffffffu)));
+      if (VER) qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub((alive ? j : kNoNext) | (geo_stamp(fb(sum.w)) << kNextBits))));  // (sum.w: the flags the vertex came with)
+      else qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(alive ? j : 0xffffffffu)));
       qst(&sq.S3[s], mkq(occ.x, occ.y, occ.z, ub(alive ? out.next.flags : r.sid)));
     }
     GSP_PROF_END(PR_WRITE);
@@ -613,12 +651,16 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
     in.flags = fb(p3.w);
     const uint32_t sid = in.sid;
     q4 res = mkq(p3.x, p3.y, p3.z, 0.0f);  // the sample's sum so far
+    // VER: this path's version of the geometry (constant along the path)
+    const uint32_t goff = VER ? geo_slot_offset(S.geo, geo_stamp(in.flags)) : 0u;
+    const q4* nodes_v = VER ? (const q4*)((const char*)S.nodes + (size_t)goff * kNodeBytes) : S.nodes;
+    const q4* isect_v = VER ? S.tri_isect + 3ull * goff : S.tri_isect;
     for (;;) {
       HitRec h;
       uint32_t aux;
       ++ext;
       stk.top = 0;
-      if (!trace_ray<false>(S.nodes, S.tri_isect, in.o, in.d, 0.0f, 1e10f, h, aux, stk, tab)) {  // miss.rmiss:15-18
+      if (!trace_ray<false>(nodes_v, isect_v, in.o, in.d, 0.0f, 1e10f, h, aux, stk, tab)) {  // miss.rmiss:15-18
         if (TEX && S.tex.env_texels != nullptr) add_emitted(rc.clamp, miss_emitted(S, in), res);
         break;
       }
@@ -632,7 +674,7 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
         uint32_t aux2;
         ++sh;
         stk.top = 0;
-        const bool occluded = trace_ray<true>(S.nodes, S.tri_isect, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2, stk, tab);
+        const bool occluded = trace_ray<true>(nodes_v, isect_v, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2, stk, tab);
         bool nee_done;
         connect_vertex(rc.clamp, out.shadow, occluded, res, nee_done);
         if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;  // rayhit.rchit:785-787
@@ -785,6 +827,16 @@ struct gsp_context {
   uint32_t tab_rot = 0;  // version that slot 0 / flags field 0 stand for
   uint32_t tab_slot(uint32_t v) const { return (v - tab_rot) % kTableVersions; }
   uint32_t num_lights = 0;
+  // r05: the GEOMETRY ring (pt_stages.h): kGeoVersions slots of geo_stride triangle slots each -- node records, intersection
+  // triangles, shading packets -- so that gsp_update_instances need not wait for the samples in flight either: the refit goes
+  // into the next slot, new samples are stamped with it, the old ones finish in theirs.  Made by the first gsp_update_instances
+  // of a tree (which drains, as every one did until r04); `bvh.nodes / tri_isect / tri_shade` then point at the NEWEST slot.
+  DevBuf<q4> ring_nodes, ring_isect, ring_shade;
+  uint32_t geo_stride = 0;  // triangle slots per version; 0 = no ring (the tree owns its arrays)
+  uint32_t geo_ver = 0;     // version the next sample is generated under (monotonic); its slot: geo_ver % kGeoVersions
+  uint32_t geo_base = 0;    // slot that stamp 0 stands for
+  bool geo_ring_failed = false;  // no memory for it: edits drain, as before
+  uint32_t geo_phys(uint32_t v) const { return v % kGeoVersions; }
   gsp_camera camera{};
   double bvh_build_ms = 0.0;
   // what gsp_upload_scene leaves resident for the per-frame edits (gsp_update_instances re-bakes from it, as the reference
@@ -826,7 +878,8 @@ struct gsp_context {
   // Streaming pipeline state: survives across gsp_render calls, drained by gsp_sync & friends.
   struct Batch {
     uint32_t t0, kb, slot;
-    uint32_t ver;  // table version its samples were generated under
+    uint32_t ver;   // table version its samples were generated under
+    uint32_t gver;  // ... and geometry version
   };
   struct Pipeline {
     bool active = false;
@@ -895,13 +948,27 @@ struct gsp_context {
       if (lanes[l].pipe.active && !lanes[l].pipe.inflight.empty()) o = std::min(o, lanes[l].pipe.inflight.front().ver);
     return o;
   }
-  // versioned == false: the tables of the current version (all samples in flight belong to it); true: slot 0 of the ring +
-  // the stride, for the <VER> instantiations
+  uint32_t oldest_live_geo() const {
+    uint32_t o = geo_ver;
+    for (uint32_t l = 0; l < num_lanes; ++l)
+      if (lanes[l].pipe.active && !lanes[l].pipe.inflight.empty()) o = std::min(o, lanes[l].pipe.inflight.front().gver);
+    return o;
+  }
+  // the <VER> kernels' shadow records keep the geometry stamp in the top bits of a queue index (kNextBits)
+  bool caps_allow_versions() const {
+    for (uint32_t l = 0; l < num_lanes; ++l)
+      if (lanes[l].pipe.active && lanes[l].pipe.cap >= (uint64_t)kNoNext) return false;
+    return true;
+  }
+  // versioned == false: the tables and the geometry of the current version (all samples in flight belong to it); true: slot 0
+  // of the rings + the strides, for the <VER> instantiations
   SceneView view(bool versioned = false) const {
     SceneView v;
-    v.nodes = bvh.nodes;
-    v.tri_isect = bvh.tri_isect;
-    v.tri_shade = bvh.tri_shade;
+    const bool ring = versioned && geo_stride != 0;
+    v.nodes = ring ? ring_nodes.p : bvh.nodes;
+    v.tri_isect = ring ? ring_isect.p : bvh.tri_isect;
+    v.tri_shade = ring ? ring_shade.p : bvh.tri_shade;
+    v.geo = ring ? pack_geo(geo_base, geo_stride) : 0u;
     const uint8_t* tb = tables.p;  // slot 0: the one live version (versioned == false), or the base the <VER> kernels add their offset to
     v.ver_stride = versioned ? (uint32_t)tab_slot_bytes : 0u;
     v.bsdf.diffuse = (const gsp_diffuse_bsdf*)(tb + table_off[0]);
@@ -1243,6 +1310,74 @@ static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage&
   return GSP_OK;
 }
 
+// ---- geometry ring (gsp_context::ring_*) ----------------------------------------------------------------------------------
+// Both need an idle pipeline: nothing queued may name the arrays that go away.
+static void drop_geo_ring(gsp_context* ctx) {
+  if (ctx->bvh.arrays_external) {  // the tree's arrays were a slot of the ring
+    ctx->bvh.nodes = ctx->bvh.tri_isect = ctx->bvh.tri_shade = nullptr;
+    ctx->bvh.arrays_external = false;
+  }
+  for (DevBuf<q4>* b : {&ctx->ring_nodes, &ctx->ring_isect, &ctx->ring_shade}) {
+    if (b->p) ctx->bytes -= b->count * sizeof(q4);
+    b->release();
+  }
+  ctx->geo_stride = 0;
+  ctx->geo_ver = 0;
+  ctx->geo_base = 0;
+}
+// Moves the tree's three arrays into slot geo_ver % kGeoVersions of a new ring.  GSP_OK also when there is no ring to be had
+// (tree too large for 32-bit node offsets, no memory): gsp_update_instances then drains every time, as before.
+static int make_geo_ring(gsp_context* ctx) {
+  DeviceBvh& b = ctx->bvh;
+  if (ctx->geo_stride != 0 || ctx->geo_ring_failed || !b.nodes || b.num_tris == 0 || b.arrays_external) return GSP_OK;
+  const uint64_t slots = (uint64_t)b.num_tris + b.first_slot + (kWide - 1);
+  const uint64_t stride = std::max<uint64_t>(slots, kNodeAllocMin / kNodeBytes);
+  if (stride > kGeoMaxStride || b.num_nodes > stride) return GSP_OK;
+  hipStream_t st = ctx->stream;
+  const size_t total = (size_t)kGeoVersions * stride;
+  if (ctx->ring_nodes.ensure(total * kNodeQuads, &ctx->bytes) != hipSuccess || ctx->ring_isect.ensure(total * 3, &ctx->bytes) != hipSuccess ||
+      ctx->ring_shade.ensure(total * 4, &ctx->bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->geo_stride = 1;  // (so that drop_geo_ring releases what was allocated)
+    drop_geo_ring(ctx);
+    ctx->geo_ring_failed = true;
+    return GSP_OK;
+  }
+  // all-zero everywhere: the leading / trailing triangle slots of every version (build_bvh), node records nothing refers to
+  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_nodes.p, 0, total * kNodeQuads * sizeof(q4), st));
+  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_isect.p, 0, total * 3 * sizeof(q4), st));
+  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_shade.p, 0, total * 4 * sizeof(q4), st));
+  ctx->geo_ver = 0;
+  ctx->geo_base = 0;
+  q4* nn = ctx->ring_nodes.p;  // (slot 0)
+  q4* ni = ctx->ring_isect.p;
+  q4* ns = ctx->ring_shade.p;
+  const size_t b_nodes = (size_t)b.num_nodes * kNodeBytes, b_is = slots * 3 * sizeof(q4), b_sh = slots * 4 * sizeof(q4);
+  CTX_TRY(ctx, hipMemcpyAsync(nn, b.nodes, b_nodes, hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemcpyAsync(ni, b.tri_isect, b_is, hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemcpyAsync(ns, b.tri_shade, b_sh, hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipStreamSynchronize(st));
+  (void)hipFree(b.nodes);
+  (void)hipFree(b.tri_isect);
+  (void)hipFree(b.tri_shade);
+  const size_t freed = std::max<size_t>(b_nodes, kNodeAllocMin) + b_is + b_sh;
+  b.bytes -= std::min(b.bytes, freed);
+  ctx->bytes -= std::min(ctx->bytes, freed);
+  b.nodes = nn;
+  b.tri_isect = ni;
+  b.tri_shade = ns;
+  b.arrays_external = true;
+  ctx->geo_stride = (uint32_t)stride;
+  return GSP_OK;
+}
+// the tree's arrays := slot `v % kGeoVersions`
+static void point_bvh_at(gsp_context* ctx, uint32_t v) {
+  const size_t off = (size_t)ctx->geo_phys(v) * ctx->geo_stride;
+  ctx->bvh.nodes = ctx->ring_nodes.p + off * kNodeQuads;
+  ctx->bvh.tri_isect = ctx->ring_isect.p + off * 3;
+  ctx->bvh.tri_shade = ctx->ring_shade.p + off * 4;
+}
+
 // instance table (ctx->h_inst) -> device, transformInvT per instance, world-space bake + BVH build from the RESIDENT vertex
 // arrays, per-slot uv gather of a textured scene, traversal spill region
 // refit == true (gsp_update_instances): keep the tree's topology if its boxes stay within gsp_ctx_options.refit_growth of what
@@ -1290,6 +1425,14 @@ static int bake_and_build(gsp_context* ctx, bool refit = false, bool* refitted =
       return GSP_OK;
     }
   }
+  // a new tree: its arrays are its own again, and whatever is in flight ends on the old ones first (the committed version's:
+  // a refit into the next slot of the ring that grew too much is abandoned here)
+  if (ctx->geo_stride) point_bvh_at(ctx, ctx->geo_ver);
+  if (ctx->pipe_active) {
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
+  drop_geo_ring(ctx);
   ctx->bytes -= ctx->bvh.bytes;
   if (ctx->node_hist.p) ctx->bytes -= (ctx->node_hist.count + ctx->tri_hist.count) * sizeof(uint32_t);
   ctx->node_hist.release();
@@ -1322,6 +1465,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   }
   ctx->have_scene = false;
   for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
+  ctx->geo_ring_failed = false;
   // ---- validate ----
   if ((sc->num_instances && !sc->instances) || (sc->num_vertices && (!sc->positions || !sc->normals)) ||
       (sc->num_lights && !sc->lights)) {
@@ -1453,15 +1597,38 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   rc = check_instances(ctx, instances, num_instances, ctx->num_bsdfs, ctx->num_vertices, nullptr);
   if (rc != GSP_OK) return rc;
   if (num_instances == 0 || std::memcmp(ctx->h_inst.data(), instances, num_instances * sizeof(gsp_instance)) == 0) return GSP_OK;
-  rc = pipeline_drain(ctx);
-  if (rc != GSP_OK) return rc;
+  // r05: NO DRAIN when the tree has its geometry ring and a slot of it is free: the refit -- re-bake of every packet, node boxes
+  // bottom-up in the existing topology -- goes into the NEXT slot, on the context's stream, while the lanes' streams finish the
+  // samples in flight in the slots they were generated under (a path carries its slot in its flags word, pt_stages.h); the next
+  // gsp_render stamps its samples with the new one.  Otherwise -- first edit of this tree (the ring is made then), kGeoVersions
+  // edits within the life of one sample, a tree that degrades and is rebuilt -- the queued samples finish first, as until r04.
+  const bool in_ring = ctx->pipe_active && ctx->geo_stride != 0 && ctx->opt.refit_growth > 1.0 && ctx->caps_allow_versions() &&
+                       ctx->geo_ver + 1 - ctx->oldest_live_geo() < kGeoVersions;
+  if (!in_ring) {
+    rc = pipeline_drain(ctx);
+    if (rc != GSP_OK) return rc;
+    if (ctx->opt.refit_growth > 1.0) {
+      rc = make_geo_ring(ctx);
+      if (rc != GSP_OK) return rc;
+    }
+  }
   auto t0 = std::chrono::steady_clock::now();
   ctx->have_scene = false;  // (a failed rebuild leaves no half-built tree in use)
   for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
   ctx->h_inst.assign(instances, instances + num_instances);
   bool refitted = false;
+  if (in_ring) {
+    // topology (child links, triangle ranges) of the current version -> next slot; refit_bvh rewrites every box and packet there
+    const q4* from = ctx->bvh.nodes;
+    point_bvh_at(ctx, ctx->geo_ver + 1);
+    CTX_TRY(ctx, hipMemcpyAsync(ctx->bvh.nodes, from, (size_t)ctx->bvh.num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   rc = bake_and_build(ctx, true, &refitted);
-  if (rc != GSP_OK) return rc;
+  if (rc != GSP_OK) {
+    if (ctx->geo_stride) point_bvh_at(ctx, ctx->geo_ver);
+    return rc;
+  }
+  if (in_ring && refitted) ++ctx->geo_ver;  // (not refitted: the tree was rebuilt behind a drain and owns its arrays again)
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->have_scene = true;
   ++ctx->stats.scene_updates;
@@ -1496,7 +1663,7 @@ int gsp_update_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
   // the queued samples finish first, as until r04.
   bool same_layout = ctx->pipe_active && sc->num_lights == ctx->num_lights && img.total == ctx->tables_bytes && ctx->tables.p != nullptr;
   for (int k = 0; k < GSP_BSDF_TYPE_COUNT && same_layout; ++k) same_layout = sc->num_bsdfs[k] == ctx->num_bsdfs[k];
-  const bool in_place = same_layout && ctx->tab_ver + 1 - ctx->oldest_live_version() < kTableVersions;
+  const bool in_place = same_layout && ctx->caps_allow_versions() && ctx->tab_ver + 1 - ctx->oldest_live_version() < kTableVersions;
   if (!in_place) {
     rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
@@ -1649,7 +1816,10 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   I = gsp_context::Lane::Iter{};
   // do the samples in flight belong to more than one version of the BSDF / light tables?  (only after a gsp_update_tables
   // that did not drain: then k_shade / k_finish read every vertex's tables through the version its path carries)
-  const bool multi_version = ctx->oldest_live_version() != ctx->tab_ver;
+  // ... or to more than one version of the geometry (gsp_update_instances without a drain: then the traversal kernels too take
+  // every ray's geometry from the slot its path names)
+  const bool multi_version = ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver;
+  if (!multi_version) ctx->geo_base = ctx->geo_phys(ctx->geo_ver);  // stamp 0 = the one live version (no copy: the kernels get its slot's pointers)
   if (!multi_version && ctx->tab_rot != ctx->tab_ver) {
     // the edits are over and the samples of the older versions have ended: the one live version moves into slot 0 and the
     // version field of the paths goes back to 0 (the <VER = false> kernels write 0).  Nothing reads slot 0 any more -- it held a
@@ -1660,7 +1830,9 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
     ctx->tab_rot = ctx->tab_ver;
   }
   const SceneView vview = multi_version ? ctx->view(true) : view;
-  const uint32_t gen_ver_bits = ctx->tab_slot(ctx->tab_ver) << kVerShift;  // (0 unless an edit is in flight)
+  const uint32_t gen_ver_bits = (ctx->tab_slot(ctx->tab_ver) << kVerShift) |  // (0 unless an edit is in flight)
+                                (((ctx->geo_phys(ctx->geo_ver) + kGeoVersions - ctx->geo_base) % kGeoVersions) << kGeoShift);
+  const GeoRing gring{vview.geo, (uint32_t)((size_t)ctx->geo_phys(ctx->geo_ver) * ctx->geo_stride * kNodeBytes)};
 
   CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
   const bool use_memo = ctx->primary_memo && !stats_mode;
@@ -1737,7 +1909,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       L.h_live[slot] = (uint32_t)paths;
       L.live_since[slot] = L.enq;  // read-backs of earlier iterations still show the slot's previous state
       P.slot_used[slot] = 1;
-      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot, ctx->tab_ver});
+      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot, ctx->tab_ver, ctx->geo_ver});
       inj += paths;
       P.next_ts += kb;
       P.remaining -= kb;
@@ -1752,7 +1924,12 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       {
         const ExtendIO io{Q[cur], L.hits[cur].p};
         uint32_t* work = L.counters.p + C_WORK_EXT;
-        if (stats_mode)
+        if (multi_version) {
+          const ExtendVerIO vio{io, gring};
+          hipLaunchKernelGGL((k_trace<false, false, ExtendVerIO>), dim3(grid), dim3(kTraceBlock), 0, st, vview.nodes, vview.tri_isect,
+                             (const uint32_t*)(tails_in + T_NEXT), 0u, (uint32_t)front, chunk, vio, work, L.spill.p, ctx->spill_stride,
+                             so_ext);
+        } else if (stats_mode)
           hipLaunchKernelGGL((k_trace<false, true, ExtendIO>), dim3(grid), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
                              (const uint32_t*)(tails_in + T_NEXT), 0u, (uint32_t)front, chunk, io, work, L.spill.p, ctx->spill_stride,
                              so_ext);
@@ -1785,7 +1962,12 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
         const ConnectIO io{SQ, Q[cur ^ 1].P2, Q[cur ^ 1].P3, L.result.p, rcst.clamp};
         uint32_t* work = L.counters.p + C_WORK_SH;
         const uint32_t grid_any = ctx->trace_grid(std::max<uint64_t>(n, 1), chunk, true);
-        if (stats_mode)
+        if (multi_version) {
+          const ConnectVerIO vio{io, gring};
+          hipLaunchKernelGGL((k_trace<true, false, ConnectVerIO>), dim3(grid_any), dim3(kTraceBlock), 0, st, vview.nodes, vview.tri_isect,
+                             (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, vio, work, L.spill.p,
+                             ctx->spill_stride, so_sh);
+        } else if (stats_mode)
           hipLaunchKernelGGL((k_trace<true, true, ConnectIO>), dim3(grid_any), dim3(kTraceBlock), 0, st, view.nodes, view.tri_isect,
                              (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, io, work, L.spill.p,
                              ctx->spill_stride, so_sh);
@@ -2037,6 +2219,12 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       P.active = true;
     }
     ctx->pipe_active = true;
+  }
+  if (rp->collect_traversal_stats != 0 && ctx->pipe_active &&
+      (ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver)) {
+    // the statistics instantiations of k_trace know one version of the scene: samples of older ones finish first
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
   }
   ctx->pipe_params = *rp;  // (stats / timing flags may change from call to call)
   if (rp->collect_traversal_stats >= 2) {

@@ -45,13 +45,14 @@ struct SceneView {
   uint32_t num_lights;
   float inv_num_lights = 0.0f;       // 1.0f / (float)num_lights (rayhit.rchit:151), formed once on the host
   int32_t root;
+  uint32_t geo = 0;                 // <VER = true>: geometry ring (below): phys slot that stamp 0 stands for << 29 | triangle slots per version
   const uint8_t* tables = nullptr;  // the BSDF tables + lights back to back (device: one allocation), for LDS staging
   uint32_t tables_bytes = 0;
   uint32_t ver_stride = 0;          // <VER = true> instantiations: bytes between two versions of the tables (slot 0 is what the pointers name)
   TextureView tex;                  // dormant-feature extension; read only by the <TEX = true> instantiations
 };
 
-// path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9 | table version << 10 [10,15]
+// path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9 | table version << 10 [10,15] | geometry version << 16 [16,18]
 GSP_HD uint32_t pack_flags(uint32_t depth, uint32_t wasDelta, uint32_t countEmitted) {
   return depth | (wasDelta << 8) | (countEmitted << 9);
 }
@@ -61,6 +62,21 @@ GSP_HD uint32_t pack_flags(uint32_t depth, uint32_t wasDelta, uint32_t countEmit
 // While every sample in flight belongs to ONE version -- always, for a scene that is not being edited -- that version sits in
 // slot 0, the field is 0 and the <VER = false> kernels neither read nor write it: their code is what it was before versions existed.
 constexpr uint32_t kVerShift = 10, kTableVersions = 64, kVerMask = (kTableVersions - 1u) << kVerShift;
+// ... and the version of the GEOMETRY (gsp_update_instances without a drain: bits [16,18]): the node records, intersection
+// triangles and shading packets of up to kGeoVersions edits live in a ring -- version slot p at nodes + p * stride * 64 B (a tree
+// of n triangles has fewer than n nodes), tri_isect + 3 * p * stride, tri_shade + 4 * p * stride quads, stride = triangle slots per
+// version -- and a path's stamp s names slot (s + base) % kGeoVersions, base = the slot of the one live version the last time only
+// one was (then the field is 0, as for the tables).  Both travel in SceneView::geo / GeoRing.
+constexpr uint32_t kGeoShift = 16, kGeoVersions = 8, kGeoMask = (kGeoVersions - 1u) << kGeoShift;
+constexpr uint32_t kStampMask = kVerMask | kGeoMask;
+constexpr uint32_t kGeoStrideBits = 29, kGeoStrideMask = (1u << kGeoStrideBits) - 1u;
+constexpr uint32_t kGeoMaxStride = (1u << 23) - 1u;  // 8 versions x stride x 64 B of node records stay below 4 GB (32-bit node offsets)
+GSP_HD uint32_t pack_geo(uint32_t base, uint32_t stride) { return (base << kGeoStrideBits) | stride; }
+// slot offset (in triangle slots) of the geometry version a stamp names
+GSP_HD uint32_t geo_slot_offset(uint32_t geo, uint32_t stamp) {
+  return ((stamp + (geo >> kGeoStrideBits)) & (kGeoVersions - 1u)) * (geo & kGeoStrideMask);
+}
+GSP_HD uint32_t geo_stamp(uint32_t flags) { return (flags & kGeoMask) >> kGeoShift; }
 
 struct PathState {
   f3 o, d;
@@ -141,7 +157,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   const BsdfTables& T = VER ? Tv : S.bsdf;
   const gsp_triangle_light* lights = VER ? lights_v : S.lights;
   GSP_PROF_BEGIN(PR_PACKET);
-  const q4* sp = S.tri_shade + 4ll * hit.slot;
+  const q4* sp = S.tri_shade + 4ll * ((long long)hit.slot + (VER ? (long long)geo_slot_offset(S.geo, geo_stamp(in.flags)) : 0ll));
   const q4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
   const uint32_t material = f2u(s0.w);                                    // :672 (instance record, baked per triangle)
   const uint32_t bsdf = material & 0x7fffffffu;
@@ -240,7 +256,7 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   }
   if (depth > rc.max_depth) alive = false;                                // rgen:73-75
   if (done) alive = false;                                                // rgen:77-78
-  nx.flags = pack_flags(depth + 1u, bs.delta ? 1u : 0u, 0u) | (VER ? (in.flags & kVerMask) : 0u);  // rgen:80, rchit:792,796; VER: the version rides along
+  nx.flags = pack_flags(depth + 1u, bs.delta ? 1u : 0u, 0u) | (VER ? (in.flags & kStampMask) : 0u);  // rgen:80, rchit:792,796; VER: the versions ride along
 
   out.alive = alive;
   out.next = nx;

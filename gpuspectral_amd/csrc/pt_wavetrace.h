@@ -178,6 +178,12 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 //                                                  record that load() hands to store() through the traversal
 //   static constexpr float kTmin, kTmax: >= 0 = every ray of this source has that bound (load() returns the same
 //                                                  value): the kernel keeps it out of the registers
+//   static constexpr bool kVersioned: the rays of this source belong to several versions of the geometry (pt_stages.h, geometry
+//                                                  ring; gsp_update_instances without a drain).  Then also
+//   __device__ void geometry(uint32_t i, uint32_t pay, uint32_t& node_off, uint32_t& tri_base) const;  // byte offset of the ray's
+//                                                  node records from `nodes`, slot offset of its triangles
+//   __device__ uint32_t top_offset() const;        // node_off of the version whose top of the tree the blocks stage into LDS
+//                                                  kVersioned == false: the kernel is what it was before versions existed
 // Rays [first, n) of the queue are traced (first > 0: the leading entries carry memoised results, pt_render.hip).
 template <bool ANY, bool STATS, class IO>
 __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_WAVES) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
@@ -201,7 +207,12 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   // nothing and makes the any-hit kernel 2.5 % slower (one more address op per LDS node step): the replays are hidden behind
   // the other six waves.  profiles/r04_ab_lds_layout.txt
   __shared__ q4 lds_top[kTopNodes > 0 ? kTopNodes * kNodeQuads : 1];
-  for (uint32_t i = threadIdx.x; i < kTopNodes * kNodeQuads; i += kTraceBlock) lds_top[i] = nodes[i];
+  uint32_t top_off = 0;  // (versioned sources: the newest version's top of the tree is the one in LDS)
+  if constexpr (IO::kVersioned) top_off = io.top_offset();
+  {
+    const q4* top = IO::kVersioned ? (const q4*)((const char*)nodes + top_off) : nodes;
+    for (uint32_t i = threadIdx.x; i < kTopNodes * kNodeQuads; i += kTraceBlock) lds_top[i] = top[i];
+  }
   __syncthreads();
   const LdsStepTable tab{(const __attribute__((address_space(3))) char*)lds_table};
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   uint32_t gb = 0, gs = no_group<ANY>(), tb = 0, tm = 0, tb2 = 0, tm2 = 0;
   uint32_t ri = 0xffffffffu, best_id = 0xffffffffu;  // best_id: p0.w of the closest hit so far (id << 3 | BSDF type)
   uint32_t pay = 0;                                   // (sources that do not use it leave no register behind)
+  uint32_t node_off = 0, tri_base = 0;                // versioned sources: where this ray's version of the geometry starts
   RayBox rb = make_raybox(mk3(0, 0, 0), mk3(1, 1, 1));
   RayShearRot rs;
   rs.m0 = rs.m1 = rs.ms = 0u;
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           f3 d;
           f3 o;
           io.load(ri, o, d, tmin_v, tmax_v, pay);
+          if constexpr (IO::kVersioned) io.geometry(ri, pay, node_off, tri_base);
           rb = make_raybox(o, d);
           rs = make_shear_rot(d);
           rs.Sz = permute_axes(rs, rb.inv).z;  // = 1 / d[kz], the same correctly rounded quotient make_shear_rot computes
@@ -364,10 +377,12 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 #endif
         if (on) {
           // the nearest child of the current group (32-bit offset + uniform base, no 64-bit address arithmetic)
-          const uint32_t noff = group_next<ANY>(gb, gs, rb, tab);
+          const uint32_t noff_v = group_next<ANY>(gb, gs, rb, tab);
+          const uint32_t noff = IO::kVersioned ? noff_v + node_off : noff_v;        // offset from `nodes`
+          const uint32_t loff = IO::kVersioned ? noff - top_off : noff;             // offset inside the LDS copy, if below its size
           q4 nq[kNodeQuads];
-          if (kTopNodes > 0 && noff < kTopNodes * kNodeBytes) {
-            const lds_v4f* nd = (const lds_v4f*)((const __attribute__((address_space(3))) char*)lds_top + noff);
+          if (kTopNodes > 0 && loff < kTopNodes * kNodeBytes) {
+            const lds_v4f* nd = (const lds_v4f*)((const __attribute__((address_space(3))) char*)lds_top + loff);
 #pragma unroll
             for (uint32_t k = 0; k < kNodeQuads; ++k) {
               const v4f_t q = nd[k];  // ds_read_b128
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           if (STATS) {
             ++c_nodes;
             ++ray_nodes;
-            if (kTopNodes > 0 && noff < kTopNodes * kNodeBytes) ++c_lds;
+            if (kTopNodes > 0 && loff < kTopNodes * kNodeBytes) ++c_lds;
             if (so.node_hist) atomicAdd(so.node_hist + noff / kNodeBytes, 1u);
           }
           uint32_t ngb, ngs, ntb, ntm;
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
       asm("" : "=v"(t), "=v"(u), "=v"(v), "=v"(aw));  // any value
       bool hit = false;
       if (act) {
-        const q4* p = tris + 3ll * slot;
+        const q4* p = tris + 3ll * (IO::kVersioned ? slot + tri_base : slot);
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
         aw = p0.w;
         hit = intersect_tri_rot(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u, v);

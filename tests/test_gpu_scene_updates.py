@@ -445,3 +445,83 @@ def test_table_edits_every_frame_without_a_drain(oracle_mod, cornell, materials_
         ctx.render(spp=2, first_timestamp=frames + 6)
         acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=2, first_timestamp=frames + 6, accum=acc)
         assert np.array_equal(ctx.download().reshape(-1, 4), acc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["cornell", "interior"])
+def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which):
+    """(r05, VERDICT r04 item 6, second half) gsp_update_instances with samples IN FLIGHT keeps them in flight: the refit goes
+    into the next slot of the geometry ring (8 versions of node records, intersection triangles and shading packets), a sample
+    carries the slot it was generated under and finishes in it.  One sample per frame, an object moved (and a material flag
+    flipped, a BSDF record and the light's radiance edited: both rings at once) before EVERY frame, no sync in the loop: several
+    rounds of the ring, rays of up to eight trees in one launch.  The accumulate buffer must equal the oracle's running mean
+    over the same sequence of scenes, bit for bit; then the edits stop (one version again, the <VER = false> kernels), an object
+    leaves the room (the refit is abandoned, the samples in flight finish, the tree is rebuilt) and comes back."""
+    import copy
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import scenes
+
+    if which == "cornell":
+        sc, (W, H), frames = copy.deepcopy(cornell), (48, 40), 60
+    else:
+        sc, (W, H), frames = scenes.interior(20_000), (64, 36), 30
+    base = sc.instances.copy()
+    big = int(np.argmax(base["vertex_count"])) if which == "interior" else len(base) - 1
+    emissive = {int(i) for i in np.nonzero(np.asarray(base["emission"]).reshape(len(base), -1)[:, :3].any(1))[0]}
+
+    def edit(k, far=False):
+        inst = base.copy()
+        t = inst["transform"][big].copy()
+        t[12:15] += (np.float32(80.0) if far else np.float32(0.01 * (k % 13))) * np.array([1.0, 0.25, -0.5], np.float32)
+        inst["transform"][big] = t
+        j = (5 * k) % len(inst)
+        if j not in emissive and j != big:
+            inst["twofaced"][j] ^= 1
+        sc.instances = inst
+        if k % 3 == 0:  # the tables now and then as well
+            bs = [b.copy() for b in sc.bsdfs]
+            bs[0]["reflectance"][k % len(bs[0])] = (0.15 + 0.7 * ((k * 7) % 11) / 11.0, 0.5, 0.85 - 0.6 * ((k * 5) % 7) / 7.0)
+            sc.bsdfs = bs
+
+    acc = None
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        for k in range(frames):
+            edit(k + 1)
+            ctx.update_instances(sc.instances)  # (the first one drains and makes the ring; no sync after that)
+            ctx.update_tables(sc)
+            ctx.render(spp=1, first_timestamp=k)
+            acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+        img = ctx.download().reshape(-1, 4)
+        assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(1).sum())
+        st = ctx.stats()
+        assert st["scene_refits"] == frames, st
+        # the edits are over: more samples of the last version, then one edit with nothing but that version in flight
+        ctx.render(spp=3, first_timestamp=frames)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=3, first_timestamp=frames, accum=acc)
+        edit(frames + 2)
+        ctx.update_instances(sc.instances)
+        ctx.update_tables(sc)
+        ctx.render(spp=2, first_timestamp=frames + 3)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=2, first_timestamp=frames + 3, accum=acc)
+        assert np.array_equal(ctx.download().reshape(-1, 4), acc)
+        # an object leaves the room while samples are in flight: refit abandoned, drain, rebuild -- and back (a new ring)
+        ctx.render(spp=1, first_timestamp=frames + 5)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=frames + 5, accum=acc)
+        refits = ctx.stats()["scene_refits"]
+        edit(frames + 3, far=True)
+        ctx.update_instances(sc.instances)
+        ctx.update_tables(sc)
+        if which == "interior":
+            assert ctx.stats()["scene_refits"] == refits  # rebuilt
+        ctx.render(spp=1, first_timestamp=frames + 6)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=frames + 6, accum=acc)
+        for k in range(frames + 7, frames + 12):
+            edit(k)
+            ctx.update_instances(sc.instances)
+            ctx.update_tables(sc)
+            ctx.render(spp=1, first_timestamp=k)
+            acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+        assert np.array_equal(ctx.download().reshape(-1, 4), acc)
