@@ -237,8 +237,8 @@ struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any h
 };
 
 // The same two sources while samples of several GEOMETRY versions are in flight (gsp_update_instances without a drain,
-// pt_stages.h): a path's stamp sits in its flags word, a shadow ray's in the top three bits of the word that names the
-// continuing path (queues hold fewer than 2^29 entries then: lane_enqueue).  `nodes` / `tris` of the launch are slot 0 of the ring.
+// pt_stages.h): a path's stamp sits in its flags word; a shadow ray finds it in the flags of the continuing path (S3.w) or, when
+// the path ended at the vertex, in the word that would have named it.  `nodes` / `tris` of the launch are slot 0 of the ring.
 struct GeoRing {
   uint32_t geo;      // pt_stages.h pack_geo
   uint32_t top_off;  // node-record byte offset of the newest version
@@ -247,7 +247,7 @@ struct GeoRing {
     node_off = tri_base * kNodeBytes;
   }
 };
-constexpr uint32_t kNextBits = 29, kNoNext = (1u << kNextBits) - 1u;  // <VER> shadow records: index of the continuing path | stamp << 29
+constexpr uint32_t kNoNextBit = 0x80000000u;  // <VER> shadow records: index of the continuing path, or this bit | the geometry stamp
 struct ExtendVerIO : ExtendIO {
   static constexpr bool kVersioned = true;
   GeoRing g;
@@ -260,12 +260,12 @@ struct ConnectVerIO : ConnectIO {
   static constexpr bool kVersioned = true;
   GeoRing g;
   __device__ __forceinline__ uint32_t top_offset() const { return g.top_off; }
-  __device__ __forceinline__ void geometry(uint32_t, uint32_t pay, uint32_t& node_off, uint32_t& tri_base) const {
-    g.offsets(pay >> kNextBits, node_off, tri_base);
+  __device__ __forceinline__ void geometry(uint32_t i, uint32_t pay, uint32_t& node_off, uint32_t& tri_base) const {
+    const uint32_t stamp = (pay & kNoNextBit) ? (pay & (kGeoVersions - 1u)) : geo_stamp(((const uint32_t*)&sq.S3[i])[3]);
+    g.offsets(stamp, node_off, tri_base);
   }
   __device__ __forceinline__ void store(uint32_t i, const HitRec& h, uint32_t aux, uint32_t pay) const {
-    const uint32_t nx = pay & kNoNext;
-    ConnectIO::store(i, h, aux, nx == kNoNext ? 0xffffffffu : nx);
+    ConnectIO::store(i, h, aux, (pay & kNoNextBit) ? 0xffffffffu : pay);
   }
 };
 
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
       const ShadowRay& r = out.shadow;
       if (!alive) result[my_sid] = mkq(clear.x, clear.y, clear.z, 0.0f);  // the path ended here: its sample, unless occluded
       qst(&sq.S0[s], mkq(r.o.x, r.o.y, r.o.z, r.tmax));
-      if (VER) qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub((alive ? j : kNoNext) | (geo_stamp(fb(sum.w)) << kNextBits))));  // (sum.w: the flags the vertex came with)
+      if (VER) qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(alive ? j : (kNoNextBit | geo_stamp(fb(sum.w))))));  // (sum.w: the flags the vertex came with)
       else qst(&sq.S1[s], mkq(r.d.x, r.d.y, r.d.z, ub(alive ? j : 0xffffffffu)));
       qst(&sq.S3[s], mkq(occ.x, occ.y, occ.z, ub(alive ? out.next.flags : r.sid)));
     }
@@ -827,16 +827,18 @@ struct gsp_context {
   uint32_t tab_rot = 0;  // version that slot 0 / flags field 0 stand for
   uint32_t tab_slot(uint32_t v) const { return (v - tab_rot) % kTableVersions; }
   uint32_t num_lights = 0;
-  // r05: the GEOMETRY ring (pt_stages.h): kGeoVersions slots of geo_stride triangle slots each -- node records, intersection
+  // r05: the GEOMETRY ring (pt_stages.h): 2^geo_log2 <= kGeoVersions slots of geo_stride triangle slots each -- node records, intersection
   // triangles, shading packets -- so that gsp_update_instances need not wait for the samples in flight either: the refit goes
   // into the next slot, new samples are stamped with it, the old ones finish in theirs.  Made by the first gsp_update_instances
   // of a tree (which drains, as every one did until r04); `bvh.nodes / tri_isect / tri_shade` then point at the NEWEST slot.
   DevBuf<q4> ring_nodes, ring_isect, ring_shade;
   uint32_t geo_stride = 0;  // triangle slots per version; 0 = no ring (the tree owns its arrays)
-  uint32_t geo_ver = 0;     // version the next sample is generated under (monotonic); its slot: geo_ver % kGeoVersions
+  uint32_t geo_log2 = 0;    // log2 of the slots of the ring
+  uint32_t geo_ver = 0;     // version the next sample is generated under (monotonic); its slot: geo_ver % slots
   uint32_t geo_base = 0;    // slot that stamp 0 stands for
   bool geo_ring_failed = false;  // no memory for it: edits drain, as before
-  uint32_t geo_phys(uint32_t v) const { return v % kGeoVersions; }
+  uint32_t geo_slots() const { return 1u << geo_log2; }
+  uint32_t geo_phys(uint32_t v) const { return v & (geo_slots() - 1u); }
   gsp_camera camera{};
   double bvh_build_ms = 0.0;
   // what gsp_upload_scene leaves resident for the per-frame edits (gsp_update_instances re-bakes from it, as the reference
@@ -954,10 +956,10 @@ struct gsp_context {
       if (lanes[l].pipe.active && !lanes[l].pipe.inflight.empty()) o = std::min(o, lanes[l].pipe.inflight.front().gver);
     return o;
   }
-  // the <VER> kernels' shadow records keep the geometry stamp in the top bits of a queue index (kNextBits)
+  // the <VER> kernels' shadow records keep a flag in the top bit of a queue index (kNoNextBit)
   bool caps_allow_versions() const {
     for (uint32_t l = 0; l < num_lanes; ++l)
-      if (lanes[l].pipe.active && lanes[l].pipe.cap >= (uint64_t)kNoNext) return false;
+      if (lanes[l].pipe.active && lanes[l].pipe.cap >= (uint64_t)kNoNextBit) return false;
     return true;
   }
   // versioned == false: the tables and the geometry of the current version (all samples in flight belong to it); true: slot 0
@@ -968,7 +970,7 @@ struct gsp_context {
     v.nodes = ring ? ring_nodes.p : bvh.nodes;
     v.tri_isect = ring ? ring_isect.p : bvh.tri_isect;
     v.tri_shade = ring ? ring_shade.p : bvh.tri_shade;
-    v.geo = ring ? pack_geo(geo_base, geo_stride) : 0u;
+    v.geo = ring ? pack_geo(geo_base, geo_stride, geo_log2) : 0u;
     const uint8_t* tb = tables.p;  // slot 0: the one live version (versioned == false), or the base the <VER> kernels add their offset to
     v.ver_stride = versioned ? (uint32_t)tab_slot_bytes : 0u;
     v.bsdf.diffuse = (const gsp_diffuse_bsdf*)(tb + table_off[0]);
@@ -1322,23 +1324,31 @@ static void drop_geo_ring(gsp_context* ctx) {
     b->release();
   }
   ctx->geo_stride = 0;
+  ctx->geo_log2 = 0;
   ctx->geo_ver = 0;
   ctx->geo_base = 0;
 }
-// Moves the tree's three arrays into slot geo_ver % kGeoVersions of a new ring.  GSP_OK also when there is no ring to be had
-// (tree too large for 32-bit node offsets, no memory): gsp_update_instances then drains every time, as before.
+// Moves the tree's three arrays into slot 0 of a new ring of as many versions (a power of two, at most kGeoVersions) as 32-bit node
+// offsets and a quarter of the free device memory allow: 176 B per triangle and version, 11 GB for 64 versions of a million
+// triangles.  GSP_OK also when there is no ring to be had (fewer than four versions fit): gsp_update_instances then drains every
+// time, as before.
 static int make_geo_ring(gsp_context* ctx) {
   DeviceBvh& b = ctx->bvh;
   if (ctx->geo_stride != 0 || ctx->geo_ring_failed || !b.nodes || b.num_tris == 0 || b.arrays_external) return GSP_OK;
   const uint64_t slots = (uint64_t)b.num_tris + b.first_slot + (kWide - 1);
   const uint64_t stride = std::max<uint64_t>(slots, kNodeAllocMin / kNodeBytes);
   if (stride > kGeoMaxStride || b.num_nodes > stride) return GSP_OK;
+  size_t free_b = 0, total_b = 0;
+  CTX_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  uint32_t lg = 6;  // log2(kGeoVersions)
+  static_assert(kGeoVersions == 64, "log2");
+  while (lg > 0 && (((uint64_t)stride << lg) * kNodeBytes >= (1ull << 32) || ((uint64_t)stride << lg) * 11 * sizeof(q4) > free_b / 4)) --lg;
+  if (lg < 2) return GSP_OK;
   hipStream_t st = ctx->stream;
-  const size_t total = (size_t)kGeoVersions * stride;
+  const size_t total = (size_t)stride << lg;
   if (ctx->ring_nodes.ensure(total * kNodeQuads, &ctx->bytes) != hipSuccess || ctx->ring_isect.ensure(total * 3, &ctx->bytes) != hipSuccess ||
       ctx->ring_shade.ensure(total * 4, &ctx->bytes) != hipSuccess) {
     (void)hipGetLastError();
-    ctx->geo_stride = 1;  // (so that drop_geo_ring releases what was allocated)
     drop_geo_ring(ctx);
     ctx->geo_ring_failed = true;
     return GSP_OK;
@@ -1349,6 +1359,7 @@ static int make_geo_ring(gsp_context* ctx) {
   CTX_TRY(ctx, hipMemsetAsync(ctx->ring_shade.p, 0, total * 4 * sizeof(q4), st));
   ctx->geo_ver = 0;
   ctx->geo_base = 0;
+  ctx->geo_log2 = lg;
   q4* nn = ctx->ring_nodes.p;  // (slot 0)
   q4* ni = ctx->ring_isect.p;
   q4* ns = ctx->ring_shade.p;
@@ -1370,7 +1381,7 @@ static int make_geo_ring(gsp_context* ctx) {
   ctx->geo_stride = (uint32_t)stride;
   return GSP_OK;
 }
-// the tree's arrays := slot `v % kGeoVersions`
+// the tree's arrays := the slot of version v
 static void point_bvh_at(gsp_context* ctx, uint32_t v) {
   const size_t off = (size_t)ctx->geo_phys(v) * ctx->geo_stride;
   ctx->bvh.nodes = ctx->ring_nodes.p + off * kNodeQuads;
@@ -1429,6 +1440,7 @@ static int bake_and_build(gsp_context* ctx, bool refit = false, bool* refitted =
   // a refit into the next slot of the ring that grew too much is abandoned here)
   if (ctx->geo_stride) point_bvh_at(ctx, ctx->geo_ver);
   if (ctx->pipe_active) {
+    ++ctx->stats.scene_drains;
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
@@ -1545,6 +1557,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->stats.scene_updates = 0;
   ctx->stats.scene_refits = 0;
+  ctx->stats.scene_drains = 0;
   ctx->have_scene = true;
   return GSP_OK;
 }
@@ -1600,11 +1613,13 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   // r05: NO DRAIN when the tree has its geometry ring and a slot of it is free: the refit -- re-bake of every packet, node boxes
   // bottom-up in the existing topology -- goes into the NEXT slot, on the context's stream, while the lanes' streams finish the
   // samples in flight in the slots they were generated under (a path carries its slot in its flags word, pt_stages.h); the next
-  // gsp_render stamps its samples with the new one.  Otherwise -- first edit of this tree (the ring is made then), kGeoVersions
-  // edits within the life of one sample, a tree that degrades and is rebuilt -- the queued samples finish first, as until r04.
+  // gsp_render stamps its samples with the new one.  Otherwise -- first edit of this tree (the ring is made then), as many edits
+  // as the ring has slots within the life of one sample, a tree that degrades and is rebuilt -- the queued samples finish first,
+  // as until r04.
   const bool in_ring = ctx->pipe_active && ctx->geo_stride != 0 && ctx->opt.refit_growth > 1.0 && ctx->caps_allow_versions() &&
-                       ctx->geo_ver + 1 - ctx->oldest_live_geo() < kGeoVersions;
+                       ctx->geo_ver + 1 - ctx->oldest_live_geo() < ctx->geo_slots();
   if (!in_ring) {
+    if (ctx->pipe_active) ++ctx->stats.scene_drains;
     rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
     if (ctx->opt.refit_growth > 1.0) {
@@ -1665,6 +1680,7 @@ int gsp_update_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
   for (int k = 0; k < GSP_BSDF_TYPE_COUNT && same_layout; ++k) same_layout = sc->num_bsdfs[k] == ctx->num_bsdfs[k];
   const bool in_place = same_layout && ctx->caps_allow_versions() && ctx->tab_ver + 1 - ctx->oldest_live_version() < kTableVersions;
   if (!in_place) {
+    if (ctx->pipe_active) ++ctx->stats.scene_drains;
     rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
   }
@@ -1831,7 +1847,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   }
   const SceneView vview = multi_version ? ctx->view(true) : view;
   const uint32_t gen_ver_bits = (ctx->tab_slot(ctx->tab_ver) << kVerShift) |  // (0 unless an edit is in flight)
-                                (((ctx->geo_phys(ctx->geo_ver) + kGeoVersions - ctx->geo_base) % kGeoVersions) << kGeoShift);
+                                (ctx->geo_phys(ctx->geo_ver + ctx->geo_slots() - ctx->geo_base) << kGeoShift);
   const GeoRing gring{vview.geo, (uint32_t)((size_t)ctx->geo_phys(ctx->geo_ver) * ctx->geo_stride * kNodeBytes)};
 
   CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
@@ -2402,10 +2418,11 @@ int gsp_reset_stats(gsp_context* ctx) {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
-  const uint64_t updates = ctx->stats.scene_updates, refits = ctx->stats.scene_refits;  // (counts since the last gsp_upload_scene, not since the last reset)
+  const uint64_t updates = ctx->stats.scene_updates, refits = ctx->stats.scene_refits, drains = ctx->stats.scene_drains;  // (counts since the last gsp_upload_scene, not since the last reset)
   ctx->stats = gsp_stats{};
   ctx->stats.scene_updates = updates;
   ctx->stats.scene_refits = refits;
+  ctx->stats.scene_drains = drains;
   if (ctx->dstats.p) {
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
     CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));

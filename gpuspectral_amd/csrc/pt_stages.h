@@ -52,7 +52,7 @@ struct SceneView {
   TextureView tex;                  // dormant-feature extension; read only by the <TEX = true> instantiations
 };
 
-// path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9 | table version << 10 [10,15] | geometry version << 16 [16,18]
+// path flags word: depth [0,7] | wasDelta << 8 | countEmitted << 9 | table version << 10 [10,15] | geometry version << 16 [16,21]
 GSP_HD uint32_t pack_flags(uint32_t depth, uint32_t wasDelta, uint32_t countEmitted) {
   return depth | (wasDelta << 8) | (countEmitted << 9);
 }
@@ -62,19 +62,25 @@ GSP_HD uint32_t pack_flags(uint32_t depth, uint32_t wasDelta, uint32_t countEmit
 // While every sample in flight belongs to ONE version -- always, for a scene that is not being edited -- that version sits in
 // slot 0, the field is 0 and the <VER = false> kernels neither read nor write it: their code is what it was before versions existed.
 constexpr uint32_t kVerShift = 10, kTableVersions = 64, kVerMask = (kTableVersions - 1u) << kVerShift;
-// ... and the version of the GEOMETRY (gsp_update_instances without a drain: bits [16,18]): the node records, intersection
-// triangles and shading packets of up to kGeoVersions edits live in a ring -- version slot p at nodes + p * stride * 64 B (a tree
-// of n triangles has fewer than n nodes), tri_isect + 3 * p * stride, tri_shade + 4 * p * stride quads, stride = triangle slots per
-// version -- and a path's stamp s names slot (s + base) % kGeoVersions, base = the slot of the one live version the last time only
-// one was (then the field is 0, as for the tables).  Both travel in SceneView::geo / GeoRing.
-constexpr uint32_t kGeoShift = 16, kGeoVersions = 8, kGeoMask = (kGeoVersions - 1u) << kGeoShift;
+// ... and the version of the GEOMETRY (gsp_update_instances without a drain: bits [16,21]): the node records, intersection
+// triangles and shading packets of up to kGeoVersions edits live in a ring of G = 2^g slots -- version slot p at nodes + p * stride
+// * 64 B (a tree of n triangles has fewer than n nodes), tri_isect + 3 * p * stride, tri_shade + 4 * p * stride quads, stride =
+// triangle slots per version -- and a path's stamp s names slot (s + base) % G, base = the slot of the one live version the last
+// time only one was (then the field is 0, as for the tables).  A path of 52 bounces lives 52 iterations -- 52 frames of a viewer
+// that renders one sample per frame -- so the ring is as long as the tables' when memory and the 32-bit node offsets allow
+// (G * stride * 64 B < 4 GB: 64 versions up to a million triangles, 8 up to eight million).  g, base and stride travel in one
+// word (SceneView::geo / GeoRing).
+constexpr uint32_t kGeoShift = 16, kGeoVersions = 64, kGeoMask = (kGeoVersions - 1u) << kGeoShift;
 constexpr uint32_t kStampMask = kVerMask | kGeoMask;
-constexpr uint32_t kGeoStrideBits = 29, kGeoStrideMask = (1u << kGeoStrideBits) - 1u;
-constexpr uint32_t kGeoMaxStride = (1u << 23) - 1u;  // 8 versions x stride x 64 B of node records stay below 4 GB (32-bit node offsets)
-GSP_HD uint32_t pack_geo(uint32_t base, uint32_t stride) { return (base << kGeoStrideBits) | stride; }
+constexpr uint32_t kGeoStrideBits = 23, kGeoStrideMask = (1u << kGeoStrideBits) - 1u;  // stride | base << 23 | g << 29
+constexpr uint32_t kGeoMaxStride = kGeoStrideMask;
+GSP_HD uint32_t pack_geo(uint32_t base, uint32_t stride, uint32_t log2_versions) {
+  return stride | (base << kGeoStrideBits) | (log2_versions << 29);
+}
 // slot offset (in triangle slots) of the geometry version a stamp names
 GSP_HD uint32_t geo_slot_offset(uint32_t geo, uint32_t stamp) {
-  return ((stamp + (geo >> kGeoStrideBits)) & (kGeoVersions - 1u)) * (geo & kGeoStrideMask);
+  const uint32_t mask = (1u << (geo >> 29)) - 1u;
+  return ((stamp + ((geo >> kGeoStrideBits) & (kGeoVersions - 1u))) & mask) * (geo & kGeoStrideMask);
 }
 GSP_HD uint32_t geo_stamp(uint32_t flags) { return (flags & kGeoMask) >> kGeoShift; }
 

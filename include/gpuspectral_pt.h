@@ -298,6 +298,8 @@ typedef struct gsp_stats {
   uint64_t scene_refits;     /* (ABI 6) of those, gsp_update_instances calls that kept the tree's topology (refit) */
   uint64_t shadow_stat_no_triangle; /* (ABI 7, stats mode) shadow rays of shadow_stat_rays that ended without ONE triangle test
                                        (the ray's shear constants Sx, Sy were computed for nothing: VERDICT r04 item 7) */
+  uint64_t scene_drains;     /* (ABI 7) of scene_updates: calls that first let the samples in flight finish (a test hook: an edited
+                                BSDF record / light / transform does not, once the version rings exist: INTEGRATION.md) */
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;

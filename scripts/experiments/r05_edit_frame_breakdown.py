@@ -1,0 +1,47 @@
+"""Where does a frame with a transform edit spend its time?  500x500, one sample per frame, the 988 k-triangle scene: wall time of
+gsp_update_instances / gsp_render / gsp_peek per frame, for a transform edit, a camera edit and no edit.
+   python scripts/experiments/r05_edit_frame_breakdown.py"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import gpuspectral_amd as g
+from gpuspectral_amd import scenes
+
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (500, 500)
+sc = scenes.interior(1_000_000, seed=7)
+with g.Context(0) as ctx:
+    ctx.upload_scene(sc)
+    for what in ("none", "camera", "transform"):
+        ctx.frame_begin(W, H)
+        ctx.render(spp=4)
+        ctx.sync()
+        tt = np.zeros(3)
+        n = 60
+        st0 = ctx.stats()
+        t_all = time.time()
+        for f in range(n):
+            t0 = time.time()
+            if what == "transform":
+                i = sc.instances.copy()
+                t = i["transform"][len(i) - 1].copy()
+                t[13] += np.float32(0.0005)
+                i["transform"][len(i) - 1] = t
+                sc.instances = i
+                ctx.update_instances(i)
+            elif what == "camera":
+                m = np.array(sc.to_world, np.float32).copy()
+                m[12] += np.float32(0.002 * f)
+                ctx.update_camera(m, sc.fov)
+            t1 = time.time()
+            ctx.render(spp=1, first_timestamp=4 + f)
+            t2 = time.time()
+            ctx.peek()
+            t3 = time.time()
+            tt += (t1 - t0, t2 - t1, t3 - t2)
+        ctx.sync()
+        el = time.time() - t_all
+        st = ctx.stats()
+        rays = st["extension_rays"] + st["shadow_rays"] - st0["extension_rays"] - st0["shadow_rays"]
+        print("%-9s %dx%d: %7.1f frames/s | per frame: edit %.3f ms, render %.3f ms, peek %.3f ms | %.1f Mrays/s" %
+              (what, W, H, n / el, *(1e3 * tt / n), rays / el / 1e6))

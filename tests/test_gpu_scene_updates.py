@@ -424,6 +424,7 @@ def test_table_edits_every_frame_without_a_drain(oracle_mod, cornell, materials_
         img = ctx.download().reshape(-1, 4)
         assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(1).sum())
         assert ctx.stats()["scene_updates"] == frames
+        assert ctx.stats()["scene_drains"] == 0
         # the edits are over: more samples of the last version (the pipeline goes back to one version in slot 0), then one more
         # edit with nothing but that version in flight
         ctx.render(spp=3, first_timestamp=frames)
@@ -498,6 +499,7 @@ def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which)
         assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(1).sum())
         st = ctx.stats()
         assert st["scene_refits"] == frames, st
+        assert st["scene_drains"] == 0, st  # (the first edit makes the ring: nothing was in flight yet); every later one found a free slot
         # the edits are over: more samples of the last version, then one edit with nothing but that version in flight
         ctx.render(spp=3, first_timestamp=frames)
         acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=3, first_timestamp=frames, accum=acc)
@@ -510,12 +512,12 @@ def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which)
         # an object leaves the room while samples are in flight: refit abandoned, drain, rebuild -- and back (a new ring)
         ctx.render(spp=1, first_timestamp=frames + 5)
         acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=frames + 5, accum=acc)
-        refits = ctx.stats()["scene_refits"]
+        refits = frames + 1  # (gsp_get_stats would drain: not asked here)
         edit(frames + 3, far=True)
         ctx.update_instances(sc.instances)
         ctx.update_tables(sc)
         if which == "interior":
-            assert ctx.stats()["scene_refits"] == refits  # rebuilt
+            assert ctx.stats()["scene_refits"] == refits and ctx.stats()["scene_drains"] == 1  # rebuilt, behind a drain
         ctx.render(spp=1, first_timestamp=frames + 6)
         acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=frames + 6, accum=acc)
         for k in range(frames + 7, frames + 12):
