@@ -807,16 +807,17 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(uint32_t first, uint32_t
   node_children(n, ni, nl, child_base, tri_base);
   WideChild wc[kWide];
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int k = 0; k < ni + nl; ++k) {
-    if (k < ni) {
-      wc[k].lo = box_lo[child_base + (uint32_t)k];
-      wc[k].hi = box_hi[child_base + (uint32_t)k];
-    } else {
-      wc[k].lo = leaf_lo[tri_base + (uint32_t)(k - ni)];
-      wc[k].hi = leaf_hi[tri_base + (uint32_t)(k - ni)];
+#pragma unroll
+  for (int k = 0; k < kWide; ++k) {  // (positions by constant index: the four boxes stay in registers)
+    wc[k].lo = wc[k].hi = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+    if (k < ni + nl) {
+      const q4* pl = k < ni ? box_lo + (child_base + (uint32_t)k) : leaf_lo + (tri_base + (uint32_t)(k - ni));
+      const q4* ph = k < ni ? box_hi + (child_base + (uint32_t)k) : leaf_hi + (tri_base + (uint32_t)(k - ni));
+      wc[k].lo = *pl;
+      wc[k].hi = *ph;
+      lo[0] = fminf(lo[0], wc[k].lo.x), lo[1] = fminf(lo[1], wc[k].lo.y), lo[2] = fminf(lo[2], wc[k].lo.z);
+      hi[0] = fmaxf(hi[0], wc[k].hi.x), hi[1] = fmaxf(hi[1], wc[k].hi.y), hi[2] = fmaxf(hi[2], wc[k].hi.z);
     }
-    lo[0] = fminf(lo[0], wc[k].lo.x), lo[1] = fminf(lo[1], wc[k].lo.y), lo[2] = fminf(lo[2], wc[k].lo.z);
-    hi[0] = fmaxf(hi[0], wc[k].hi.x), hi[1] = fmaxf(hi[1], wc[k].hi.y), hi[2] = fmaxf(hi[2], wc[k].hi.z);
   }
   encode_node_w4(rec, wc, ni, nl, child_base, tri_base);
   box_lo[node] = mkq(lo[0], lo[1], lo[2], 0.0f);

@@ -341,7 +341,11 @@ GSP_HD float order_key(const WideChild& c, const float* ext, int oct) {
 GSP_HD uint32_t pack4(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
 
 // 4-wide node: e[0..ni) inner children (nodes child_base + k), e[ni..ni+nl) leaf children (triangle slots tri_base + j)
-GSP_HD void encode_node_w4(q4* __restrict__ o, const WideChild* e, int ni, int nl, uint32_t child_base, uint32_t tri_base) {
+// The encoder as first written -- loops over the children, arrays indexed by loop variables -- kept as the DEFINITION the one
+// below is checked against (tests/test_emu_parity.py::test_node_encoder_forms_agree): on the device its arrays live in scratch
+// memory and a node takes ~5 k dependent instructions, which is what a refit of the tree waited for, level by level
+// (21 launches of 9-90 us each for a million triangles: profiles/r05_refit_encoder.txt).
+GSP_HD void encode_node_w4_ref(q4* __restrict__ o, const WideChild* e, int ni, int nl, uint32_t child_base, uint32_t tri_base) {
   float lo[3], scale[3];
   uint8_t q[6][8];
   quantise_children(e, ni + nl, lo, scale, q);
@@ -369,6 +373,148 @@ GSP_HD void encode_node_w4(q4* __restrict__ o, const WideChild* e, int ni, int n
   o[0] = make_q4(lo[0], lo[1], lo[2], scale[0]);
   o[1] = make_q4(u2f(pack4(q[0])), u2f(pack4(q[1])), u2f(pack4(q[2])), u2f(pack4(q[3])));
   o[2] = make_q4(u2f(pack4(q[4])), u2f(pack4(q[5])), u2f(child_base), u2f(tri_base - (uint32_t)ni));
+  o[3] = make_q4(u2f(order[0]), u2f(order[1]), scale[1], scale[2]);
+}
+
+// The same record, written for the device: the four child positions in named variables, every loop unrolled over them with the
+// position's validity as a predicate, the stable insertion sort of the per-octant keys as its six compare-exchanges (each one
+// conditional on the one before, as the loop's early exit is), the order code from the Lehmer digits in closed form, power-of-two
+// divisions as exact multiplications.  Same operations in the same order on the same values: the same bits.
+GSP_HD void encode_node_w4(q4* __restrict__ o, const WideChild* e, int ni, int nl, uint32_t child_base, uint32_t tri_base) {
+  const int cnt = ni + nl;
+  const bool on[4] = {cnt > 0, cnt > 1, cnt > 2, cnt > 3};
+  WideChild c[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 4; ++k) {
+    c[k].lo = make_q4(0.0f, 0.0f, 0.0f, 0.0f);
+    c[k].hi = make_q4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (on[k]) c[k] = e[k];
+  }
+  // ---- quantise_children: origin, power-of-two scales ----
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 4; ++k)
+    if (on[k]) {
+      lo[0] = fmin_(lo[0], c[k].lo.x); lo[1] = fmin_(lo[1], c[k].lo.y); lo[2] = fmin_(lo[2], c[k].lo.z);
+      hi[0] = fmax_(hi[0], c[k].hi.x); hi[1] = fmax_(hi[1], c[k].hi.y); hi[2] = fmax_(hi[2], c[k].hi.z);
+    }
+  if (cnt == 0) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
+  float scale[3], inv_scale[3];
+  bool exact_inv[3];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int a = 0; a < 3; ++a) {
+    const float ext = hi[a] - lo[a];
+    int ex = -100;
+    if (ext > 0.0f) (void)frexpf(ext / 255.0f, &ex);  // 2^ex >= ext / 255
+    int eb = ex + 127;
+    eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+    while (eb < 254 && __builtin_fmaf(255.0f, u2f((uint32_t)eb << 23), lo[a]) < hi[a]) ++eb;  // the largest code must reach the far side
+    scale[a] = u2f((uint32_t)eb << 23);
+    // x / 2^k == x * 2^-k, correctly rounded both, whenever 2^-k is a normal number
+    exact_inv[a] = eb <= 253;
+    inv_scale[a] = u2f((uint32_t)(254 - eb) << 23);
+  }
+  // ---- quantised planes, packed: word[plane] byte k = child k; unused positions carry the inverted box (255 / 0) ----
+  uint32_t qw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 4; ++k) {
+    const float cl[3] = {c[k].lo.x, c[k].lo.y, c[k].lo.z}, ch[3] = {c[k].hi.x, c[k].hi.y, c[k].hi.z};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int a = 0; a < 3; ++a) {
+      uint32_t bl = 255u, bh = 0u;
+      if (on[k]) {
+        const float dl = cl[a] - lo[a], dh = ch[a] - lo[a];
+        float ql = fmin_(fmax_(__builtin_floorf(exact_inv[a] ? dl * inv_scale[a] : dl / scale[a]), 0.0f), 255.0f);
+        while (ql > 0.0f && __builtin_fmaf(ql, scale[a], lo[a]) > cl[a]) ql -= 1.0f;  // decoded plane must not exceed the box
+        float qh = fmin_(fmax_(__builtin_ceilf(exact_inv[a] ? dh * inv_scale[a] : dh / scale[a]), 0.0f), 255.0f);
+        while (qh < 255.0f && __builtin_fmaf(qh, scale[a], lo[a]) < ch[a]) qh += 1.0f;
+        bl = (uint32_t)(uint8_t)ql;
+        bh = (uint32_t)(uint8_t)qh;
+      }
+      qw[a] |= bl << (8 * k);
+      qw[3 + a] |= bh << (8 * k);
+    }
+  }
+  // ---- per-octant visiting orders of the inner children ----
+  float ext[3] = {0.0f, 0.0f, 0.0f};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 4; ++k)
+    if (on[k]) {
+      ext[0] = fmax_(ext[0], c[k].hi.x - lo[0]);
+      ext[1] = fmax_(ext[1], c[k].hi.y - lo[1]);
+      ext[2] = fmax_(ext[2], c[k].hi.z - lo[2]);
+    }
+  float cx[4], cy[4], cz[4];  // order_key's centre of child k in units of the node's extent (the same for all eight octants)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 4; ++k) {
+    cx[k] = ext[0] > 0.0f ? (c[k].lo.x + c[k].hi.x) / ext[0] : 0.0f;
+    cy[k] = ext[1] > 0.0f ? (c[k].lo.y + c[k].hi.y) / ext[1] : 0.0f;
+    cz[k] = ext[2] > 0.0f ? (c[k].lo.z + c[k].hi.z) / ext[2] : 0.0f;
+  }
+  uint32_t order[2] = {0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int oct = 0; oct < 8; ++oct) {
+    // slot j holds perm[j] and its key
+    float k0 = ((oct & 1 ? -cx[0] : cx[0]) + (oct & 2 ? -cy[0] : cy[0])) + (oct & 4 ? -cz[0] : cz[0]);
+    float k1 = ((oct & 1 ? -cx[1] : cx[1]) + (oct & 2 ? -cy[1] : cy[1])) + (oct & 4 ? -cz[1] : cz[1]);
+    float k2 = ((oct & 1 ? -cx[2] : cx[2]) + (oct & 2 ? -cy[2] : cy[2])) + (oct & 4 ? -cz[2] : cz[2]);
+    float k3 = ((oct & 1 ? -cx[3] : cx[3]) + (oct & 2 ? -cy[3] : cy[3])) + (oct & 4 ? -cz[3] : cz[3]);
+    int p0 = 0, p1 = 1, p2 = 2, p3 = 3;
+#define GSP_CSWAP(KA, KB, PA, PB, COND)        \
+  {                                            \
+    const bool s_ = (COND);                    \
+    const float ta_ = KA, tb_ = KB;            \
+    const int qa_ = PA, qb_ = PB;              \
+    KA = s_ ? tb_ : ta_;                       \
+    KB = s_ ? ta_ : tb_;                       \
+    PA = s_ ? qb_ : qa_;                       \
+    PB = s_ ? qa_ : qb_;                       \
+  }
+    bool m;  // "the element being inserted is still moving left"
+    m = ni > 1 && k1 < k0;
+    GSP_CSWAP(k0, k1, p0, p1, m)
+    m = ni > 2 && k2 < k1;
+    GSP_CSWAP(k1, k2, p1, p2, m)
+    m = m && k1 < k0;
+    GSP_CSWAP(k0, k1, p0, p1, m)
+    m = ni > 3 && k3 < k2;
+    GSP_CSWAP(k2, k3, p2, p3, m)
+    m = m && k2 < k1;
+    GSP_CSWAP(k1, k2, p1, p2, m)
+    m = m && k1 < k0;
+    GSP_CSWAP(k0, k1, p0, p1, m)
+#undef GSP_CSWAP
+    // encode_order: Lehmer digits d_i = perm[i] - #{j < i : perm[j] < perm[i]}, weights (ni - 1 - i)!
+    const int d0 = p0;
+    const int d1 = p1 - (p0 < p1 ? 1 : 0);
+    const int d2 = p2 - (p0 < p2 ? 1 : 0) - (p1 < p2 ? 1 : 0);
+    int code = 0;
+    if (ni == 1) code = 1;
+    else if (ni == 2) code = 2 + d0;
+    else if (ni == 3) code = 4 + 2 * d0 + d1;
+    else if (ni == 4) code = 10 + 6 * d0 + 2 * d1 + d2;
+    order[oct >> 2] |= (2u * (uint32_t)code) << (7 * (oct & 3));
+  }
+  order[0] |= ((1u << ni) - 1u) << 28;
+  o[0] = make_q4(lo[0], lo[1], lo[2], scale[0]);
+  o[1] = make_q4(u2f(qw[0]), u2f(qw[1]), u2f(qw[2]), u2f(qw[3]));
+  o[2] = make_q4(u2f(qw[4]), u2f(qw[5]), u2f(child_base), u2f(tri_base - (uint32_t)ni));
   o[3] = make_q4(u2f(order[0]), u2f(order[1]), scale[1], scale[2]);
 }
 

@@ -12,7 +12,7 @@ W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (500, 500)
 sc = scenes.interior(1_000_000, seed=7)
 with g.Context(0) as ctx:
     ctx.upload_scene(sc)
-    for what in ("none", "camera", "transform"):
+    for what in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("none", "camera", "transform")):
         ctx.frame_begin(W, H)
         ctx.render(spp=4)
         ctx.sync()

@@ -120,6 +120,7 @@ class Emu:
         L.emu_det_math.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 4
         L.emu_transform_inv_t.argtypes = [C.c_void_p, C.c_void_p]
         L.emu_tri_tests.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.emu_encode_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.emu_seed.restype = C.c_uint32
         L.emu_seed.argtypes = [C.c_uint32] * 4
         self.L = L

@@ -470,6 +470,25 @@ void emu_tri_tests(const float* rays, const float* tris, uint64_t n, float* out_
     out_rot[4 * i + 3] = h1 ? v : 0.0f;
   }
 }
+// The two statements of the 4-wide node encoder (pt_trace.h): encode_node_w4_ref (loops, arrays: the definition) and
+// encode_node_w4 (what the build and the refit run: positions in registers, the insertion sort as compare-exchanges, closed-form
+// order codes).  boxes: n x 4 x {lo.xyz, hi.xyz}; counts: n x {ni, nl}; out: n x 16 words each.
+void emu_encode_nodes(const float* boxes, const int32_t* counts, uint64_t n, uint32_t* out_ref, uint32_t* out_fast) {
+  for (uint64_t i = 0; i < n; ++i) {
+    WideChild wc[4];
+    for (int k = 0; k < 4; ++k) {
+      const float* b = boxes + 24 * i + 6 * k;
+      wc[k].lo = make_q4(b[0], b[1], b[2], 0.0f);
+      wc[k].hi = make_q4(b[3], b[4], b[5], 0.0f);
+    }
+    q4 a[4], c[4];
+    const int ni = counts[2 * i], nl = counts[2 * i + 1];
+    encode_node_w4_ref(a, wc, ni, nl, 1000u + (uint32_t)i, 77u + (uint32_t)i);
+    encode_node_w4(c, wc, ni, nl, 1000u + (uint32_t)i, 77u + (uint32_t)i);
+    std::memcpy(out_ref + 16 * i, a, 64);
+    std::memcpy(out_fast + 16 * i, c, 64);
+  }
+}
 void emu_transform_inv_t(const float* m, float* out) {
   float tr[16];
   transpose4(m, tr);

@@ -191,3 +191,36 @@ def test_leaf_step_triangle_test_equals_the_oracle_statement(emu):
     emu.L.emu_tri_tests(rays.ctypes.data, tris.ctypes.data, n, a.ctypes.data, b.ctypes.data)
     assert a[:, 0].sum() > n // 5  # (the case set does hit)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_node_encoder_forms_agree(emu):
+    """pt_trace.h states the 4-wide node encoder twice: encode_node_w4_ref (loops over the children, arrays indexed by loop
+    variables -- the definition) and encode_node_w4 (what the device build and refit run: child positions in registers, the stable
+    insertion sort of the per-octant keys as six chained compare-exchanges, the order code in closed form, power-of-two divisions
+    as multiplications).  Same record, bit for bit: every child count, boxes of every size from 1e-30 to 1e30, children that
+    coincide (ties in every octant), flat and point-like nodes, huge offsets from the origin."""
+    rng = np.random.RandomState(20250)
+    n = 400_000
+    centre = rng.uniform(-1, 1, (n, 1, 3)) * 10.0 ** rng.uniform(-3, 6, (n, 1, 1))
+    size = 10.0 ** rng.uniform(-30, 30, (n, 1, 1)) * (rng.rand(n, 1, 1) < 0.1) + 10.0 ** rng.uniform(-4, 3, (n, 1, 1)) * 1.0
+    size = np.minimum(size, 1e30)
+    lo = centre + rng.uniform(-1, 1, (n, 4, 3)) * size
+    ext = rng.uniform(0, 1, (n, 4, 3)) * size * (rng.rand(n, 4, 3) > 0.1)  # flat children on some axes
+    hi = lo + ext
+    boxes = np.concatenate([lo, hi], axis=2).astype(np.float32)
+    dup = rng.rand(n) < 0.2  # ties: children 1.. repeat child 0 (or each other)
+    boxes[dup, 1] = boxes[dup, 0]
+    dup2 = rng.rand(n) < 0.1
+    boxes[dup2, 3] = boxes[dup2, 2]
+    snap = rng.rand(n) < 0.1  # centres on a coarse grid: equal keys in some octants only
+    boxes[snap] = np.round(boxes[snap] * 4) / 4
+    boxes[snap, :, 3:] = np.maximum(boxes[snap, :, 3:], boxes[snap, :, :3])
+    cnt = rng.randint(0, 5, n)
+    ni = (rng.rand(n) * (cnt + 1)).astype(np.int32)
+    counts = np.stack([ni, cnt - ni], axis=1).astype(np.int32)
+    boxes, counts = np.ascontiguousarray(boxes), np.ascontiguousarray(counts)
+    a, b = np.zeros((n, 16), np.uint32), np.zeros((n, 16), np.uint32)
+    emu.L.emu_encode_nodes(boxes.ctypes.data, counts.ctypes.data, n, a.ctypes.data, b.ctypes.data)
+    assert len(np.unique(a[:, 12])) > 1000  # (many different order words)
+    bad = np.nonzero((a != b).any(1))[0]
+    assert len(bad) == 0, (len(bad), counts[bad[:5]], boxes[bad[:2]], a[bad[:2]], b[bad[:2]])
