@@ -17,6 +17,7 @@ with g.Context(0) as ctx:
         ctx.render(spp=4)
         ctx.sync()
         tt = np.zeros(3)
+        edits = []
         n = 60
         st0 = ctx.stats()
         t_all = time.time()
@@ -39,9 +40,12 @@ with g.Context(0) as ctx:
             ctx.peek()
             t3 = time.time()
             tt += (t1 - t0, t2 - t1, t3 - t2)
+            edits.append(1e3 * (t1 - t0))
         ctx.sync()
         el = time.time() - t_all
         st = ctx.stats()
         rays = st["extension_rays"] + st["shadow_rays"] - st0["extension_rays"] - st0["shadow_rays"]
-        print("%-9s %dx%d: %7.1f frames/s | per frame: edit %.3f ms, render %.3f ms, peek %.3f ms | %.1f Mrays/s" %
-              (what, W, H, n / el, *(1e3 * tt / n), rays / el / 1e6))
+        print("%-9s %dx%d: %7.1f frames/s | per frame: edit %.3f ms, render %.3f ms, peek %.3f ms | %.1f Mrays/s | updates %d refits %d drains %d, %.1f GB held" %
+              (what, W, H, n / el, *(1e3 * tt / n), rays / el / 1e6, st["scene_updates"], st["scene_refits"], st["scene_drains"], st["device_bytes"] / 1e9))
+        if what == "transform":
+            print("          edit call, ms: first %.2f, median %.3f, max of the rest %.3f" % (edits[0], float(np.median(edits)), max(edits[1:])))

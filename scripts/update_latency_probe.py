@@ -57,7 +57,10 @@ with g.Context(0) as ctx:
             sc.instances = i
             ctx.update_instances(i)
         n = 60 if sc.num_triangles > 100000 else 300
-        print("   a transform every frame   : %7.1f frames/s (re-bake + refit of the tree from the resident meshes each frame; ABI 5 rebuilt it: 29.6 on the 988 k scene)" % loop(ctx, sc, n, inst))
+        print("   a transform every frame   : %7.1f frames/s (re-bake + refit of the tree into the next slot of the geometry ring, the samples in flight finish in theirs; ABI 5 rebuilt the tree: 29.6 on the 988 k scene)" % loop(ctx, sc, n, inst))
+        st = ctx.stats()
+        print("   (edits that changed something %d, refits %d, edits that first let the samples in flight finish %d; %.1f GB held)" %
+              (st["scene_updates"], st["scene_refits"], st["scene_drains"], st["device_bytes"] / 1e9))
         # bare latencies with an idle pipeline
         for what, fn in (("gsp_update_camera", lambda k: ctx.update_camera(moved(sc.to_world, 1000 + k), sc.fov)), ("gsp_update_tables", lambda k: tables(1000 + k)),
                          ("gsp_update_instances", lambda k: inst(k))):
