@@ -1,9 +1,11 @@
 """Randomised GPU-vs-oracle parity: small random scenes with every BSDF type at ordinary and extreme parameters
 (alpha -> 0, ior 1, zero / >1 reflectance, huge k), random transforms (mirrored, sheared scale), several lights,
-random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed] [dormant|nee0|updates]
+random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed] [dormant|nee0|updates|stream]
 `nee0`: gsp_render_params.nee = 0 (RenderParams.nee; the other side of rayhit.rchit's `if (NEE)` branches).
 `updates`: scene seed+1 is reached from scene seed's geometry by gsp_update_* calls where the object lists agree (else a
 fresh upload): exercises the per-frame edit path with random transforms / materials / tables / cameras.
+`stream`: the same edits, but one sample per frame and NO sync between frames (r05: the table and geometry version rings --
+samples of up to a dozen scenes in one launch); the accumulate buffer after 10 frames against the oracle's running mean.
 `dormant`: every scene also gets the dormant-feature extension (tests/textured.py: random uv, random textures on the
 texturable records, a random environment map; every third scene with an sRGB table, one wall removed so paths escape)."""
 import os, sys
@@ -156,6 +158,37 @@ def check_updates(ctx, oracle_mod, seed, W=40, H=28, spp=3):
     return bad == 0, bad, sc.num_triangles
 
 
+STREAM = [0, 0, 0]  # edits that changed something, refits, edits that first let the samples in flight finish
+
+
+def check_stream(ctx, oracle_mod, seed, W=40, H=28, frames=10):
+    """random_scene(seed), then `frames` one-sample frames, each behind a round of random edits (transforms incl. mirrored
+    ones, material assignments, emission, table values, camera), with no sync in between: the samples of every frame finish on
+    the versions of the tables and of the geometry they were generated under."""
+    sc = random_scene(seed)
+    ctx.upload_scene(sc)
+    ctx.frame_begin(W, H)
+    acc = None
+    for k in range(frames):
+        if k:
+            sc, what = mutate(sc, seed * 16 + k)
+            if "instances" in what:
+                ctx.update_instances(sc.instances)
+            if "tables" in what:
+                ctx.update_tables(sc)
+            if "camera" in what:
+                ctx.update_camera(sc.to_world, sc.fov)
+        ctx.render(spp=1, first_timestamp=k)
+        acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+    img = ctx.download().reshape(-1, 4)
+    st = ctx.stats()
+    STREAM[0] += st["scene_updates"]
+    STREAM[1] += st["scene_refits"]
+    STREAM[2] += st["scene_drains"]
+    ndiff = int((~((img == acc) | (np.isnan(img) & np.isnan(acc)))).any(1).sum())
+    return ndiff == 0, ndiff, sc.num_triangles
+
+
 if __name__ == "__main__":
     import gpuspectral_amd as g
     import oracle as O
@@ -168,11 +201,15 @@ if __name__ == "__main__":
         for seed in range(s0, s0 + n):
             if len(sys.argv) > 3 and sys.argv[3] == "updates":
                 ok, ndiff, tris = check_updates(ctx, O, seed)
+            elif len(sys.argv) > 3 and sys.argv[3] == "stream":
+                ok, ndiff, tris = check_stream(ctx, O, seed)
             else:
                 ok, ndiff, tris = check(ctx, O, seed, dormant=dormant, nee=nee)
             if not ok:
                 bad.append((seed, ndiff))
                 print("seed %d: MISMATCH (%d pixels, %d tris)" % (seed, ndiff, tris), flush=True)
+    if STREAM[0]:
+        print("stream: %d edits changed something, %d refits, %d edits first let the samples in flight finish" % tuple(STREAM))
     if INSTANCE_UPDATES[0]:
         print("gsp_update_instances: %d edits, %d refitted the tree, %d rebuilt it" % (INSTANCE_UPDATES[0], INSTANCE_UPDATES[1], INSTANCE_UPDATES[0] - INSTANCE_UPDATES[1]))
     print("%d scenes%s, %d mismatching: %s" % (n, " with the dormant-feature extension" if dormant else (" with nee = 0" if nee == 0 else ""), len(bad), bad))
