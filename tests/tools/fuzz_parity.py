@@ -4,7 +4,7 @@ random cameras.  Usage: python tests/tools/fuzz_parity.py [n_scenes] [first_seed
 `nee0`: gsp_render_params.nee = 0 (RenderParams.nee; the other side of rayhit.rchit's `if (NEE)` branches).
 `updates`: scene seed+1 is reached from scene seed's geometry by gsp_update_* calls where the object lists agree (else a
 fresh upload): exercises the per-frame edit path with random transforms / materials / tables / cameras.
-`stream`: the same edits, but one sample per frame and NO sync between frames (r05: the table and geometry version rings --
+`stream` (+dormant, +lanes2: e.g. `stream+dormant+lanes2`): the same edits, but one sample per frame and NO sync between frames (r05: the table and geometry version rings --
 samples of up to a dozen scenes in one launch); the accumulate buffer after 10 frames against the oracle's running mean.
 `dormant`: every scene also gets the dormant-feature extension (tests/textured.py: random uv, random textures on the
 texturable records, a random environment map; every third scene with an sRGB table, one wall removed so paths escape)."""
@@ -161,11 +161,17 @@ def check_updates(ctx, oracle_mod, seed, W=40, H=28, spp=3):
 STREAM = [0, 0, 0]  # edits that changed something, refits, edits that first let the samples in flight finish
 
 
-def check_stream(ctx, oracle_mod, seed, W=40, H=28, frames=10):
+def check_stream(ctx, oracle_mod, seed, W=40, H=28, frames=10, dormant=False):
     """random_scene(seed), then `frames` one-sample frames, each behind a round of random edits (transforms incl. mirrored
     ones, material assignments, emission, table values, camera), with no sync in between: the samples of every frame finish on
     the versions of the tables and of the geometry they were generated under."""
     sc = random_scene(seed)
+    if dormant:  # textures + environment map: the <TEX, VER> instantiations
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import textured
+
+        sc = textured.decorate(sc, seed=seed, textures=seed % 5 != 0, envmap=seed % 7 != 0,
+                               decode=textured.srgb_table() if seed % 3 == 0 else None)
     ctx.upload_scene(sc)
     ctx.frame_begin(W, H)
     acc = None
@@ -197,12 +203,13 @@ if __name__ == "__main__":
     dormant = len(sys.argv) > 3 and sys.argv[3] == "dormant"
     nee = 0 if len(sys.argv) > 3 and sys.argv[3] == "nee0" else 1
     bad = []
-    with g.Context(0) as ctx:
+    opts = abi.CtxOptions(lanes=2) if len(sys.argv) > 3 and "lanes2" in sys.argv[3] else None
+    with g.Context(0, options=opts) as ctx:
         for seed in range(s0, s0 + n):
             if len(sys.argv) > 3 and sys.argv[3] == "updates":
                 ok, ndiff, tris = check_updates(ctx, O, seed)
-            elif len(sys.argv) > 3 and sys.argv[3] == "stream":
-                ok, ndiff, tris = check_stream(ctx, O, seed)
+            elif len(sys.argv) > 3 and sys.argv[3].startswith("stream"):  # stream | stream+dormant | stream+lanes2 | ...
+                ok, ndiff, tris = check_stream(ctx, O, seed, dormant="dormant" in sys.argv[3])
             else:
                 ok, ndiff, tris = check(ctx, O, seed, dormant=dormant, nee=nee)
             if not ok:
