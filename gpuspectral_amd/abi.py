@@ -163,6 +163,8 @@ class CtxOptions(C.Structure):
         ("reinsert_rounds", C.c_uint32),
         ("gather_route", C.c_uint32),
         ("refit_growth", C.c_double),  # (ABI 6) 0 default (1.25); <= 1: gsp_update_instances always rebuilds
+        ("geometry_versions", C.c_uint32),  # (r05) slots of the geometry ring: 0 default (as many as fit, <= 64), 1 = none
+        ("reserved_", C.c_uint32),
     ]
 
     def __init__(self, **kw):

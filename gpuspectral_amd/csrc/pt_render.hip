@@ -1096,6 +1096,7 @@ void gsp_default_ctx_options(gsp_ctx_options* o) {
   o->reinsert_rounds = 7;        // 6 rounds
   o->gather_route = GSP_GATHER_AUTO;
   o->refit_growth = 1.25;
+  o->geometry_versions = kGeoVersions;
 }
 
 }  // extern "C"
@@ -1117,6 +1118,7 @@ void gsp::gsp_internal_resolve_options(const gsp_ctx_options* in, gsp_ctx_option
   if (c.reinsert_rounds) out->reinsert_rounds = std::min<uint32_t>(c.reinsert_rounds, 65u);
   if (c.gather_route <= GSP_GATHER_COPY) out->gather_route = c.gather_route;
   if (c.refit_growth > 0.0) out->refit_growth = c.refit_growth;  // (<= 1: no refit can stay below it -> always rebuild)
+  if (c.geometry_versions) out->geometry_versions = std::min<uint32_t>(c.geometry_versions, kGeoVersions);
 }
 
 extern "C" {
@@ -1340,8 +1342,8 @@ static int make_geo_ring(gsp_context* ctx) {
   if (stride > kGeoMaxStride || b.num_nodes > stride) return GSP_OK;
   size_t free_b = 0, total_b = 0;
   CTX_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  uint32_t lg = 6;  // log2(kGeoVersions)
-  static_assert(kGeoVersions == 64, "log2");
+  uint32_t lg = 0;  // log2 of the slots: at most what the options allow (default kGeoVersions)
+  while ((2u << lg) <= std::min<uint32_t>(std::max<uint32_t>(ctx->opt.geometry_versions, 1u), kGeoVersions)) ++lg;
   while (lg > 0 && (((uint64_t)stride << lg) * kNodeBytes >= (1ull << 32) || ((uint64_t)stride << lg) * 11 * sizeof(q4) > free_b / 4)) --lg;
   if (lg < 2) return GSP_OK;
   hipStream_t st = ctx->stream;

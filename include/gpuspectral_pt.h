@@ -351,6 +351,11 @@ typedef struct gsp_ctx_options {
   double refit_growth;       /* (ABI 6) gsp_update_instances keeps the tree's topology and only recomputes its boxes while
                                 their summed surface area stays below this multiple of what it was after the last full
                                 build; beyond it the tree is rebuilt.  0 default (1.25); <= 1 = always rebuild             */
+  uint32_t geometry_versions; /* (r05) slots of the geometry ring that lets gsp_update_instances go on while samples are in
+                                flight (176 B of device memory per triangle and slot): 0 default = as many as fit a quarter of
+                                the free memory, at most 64; 1 = no ring: a transform edit first completes the samples queued;
+                                other values are rounded down to a power of two (2 and 3: no ring)                        */
+  uint32_t reserved_;
 } gsp_ctx_options;
 void gsp_default_ctx_options(gsp_ctx_options* o);
 int gsp_ctx_create_ex(int device, const gsp_ctx_options* options, gsp_context** out);

@@ -527,3 +527,40 @@ def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which)
             ctx.render(spp=1, first_timestamp=k)
             acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
         assert np.array_equal(ctx.download().reshape(-1, 4), acc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("versions", [1, 4])
+def test_geometry_versions_option(oracle_mod, cornell, versions):
+    """gsp_ctx_options.geometry_versions bounds the geometry ring (176 B per triangle and slot): 1 = no ring, every transform
+    edit first completes the samples in flight (what r04 did); 4 = a ring that a path of a dozen bounces outlives, so some edits
+    wait and some do not.  Same images either way."""
+    import copy
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi
+
+    sc = copy.deepcopy(cornell)
+    W, H, frames = 48, 40, 24
+    base = sc.instances.copy()
+    acc = None
+    with g.Context(0, options=abi.CtxOptions(geometry_versions=versions)) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        for k in range(frames):
+            inst = base.copy()
+            t = inst["transform"][len(inst) - 1].copy()
+            t[12] += np.float32(0.01 * (k % 7))
+            inst["transform"][len(inst) - 1] = t
+            sc.instances = inst
+            ctx.update_instances(sc.instances)
+            ctx.render(spp=1, first_timestamp=k)
+            acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+        assert np.array_equal(ctx.download().reshape(-1, 4), acc)
+        st = ctx.stats()
+        changed = sum(1 for k in range(frames) if k % 7 != (k - 1) % 7 or k == 0) - (1 if 0 % 7 == 0 else 0)  # frame 0 leaves the transform as uploaded
+        assert st["scene_updates"] == changed, st
+        if versions == 1:
+            assert st["scene_drains"] == changed, st  # (frame 0 was in flight when the first edit came)
+        else:
+            assert 0 < st["scene_drains"] < changed, st
