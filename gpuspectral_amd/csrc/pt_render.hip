@@ -2321,6 +2321,26 @@ int gsp_peek(gsp_context* ctx, float* out, uint32_t* samples_folded) {
   return GSP_OK;
 }
 
+int gsp_peek_to_device(gsp_context* ctx, void* dst, uint64_t bytes, uint32_t* samples_folded) {
+  if (!ctx || !dst || !ctx->have_frame) return GSP_ERR_INVALID;
+  CTX_TRY(ctx, hipSetDevice(ctx->device));
+  if (bytes < ctx->num_pixels * sizeof(q4)) {
+    ctx->err = "destination too small";
+    return GSP_ERR_INVALID;
+  }
+  uint32_t folded = 0xffffffffu;
+  for (uint32_t l = 0; l < ctx->num_lanes; ++l) {  // (as gsp_peek: the folds queued so far finish, the paths in flight stay)
+    gsp_context::Lane& L = ctx->lanes[l];
+    if (L.num_pixels == 0) continue;
+    CTX_TRY(ctx, hipStreamSynchronize(L.stream));
+    folded = std::min(folded, ctx->pipe_active && L.pipe.active ? L.pipe.folded_end : ctx->folded_idle);
+  }
+  CTX_TRY(ctx, hipMemcpyAsync(dst, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToDevice, ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (samples_folded) *samples_folded = folded == 0xffffffffu ? 0u : folded;
+  return GSP_OK;
+}
+
 int gsp_download(gsp_context* ctx, float* out) {
   if (!ctx || !out || !ctx->have_frame) return GSP_ERR_INVALID;
   if (!ctx->subset) return gsp_download_compact(ctx, out);

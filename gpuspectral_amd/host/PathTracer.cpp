@@ -182,6 +182,10 @@ std::vector<float> PathTracer::peek(uint32_t* samplesFolded) {
   return out;
 }
 
+void PathTracer::peekToDevice(void* deviceDst, uint64_t bytes, uint32_t* samplesFolded) {
+  check(gsp_peek_to_device(ctx, deviceDst, bytes, samplesFolded), "gsp_peek_to_device");
+}
+
 gsp_stats PathTracer::stats() {
   gsp_stats s;
   check(gsp_get_stats(ctx, &s), "gsp_get_stats");

@@ -76,6 +76,8 @@ class PathTracer : public RenderPassCreator {
   // The frame as it stands without waiting for paths still in flight (what the reference's blit pass shows every
   // frame, PathTracer.cpp:41-55): compact RGBA32F over the owned pixels; *samplesFolded = timestamps in every pixel.
   std::vector<float> peek(uint32_t* samplesFolded = nullptr);
+  // ... into caller-owned DEVICE memory (>= owned pixels * 16 bytes): the blit's source without a trip through the host
+  void peekToDevice(void* deviceDst, uint64_t bytes, uint32_t* samplesFolded = nullptr);
   void reset();  // timestamp = 0, accumulate buffer cleared
   int getTimestamp() const { return timestamp; }
   gsp_stats stats();

@@ -34,6 +34,7 @@ EXPORTS = (
     "gsp_download_compact",
     "gsp_peek",
     "gsp_copy_accum_to_device",
+    "gsp_peek_to_device",
     "gsp_upload_accum",
     "gsp_get_stats",
     "gsp_reset_stats",
@@ -105,6 +106,7 @@ def load():
     L.gsp_download_compact.argtypes = [vp, vp]
     L.gsp_peek.argtypes = [vp, vp, vp]
     L.gsp_copy_accum_to_device.argtypes = [vp, vp, u64]
+    L.gsp_peek_to_device.argtypes = [vp, vp, u64, C.POINTER(C.c_uint32)]
     L.gsp_upload_accum.argtypes = [vp, vp, u64]
     L.gsp_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.gsp_reset_stats.argtypes = [vp]
@@ -286,6 +288,12 @@ class Context:
 
     def copy_accum_to_device(self, device_ptr, nbytes):
         self._check(self._L.gsp_copy_accum_to_device(self._h, device_ptr, nbytes), "gsp_copy_accum_to_device")
+
+    def peek_to_device(self, device_ptr, nbytes):
+        """gsp_peek into device memory (e.g. a torch tensor's data_ptr()); returns the timestamps folded into every pixel."""
+        folded = C.c_uint32(0)
+        self._check(self._L.gsp_peek_to_device(self._h, device_ptr, nbytes, C.byref(folded)), "gsp_peek_to_device")
+        return int(folded.value)
 
     def upload_accum(self, rgba):
         rgba = np.ascontiguousarray(rgba, np.float32).reshape(-1, 4)

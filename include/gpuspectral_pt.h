@@ -30,7 +30,7 @@
  *   gsp_render
  *        driver.traceRays(pipeline, W, H) once per sample      S/renderer/PathTracer.cpp:24-39,
  *        (raygen.rgen + rayhit.rchit + miss shaders)           S/backend/vulkan/VulkanDriver.cpp:319-347
- *   gsp_download / gsp_download_compact / gsp_peek / gsp_copy_accum_to_device
+ *   gsp_download / gsp_download_compact / gsp_peek / gsp_peek_to_device / gsp_copy_accum_to_device
  *        the RGBA32F accumulateBuffer the blit pass samples    S/renderer/PathTracer.cpp:41-55, raygen.rgen:84-108
  *   gsp_last_error
  *        std::runtime_error thrown by the driver               e.g. S/backend/vulkan/VulkanDevice.cpp:31,58,66
@@ -438,6 +438,11 @@ int gsp_peek(gsp_context* ctx, float* out_rgba, uint32_t* samples_folded);
 /* Device-to-device copy of the compact accumulate buffer into caller-owned
  * device memory (e.g. a tensor handed to an RCCL gather). */
 int gsp_copy_accum_to_device(gsp_context* ctx, void* device_dst, uint64_t bytes);
+/* (r05) gsp_peek into caller-owned DEVICE memory: the compact accumulate buffer as it stands, no wait for the paths in flight,
+ * no trip through host memory -- the reference's blit samples accumulateBuffer on the GPU (S/renderer/PathTracer.cpp:41-55); a
+ * viewer that presents from device memory (an interop texture, a tensor) calls this once per displayed frame.  The copy is
+ * complete when the call returns.  `bytes` >= num_pixels * 16. */
+int gsp_peek_to_device(gsp_context* ctx, void* device_dst, uint64_t bytes, uint32_t* samples_folded);
 /* Overwrite the compact accumulate buffer from host memory (checkpoint/resume:
  * buffer + next timestamp are the whole integrator state). */
 int gsp_upload_accum(gsp_context* ctx, const float* rgba, uint64_t num_pixels);

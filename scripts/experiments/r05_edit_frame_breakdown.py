@@ -1,4 +1,4 @@
-"""Where does a frame with a transform edit spend its time?  500x500, one sample per frame, the 988 k-triangle scene: wall time of
+"""Where does a frame with a transform edit spend its time?  (4th argument `device`: the frame is shown from device memory.)  500x500, one sample per frame, the 988 k-triangle scene: wall time of
 gsp_update_instances / gsp_render / gsp_peek per frame, for a transform edit, a camera edit and no edit.
    python scripts/experiments/r05_edit_frame_breakdown.py"""
 import os, sys, time
@@ -9,6 +9,12 @@ import gpuspectral_amd as g
 from gpuspectral_amd import scenes
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (500, 500)
+DEVICE_PEEK = len(sys.argv) > 4 and sys.argv[4] == "device"  # gsp_peek_to_device instead of gsp_peek
+if DEVICE_PEEK:
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(W * H * 16)) == 0
 sc = scenes.interior(1_000_000, seed=7)
 with g.Context(0) as ctx:
     ctx.upload_scene(sc)
@@ -37,7 +43,10 @@ with g.Context(0) as ctx:
             t1 = time.time()
             ctx.render(spp=1, first_timestamp=4 + f)
             t2 = time.time()
-            ctx.peek()
+            if DEVICE_PEEK:
+                ctx.peek_to_device(dptr.value, W * H * 16)
+            else:
+                ctx.peek()
             t3 = time.time()
             tt += (t1 - t0, t2 - t1, t3 - t2)
             edits.append(1e3 * (t1 - t0))

@@ -810,10 +810,31 @@ def test_peek_shows_a_prefix_of_the_timestamps(oracle_mod, materials_scene):
                 refs[k] = o.render(W, H, spp=k)[0] if k else np.zeros((W * H, 4), np.float32)
             assert np.array_equal(img, refs[k]), "peek after %d calls reports %d timestamps" % (t + 1, k)
         assert seen == sorted(seen)
+        # (r05) the same view into DEVICE memory: gsp_peek_to_device (no wait for the paths in flight, no trip through the host)
+        import ctypes as C
+
+        hip = C.CDLL("libamdhip64.so")
+        dptr = C.c_void_p()
+        nbytes = W * H * 16
+        assert hip.hipMalloc(C.byref(dptr), C.c_size_t(nbytes)) == 0
+        try:
+            c.render(spp=1, first_timestamp=12, timestamps_in_flight=1)
+            kd = c.peek_to_device(dptr.value, nbytes)
+            back = np.zeros((W * H, 4), np.float32)
+            assert hip.hipMemcpy(C.c_void_p(back.ctypes.data), dptr, C.c_size_t(nbytes), 2) == 0  # hipMemcpyDeviceToHost
+            img, k = c.peek()
+            assert k >= kd and 0 <= kd <= 13
+            if kd not in refs:
+                refs[kd] = o.render(W, H, spp=kd)[0]
+            assert np.array_equal(back, refs[kd])
+            with pytest.raises(g.GspError, match="destination too small"):
+                c.peek_to_device(dptr.value, nbytes - 16)
+        finally:
+            hip.hipFree(dptr)
         full = c.download().reshape(-1, 4)
         img, k = c.peek()
-        assert k == 12 and np.array_equal(img, full)
-        assert np.array_equal(full, o.render(W, H, spp=12)[0])
+        assert k == 13 and np.array_equal(img, full)
+        assert np.array_equal(full, o.render(W, H, spp=13)[0])
 
 
 def test_tiny_frames_with_many_samples(ctx, oracle_mod):
