@@ -1373,7 +1373,7 @@ static int make_geo_ring(gsp_context* ctx) {
   (void)hipFree(b.nodes);
   (void)hipFree(b.tri_isect);
   (void)hipFree(b.tri_shade);
-  const size_t freed = std::max<size_t>(b_nodes, kNodeAllocMin) + b_is + b_sh;
+  const size_t freed = b_nodes + b_is + b_sh;  // (as build_bvh counted them)
   b.bytes -= std::min(b.bytes, freed);
   ctx->bytes -= std::min(ctx->bytes, freed);
   b.nodes = nn;
