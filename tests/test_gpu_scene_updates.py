@@ -449,7 +449,7 @@ def test_table_edits_every_frame_without_a_drain(oracle_mod, cornell, materials_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["cornell", "interior"])
+@pytest.mark.parametrize("which", ["cornell", "interior", "cornell-two-lanes"])
 def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which):
     """(r05, VERDICT r04 item 6, second half) gsp_update_instances with samples IN FLIGHT keeps them in flight: the refit goes
     into the next slot of the geometry ring (8 versions of node records, intersection triangles and shading packets), a sample
@@ -463,10 +463,13 @@ def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which)
     import gpuspectral_amd as g
     from gpuspectral_amd import scenes
 
-    if which == "cornell":
+    from gpuspectral_amd import abi
+
+    if which.startswith("cornell"):
         sc, (W, H), frames = copy.deepcopy(cornell), (48, 40), 60
     else:
         sc, (W, H), frames = scenes.interior(20_000), (64, 36), 30
+    options = abi.CtxOptions(lanes=2) if which.endswith("two-lanes") else None  # two pipelines, one ring
     base = sc.instances.copy()
     big = int(np.argmax(base["vertex_count"])) if which == "interior" else len(base) - 1
     emissive = {int(i) for i in np.nonzero(np.asarray(base["emission"]).reshape(len(base), -1)[:, :3].any(1))[0]}
@@ -486,7 +489,7 @@ def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which)
             sc.bsdfs = bs
 
     acc = None
-    with g.Context(0) as ctx:
+    with g.Context(0, options=options) as ctx:
         ctx.upload_scene(sc)
         ctx.frame_begin(W, H)
         for k in range(frames):
