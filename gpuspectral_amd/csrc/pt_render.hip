@@ -322,7 +322,8 @@ constexpr int kShadeWaves = kShadeBlock / 64;
 // TEX: scene with textures / an environment map (dormant-feature extension): a second instantiation, so that the code
 // of the reference's path (TEX = false) is what it was
 // VER: tables of several versions are live (gsp_update_tables while samples were in flight): every vertex reads the version its
-// path carries, from HBM / L2 (no LDS copy: it would have to hold every live version)
+// path carries, from HBM / L2 (no LDS copy: it would have to hold every live version) -- unless the versions in flight differ only
+// in their GEOMETRY (gsp_update_instances): then the one live version of the tables is staged as usual (SceneView::ver_stride == 0)
 template <bool TEX, bool VER>
 __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(SceneView S, RenderConsts rc, const uint32_t* __restrict__ n_ptr, PathQueue cur,
                                                         const q4* __restrict__ hits, PathQueue nxt, ShadowQueue sq,
@@ -335,8 +336,9 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
   // fetches into them (material record after the shading packet, light record after the RNG draw): staged into LDS
   // once per block those become ~64-cycle reads instead of L2 round trips in a kernel whose 4 waves per SIMD cannot
   // hide them.
-  __shared__ uint4 s_tables[VER ? 1 : kShadeTableBytes / 16];
-  if (!VER && S.tables_bytes <= (uint32_t)kShadeTableBytes) {
+  // (VER: only while ONE version of the tables is live -- ver_stride == 0: the versions in flight differ in their geometry)
+  __shared__ uint4 s_tables[kShadeTableBytes / 16];
+  if ((!VER || S.ver_stride == 0u) && S.tables_bytes <= (uint32_t)kShadeTableBytes) {
     const uint4* src = (const uint4*)S.tables;
     for (uint32_t k = threadIdx.x; k < S.tables_bytes / 16; k += kShadeBlock) s_tables[k] = src[k];
     const uint8_t* lb = (const uint8_t*)s_tables;
@@ -967,12 +969,15 @@ struct gsp_context {
   SceneView view(bool versioned = false) const {
     SceneView v;
     const bool ring = versioned && geo_stride != 0;
+    const bool tab_versions = versioned && oldest_live_version() != tab_ver;  // (else: one version of the tables, wherever it sits)
     v.nodes = ring ? ring_nodes.p : bvh.nodes;
     v.tri_isect = ring ? ring_isect.p : bvh.tri_isect;
     v.tri_shade = ring ? ring_shade.p : bvh.tri_shade;
     v.geo = ring ? pack_geo(geo_base, geo_stride, geo_log2) : 0u;
-    const uint8_t* tb = tables.p;  // slot 0: the one live version (versioned == false), or the base the <VER> kernels add their offset to
-    v.ver_stride = versioned ? (uint32_t)tab_slot_bytes : 0u;
+    // slot 0 = the base the <VER> kernels add their offset to, or the slot of the one live version (slot 0 again whenever the
+    // plain kernels run: lane_enqueue moves it there)
+    const uint8_t* tb = tables.p + (versioned && !tab_versions ? (size_t)tab_slot(tab_ver) * tab_slot_bytes : 0);
+    v.ver_stride = tab_versions ? (uint32_t)tab_slot_bytes : 0u;
     v.bsdf.diffuse = (const gsp_diffuse_bsdf*)(tb + table_off[0]);
     v.bsdf.smooth_dielectric = (const gsp_smooth_dielectric_bsdf*)(tb + table_off[1]);
     v.bsdf.smooth_conductor = (const gsp_smooth_conductor_bsdf*)(tb + table_off[2]);
