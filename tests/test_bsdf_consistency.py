@@ -187,3 +187,45 @@ def test_rough_conductor_value_is_the_ggx_microfacet_brdf(orc):
         assert np.allclose(back[:3] * fresnel(float(wo[2])), e[:3] * fresnel(float(wi[2])), rtol=1e-4)  # reciprocal up to F
         checked += 1
     assert checked > 150
+
+
+def test_light_sampling_is_uniform_over_the_emitters_with_the_area_to_solid_angle_pdf(orc):
+    """sampleLight: a light picked uniformly, a point uniform on its triangle (u = 1 - sqrt(e1), v = e2 sqrt(e1): the centroid of the
+    samples is the triangle's), pdf = d^2 / (|cos| A) / numLights, radiance only towards the side the emitter faces -- recomputed here from the
+    geometry in float64."""
+    o, sc = orc
+    tri = np.asarray(sc.lights["positions"], np.float64)[:, :, :3]
+    rad = np.asarray(sc.lights["radiance"], np.float64)[:, :3]
+    nl = len(tri)
+    e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    nrm = np.cross(e1, e2)
+    area = 0.5 * np.linalg.norm(nrm, axis=1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    for pos in (np.array([0.1, 0.6, -0.2]), np.array([-0.7, 1.2, 0.5]), np.array([0.0, 2.5, 0.0])):  # the last one: above the lamp
+        picked = np.zeros(nl, int)
+        centroid = np.zeros((nl, 3))
+        for s in range(6000):
+            r = o.sample_light(pos.astype(np.float32), 100 + s)
+            p = r[:3].astype(np.float64)
+            # which triangle? barycentrics inside [0, 1] and on its plane
+            hit = None
+            for k in range(nl):
+                d = p - tri[k, 0]
+                m = np.array([[e1[k] @ e1[k], e1[k] @ e2[k]], [e1[k] @ e2[k], e2[k] @ e2[k]]])
+                u, v = np.linalg.solve(m, [d @ e1[k], d @ e2[k]])
+                if abs(d @ nrm[k]) < 1e-5 and u > -1e-5 and v > -1e-5 and u + v < 1 + 1e-5:
+                    hit = k
+            assert hit is not None, (pos, p)
+            picked[hit] += 1
+            centroid[hit] += p
+            toward = pos - p
+            dist2 = toward @ toward
+            cos_l = (toward / np.sqrt(dist2)) @ nrm[hit]
+            # one-sided emission (rayhit.rchit:123-153): no radiance when the emitter faces away from the shaded point; the pdf
+            # is the area-to-solid-angle one either way
+            assert np.allclose(r[3:6], rad[hit] if cos_l > 0 else 0.0, rtol=1e-6)
+            want = dist2 / (abs(cos_l) * area[hit]) / nl
+            assert abs(r[6] - want) <= 2e-5 * max(want, 1e-12), (pos, p, r[6], want)
+        assert np.all(np.abs(picked / picked.sum() - 1.0 / nl) < 4 * np.sqrt(0.25 / picked.sum()))
+        for k in range(nl):
+            assert np.allclose(centroid[k] / picked[k], tri[k].mean(0), atol=4 * np.sqrt(area[k] / picked[k]))
