@@ -229,3 +229,57 @@ def test_light_sampling_is_uniform_over_the_emitters_with_the_area_to_solid_angl
         assert np.all(np.abs(picked / picked.sum() - 1.0 / nl) < 4 * np.sqrt(0.25 / picked.sum()))
         for k in range(nl):
             assert np.allclose(centroid[k] / picked[k], tri[k].mean(0), atol=4 * np.sqrt(area[k] / picked[k]))
+
+
+def _fresnel_dielectric(c, no, nt):
+    """Unpolarised Fresnel reflectance of a dielectric interface, cos of the angle on the `no` side (1 beyond the critical angle)."""
+    s2 = (no / nt) ** 2 * (1 - c * c)
+    if s2 >= 1:
+        return 1.0
+    ct = np.sqrt(1 - s2)
+    rs = (no * c - nt * ct) / (no * c + nt * ct)
+    rp = (nt * c - no * ct) / (nt * c + no * ct)
+    return 0.5 * (rs * rs + rp * rp)
+
+
+def test_plastic_values_follow_their_formulas(orc):
+    """Smooth plastic's diffuse lobe and rough plastic's diffuse + GGX-Smith lobes in float64 from the record values: substrate
+    term rho (1 - Fi)(1 - Fo) eta^2 / (pi (1 - rho Ri)), Ri = 1 - eta^2 (1 - (20 pi R0 + 1) / 21) (rayhit.rchit:320-324), Fresnel at
+    the surface normal (smooth) / at the half vector (rough); pdfs as sampled (the rough one with eval's clamp)."""
+    o, sc = orc
+    rng = np.random.RandomState(11)
+    for t in (3, 7):
+        b = sc.bsdfs[t][0]
+        rho = np.asarray(b["diffuse"][:3], np.float64)
+        no, nt, r0 = float(b["ior_out"]), float(b["ior_in"]), float(b["r0"])
+        eta = no / nt
+        ri = 1 - eta * eta * (1 - (np.pi * 20 * r0 + 1) / 21)
+        for _ in range(300):
+            wo = unit([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.1, 1)])
+            wi = unit([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.1, 1)])
+            if t == 7 and rng.rand() < 0.5:  # near the specular peak as well
+                wh = unit([rng.normal(0, 0.05), rng.normal(0, 0.05), 1.0])
+                wi = (2 * np.dot(wo, wh) * wh - wo).astype(np.float32)
+                if wi[2] < 0.1:
+                    continue
+            e = o.bsdf_eval(t << 16, wo, wi)
+            wo64, wi64 = wo.astype(np.float64), wi.astype(np.float64)
+            cos_pdf = max(wi64[2] / np.pi, 1e-6)
+            if t == 3:
+                fi, fo = _fresnel_dielectric(wo64[2], no, nt), _fresnel_dielectric(wi64[2], no, nt)
+                f = rho * (1 - fi) * (1 - fo) * eta * eta / (np.pi * (1 - rho * ri))
+                pdf = (1 - fi) * cos_pdf
+            else:
+                a = float(b["alpha"])
+                wh = (wo64 + wi64) / np.linalg.norm(wo64 + wi64)
+                fi, fo = _fresnel_dielectric(abs(wh @ wo64), no, nt), _fresnel_dielectric(abs(wh @ wi64), no, nt)
+                ch2 = wh[2] ** 2
+                th2 = (wh[0] ** 2 + wh[1] ** 2) / ch2
+                d_ggx = 1.0 / (np.pi * a * a * ch2 * ch2 * (1 + th2 / (a * a)) ** 2)
+                lam = lambda w: 0.5 * (-1 + np.sqrt(1 + a * a * (w[0] ** 2 + w[1] ** 2) / w[2] ** 2))
+                g = 1.0 / (1 + lam(wo64) + lam(wi64))
+                f = rho * (1 - fi) * (1 - fo) * eta * eta / (np.pi * (1 - rho * ri)) + fi * d_ggx * g / (4 * wo64[2] * wi64[2])
+                d_b = np.exp(-th2 / (a * a)) / (np.pi * a * a * ch2 * ch2)
+                pdf = 0.5 * max(d_b * wh[2], 0.01) / (4 * abs(wo64 @ wh)) + 0.5 * cos_pdf
+            assert np.allclose(e[:3], f, rtol=2e-4, atol=1e-7), (t, wo, wi, e[:3], f)
+            assert abs(e[3] - pdf) <= 2e-4 * pdf, (t, wo, wi, e[3], pdf)
