@@ -16,7 +16,9 @@ if DEVICE_PEEK:
     dptr = C.c_void_p()
     assert hip.hipMalloc(C.byref(dptr), C.c_size_t(W * H * 16)) == 0
 sc = scenes.interior(1_000_000, seed=7)
-with g.Context(0) as ctx:
+LANES = int(sys.argv[5]) if len(sys.argv) > 5 else 1  # 5th argument: pipeline lanes of the context (gsp_ctx_options.lanes)
+from gpuspectral_amd import abi
+with g.Context(0, options=abi.CtxOptions(lanes=LANES) if LANES != 1 else None) as ctx:
     ctx.upload_scene(sc)
     for what in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("none", "camera", "transform")):
         ctx.frame_begin(W, H)
