@@ -567,3 +567,47 @@ def test_geometry_versions_option(oracle_mod, cornell, versions):
             assert st["scene_drains"] == changed, st  # (frame 0 was in flight when the first edit came)
         else:
             assert 0 < st["scene_drains"] < changed, st
+
+
+@pytest.mark.gpu
+def test_ring_and_drain_paths_agree_at_scale():
+    """The oracle cannot follow a 200 k-triangle scene at 960x540 for 40 frames -- but the two roads of the library can check each
+    other there: a context with both version rings (no edit waits) against one with `geometry_versions = 1` whose transform edits
+    first complete the samples in flight (r04's behaviour), same sequence of transform + material + light edits, one sample per
+    frame, no sync: the accumulate buffers must be equal bit for bit (millions of paths of up to 40 scene versions in one launch
+    on the first road)."""
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi, scenes
+
+    W, H, frames = 960, 540, 40
+    sc = scenes.interior(200_000, seed=3)
+    base = sc.instances.copy()
+    big = int(np.argmax(base["vertex_count"]))
+    images, drains = [], []
+    for versions in (0, 1):
+        sc.instances = base.copy()
+        bs0 = [b.copy() for b in sc.bsdfs]
+        with g.Context(0, options=abi.CtxOptions(geometry_versions=versions)) as ctx:
+            ctx.upload_scene(sc)
+            ctx.frame_begin(W, H)
+            for k in range(frames):
+                inst = base.copy()
+                for j in (big, (big + 1 + k % 5) % len(inst)):
+                    t = inst["transform"][j].copy()
+                    t[12:15] += np.float32(0.004 * (1 + k % 9)) * np.array([1.0, 0.2, -0.6], np.float32)
+                    inst["transform"][j] = t
+                sc.instances = inst
+                ctx.update_instances(inst)
+                if k % 4 == 1:
+                    bs = [b.copy() for b in bs0]
+                    bs[0]["reflectance"][k % len(bs[0])] = (0.2 + 0.01 * k, 0.5, 0.7 - 0.01 * k)
+                    sc.bsdfs = bs
+                    ctx.update_tables(sc)
+                ctx.render(spp=1, first_timestamp=k)
+            images.append(ctx.download().copy())
+            drains.append(ctx.stats()["scene_drains"])
+        sc.bsdfs = bs0
+    sc.instances = base
+    assert drains[0] == 0 and drains[1] >= frames - 2, drains
+    assert np.array_equal(images[0], images[1]), "%d pixels differ" % int((images[0] != images[1]).any(-1).sum())
+    assert np.isfinite(images[0]).all() and images[0][..., :3].max() > 0
