@@ -232,6 +232,7 @@ class Stats(C.Structure):
         ("scene_refits", C.c_uint64),  # (ABI 6)
         ("shadow_stat_no_triangle", C.c_uint64),  # (ABI 7)
         ("scene_drains", C.c_uint64),  # (ABI 7)
+        ("scene_splits", C.c_uint64),  # (ABI 7)
     ]
 
     def as_dict(self):

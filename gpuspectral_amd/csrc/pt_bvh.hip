@@ -121,7 +121,8 @@ __global__ __launch_bounds__(kBlock) void k_bake(BuildInput in, q4* __restrict__
     const f3 e1 = p1 - p0, e2 = p2 - p0;
     const f3 N = normalize(cross(e1, e2));  // rayhit.rchit:694
     // p0.w: tie-break key of the closest-hit rule (orders like g) + the BSDF type of the hit for the shade sort
-    isect[3ull * o_ + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float((g << 3) | ((I.bsdf >> 16) & 7u)));
+    const uint32_t gid = in.tri_id_first ? in.tri_id_first[a] + (g - in.tri_first[a]) : g;
+    isect[3ull * o_ + 0] = mkq(p0.x, p0.y, p0.z, __uint_as_float((gid << 3) | ((I.bsdf >> 16) & 7u)));
     isect[3ull * o_ + 1] = mkq(p1.x, p1.y, p1.z, 0.0f);
     isect[3ull * o_ + 2] = mkq(p2.x, p2.y, p2.z, 0.0f);
     shade[4ull * o_ + 0] = mkq(N.x, N.y, N.z, __uint_as_float(pack_material(I.bsdf, I.twofaced)));

@@ -55,6 +55,9 @@ struct BuildInput {
   const float* positions;  // device, object space
   const float* normals;    // device
   uint32_t num_tris;
+  const uint32_t* tri_id_first = nullptr;  // device, per instance: the scene-wide index of its first triangle when `instances` is a
+                                           // SUBSET of the scene's (the closest-hit tie-break key must order like the scene's
+                                           // triangle list across both trees of a split scene); nullptr = tri_first
   int reinsert_rounds = -1;  // parallel-reinsertion rounds of the build, < 0 = the default (gsp_ctx_options.reinsert_rounds - 1)
 };
 

@@ -547,6 +547,7 @@ int gsp_multi_get_stats(gsp_multi* m, gsp_stats* total, gsp_stats* per_share) {
       t.shadow_stat_occluded_nodes += s.shadow_stat_occluded_nodes;
       t.shadow_stat_no_triangle += s.shadow_stat_no_triangle;
       t.scene_drains = std::max(t.scene_drains, s.scene_drains);
+      t.scene_splits = std::max(t.scene_splits, s.scene_splits);
       t.algorithmic_bytes += s.algorithmic_bytes;
       t.memoised_rays += s.memoised_rays;
       t.memo_build_rays += s.memo_build_rays;

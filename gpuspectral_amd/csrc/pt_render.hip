@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(RenderConsts rc, uint32_t n
 // ---- extend / connect / test hook: ray sources and result sinks of k_trace -----------------
 struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
   static constexpr float kTmin = 0.0f, kTmax = 1e10f;
-  static constexpr bool kVersioned = false;
+  static constexpr bool kVersioned = false, kSplit = false;
   PathQueue q;
   q4* hits;
   __device__ __forceinline__ void load(uint32_t i, f3& o, f3& d, float& tmin, float& tmax, uint32_t& pay) const {
@@ -182,7 +182,7 @@ struct ExtendIO {  // raygen.rgen:53-58: tmin 0, tmax 1e10, closest hit
 // traced rays (bench.py's Mrays/s leaves them out).
 struct MemoIO {
   static constexpr float kTmin = 0.0f, kTmax = 1e10f;
-  static constexpr bool kVersioned = false;
+  static constexpr bool kVersioned = false, kSplit = false;
   RenderConsts rc;
   const uint32_t* pixel_ids;
   uint32_t lane, lanes;
@@ -203,7 +203,7 @@ struct MemoIO {
 
 struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any hit
   static constexpr float kTmin = 0.01f, kTmax = -1.0f;
-  static constexpr bool kVersioned = false;
+  static constexpr bool kVersioned = false, kSplit = false;
   ShadowQueue sq;
   q4* next_P2;
   q4* next_P3;
@@ -240,26 +240,32 @@ struct ConnectIO {  // rayhit.rchit:737-757: tmin 0.01, tmax Ldist - 0.01, any h
 // pt_stages.h): a path's stamp sits in its flags word; a shadow ray finds it in the flags of the continuing path (S3.w) or, when
 // the path ended at the vertex, in the word that would have named it.  `nodes` / `tris` of the launch are slot 0 of the ring.
 struct GeoRing {
-  uint32_t geo;      // pt_stages.h pack_geo
-  uint32_t top_off;  // node-record byte offset of the newest version
+  uint32_t geo;           // pt_stages.h pack_geo
+  uint32_t top_off;       // node-record byte offset of the tree whose top the blocks stage into LDS
+  uint32_t static_slots;  // split scene: slots of the static tree in front of the ring (0: the ring holds whole trees)
   __device__ __forceinline__ void offsets(uint32_t stamp, uint32_t& node_off, uint32_t& tri_base) const {
-    tri_base = geo_slot_offset(geo, stamp);
+    tri_base = static_slots + geo_slot_offset(geo, stamp);
     node_off = tri_base * kNodeBytes;
   }
 };
 constexpr uint32_t kNoNextBit = 0x80000000u;  // <VER> shadow records: index of the continuing path, or this bit | the geometry stamp
-struct ExtendVerIO : ExtendIO {
-  static constexpr bool kVersioned = true;
+// SPLIT: the ring holds the tree of the edited instances only, the static tree at offset 0 is walked second (pt_wavetrace.h)
+template <bool SPLIT>
+struct ExtendVerIOT : ExtendIO {
+  static constexpr bool kVersioned = true, kSplit = SPLIT;
   GeoRing g;
   __device__ __forceinline__ uint32_t top_offset() const { return g.top_off; }
+  __device__ __forceinline__ uint32_t static_slots() const { return g.static_slots; }
   __device__ __forceinline__ void geometry(uint32_t i, uint32_t, uint32_t& node_off, uint32_t& tri_base) const {
     g.offsets(geo_stamp(((const uint32_t*)&q.P3[i])[3]), node_off, tri_base);
   }
 };
-struct ConnectVerIO : ConnectIO {
-  static constexpr bool kVersioned = true;
+template <bool SPLIT>
+struct ConnectVerIOT : ConnectIO {
+  static constexpr bool kVersioned = true, kSplit = SPLIT;
   GeoRing g;
   __device__ __forceinline__ uint32_t top_offset() const { return g.top_off; }
+  __device__ __forceinline__ uint32_t static_slots() const { return g.static_slots; }
   __device__ __forceinline__ void geometry(uint32_t i, uint32_t pay, uint32_t& node_off, uint32_t& tri_base) const {
     const uint32_t stamp = (pay & kNoNextBit) ? (pay & (kGeoVersions - 1u)) : geo_stamp(((const uint32_t*)&sq.S3[i])[3]);
     g.offsets(stamp, node_off, tri_base);
@@ -268,10 +274,23 @@ struct ConnectVerIO : ConnectIO {
     ConnectIO::store(i, h, aux, (pay & kNoNextBit) ? 0xffffffffu : pay);
   }
 };
+typedef ExtendVerIOT<false> ExtendVerIO;
+typedef ConnectVerIOT<false> ConnectVerIO;
+typedef ExtendVerIOT<true> ExtendSplitIO;
+typedef ConnectVerIOT<true> ConnectSplitIO;
+// the camera rays of the memo and the rays of gsp_trace on a split scene: every ray belongs to the newest version (`stamp`)
+struct MemoSplitIO : MemoIO {
+  static constexpr bool kVersioned = true, kSplit = true;
+  GeoRing g;
+  uint32_t stamp;
+  __device__ __forceinline__ uint32_t top_offset() const { return g.top_off; }
+  __device__ __forceinline__ uint32_t static_slots() const { return g.static_slots; }
+  __device__ __forceinline__ void geometry(uint32_t, uint32_t, uint32_t& node_off, uint32_t& tri_base) const { g.offsets(stamp, node_off, tri_base); }
+};
 
 struct TestIO {  // gsp_trace
   static constexpr float kTmin = -1.0f, kTmax = -1.0f;
-  static constexpr bool kVersioned = false;
+  static constexpr bool kVersioned = false, kSplit = false;
   const float* rays;
   q4* hits;
   const uint32_t* slot_to_global;
@@ -289,6 +308,15 @@ struct TestIO {  // gsp_trace
     if (any_hit) hits[i] = mkq(0.0f, 0.0f, 0.0f, ub(hit ? 0u : 0xffffffffu));
     else hits[i] = hit ? mkq(h.t, h.u, h.v, ub(slot_to_global[h.slot])) : mkq(0.0f, 0.0f, 0.0f, ub(0xffffffffu));
   }
+};
+
+struct TestSplitIO : TestIO {  // gsp_trace on a split scene (slot_to_global is indexed by the slots counted through both trees)
+  static constexpr bool kVersioned = true, kSplit = true;
+  GeoRing g;
+  uint32_t stamp;
+  __device__ __forceinline__ uint32_t top_offset() const { return g.top_off; }
+  __device__ __forceinline__ uint32_t static_slots() const { return g.static_slots; }
+  __device__ __forceinline__ void geometry(uint32_t, uint32_t, uint32_t& node_off, uint32_t& tri_base) const { g.offsets(stamp, node_off, tri_base); }
 };
 
 // ---- shade ----------------------------------------------------------------------
@@ -653,16 +681,33 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
     in.flags = fb(p3.w);
     const uint32_t sid = in.sid;
     q4 res = mkq(p3.x, p3.y, p3.z, 0.0f);  // the sample's sum so far
-    // VER: this path's version of the geometry (constant along the path)
-    const uint32_t goff = VER ? geo_slot_offset(S.geo, geo_stamp(in.flags)) : 0u;
+    // VER: this path's version of the geometry (constant along the path).  Split scene (S.static_slots != 0): the versioned tree
+    // holds the edited instances only and sits behind the static tree, which every version shares: a ray walks both, and the hit
+    // is min (t, tie-break key) of the two -- the closest-hit rule does not care which tree a triangle lives in.
+    const uint32_t goff = VER ? S.static_slots + geo_slot_offset(S.geo, geo_stamp(in.flags)) : 0u;
     const q4* nodes_v = VER ? (const q4*)((const char*)S.nodes + (size_t)goff * kNodeBytes) : S.nodes;
     const q4* isect_v = VER ? S.tri_isect + 3ull * goff : S.tri_isect;
+    const bool split = VER && S.static_slots != 0u;
     for (;;) {
       HitRec h;
       uint32_t aux;
       ++ext;
       stk.top = 0;
-      if (!trace_ray<false>(nodes_v, isect_v, in.o, in.d, 0.0f, 1e10f, h, aux, stk, tab)) {  // miss.rmiss:15-18
+      uint32_t key = 0xffffffffu;
+      bool hit = trace_ray<false>(nodes_v, isect_v, in.o, in.d, 0.0f, 1e10f, h, aux, stk, tab, &key);
+      if (split) {
+        if (hit) h.slot += (int32_t)S.static_slots;  // (slots are counted through both trees, version-free)
+        HitRec h2;
+        uint32_t aux2, key2 = 0xffffffffu;
+        stk.top = 0;
+        if (trace_ray<false>(S.nodes, S.tri_isect, in.o, in.d, 0.0f, 1e10f, h2, aux2, stk, tab, &key2) &&
+            (!hit || h2.t < h.t || (h2.t == h.t && key2 < key))) {
+          h = h2;
+          aux = aux2;
+          hit = true;
+        }
+      }
+      if (!hit) {  // miss.rmiss:15-18
         if (TEX && S.tex.env_texels != nullptr) add_emitted(rc.clamp, miss_emitted(S, in), res);
         break;
       }
@@ -676,7 +721,11 @@ __global__ __launch_bounds__(kBlock) void k_finish(SceneView S, RenderConsts rc,
         uint32_t aux2;
         ++sh;
         stk.top = 0;
-        const bool occluded = trace_ray<true>(nodes_v, isect_v, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2, stk, tab);
+        bool occluded = trace_ray<true>(nodes_v, isect_v, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2, stk, tab);
+        if (split && !occluded) {
+          stk.top = 0;
+          occluded = trace_ray<true>(S.nodes, S.tri_isect, out.shadow.o, out.shadow.d, 0.01f, out.shadow.tmax, hs, aux2, stk, tab);
+        }
         bool nee_done;
         connect_vertex(rc.clamp, out.shadow, occluded, res, nee_done);
         if (nee_done && out.alive) out.next.directWeight = out.shadow.dw_nee;  // rayhit.rchit:785-787
@@ -839,6 +888,22 @@ struct gsp_context {
   uint32_t geo_ver = 0;     // version the next sample is generated under (monotonic); its slot: geo_ver % slots
   uint32_t geo_base = 0;    // slot that stamp 0 stands for
   bool geo_ring_failed = false;  // no memory for it: edits drain, as before
+  // r05: SPLIT scene (gsp_update_instances): the instances the host has edited since the last full build live in a tree of their
+  // own, `dyn`, and only THAT tree goes through the ring; `bvh` holds the instances that never changed, once, in front of the ring
+  // (static_slots triangle slots / 64-B node records): the versions in flight share it, so the working set of a dozen versions is one
+  // large tree + a dozen small ones instead of a dozen large ones (profiles/r05_edit_frame_breakdown.txt).  A ray walks both
+  // (pt_wavetrace.h kSplit); the <VER> kernels run all the time then.
+  bool split = false;
+  bool split_declined = false;  // make_split has said no for this scene: edits go through the ring of whole trees
+  DeviceBvh dyn;
+  uint32_t static_slots = 0;
+  std::vector<uint8_t> inst_dynamic;   // per instance: edited since the last full build
+  std::vector<uint32_t> sub_index[2];  // [0] static, [1] edited: scene index of the subset's instances
+  DevBuf<gsp_instance> d_inst_sub[2];
+  DevBuf<float> d_invt_sub[2];
+  DevBuf<uint32_t> d_first_sub[2], d_idfirst_sub[2];
+  DevBuf<uint32_t> s2g_all;            // slot counted through both trees -> scene triangle index (gsp_trace)
+  bool s2g_all_valid = false;
   uint32_t geo_slots() const { return 1u << geo_log2; }
   uint32_t geo_phys(uint32_t v) const { return v & (geo_slots() - 1u); }
   gsp_camera camera{};
@@ -968,12 +1033,14 @@ struct gsp_context {
   // of the rings + the strides, for the <VER> instantiations
   SceneView view(bool versioned = false) const {
     SceneView v;
+    if (split) versioned = true;  // (a split scene has no array a plain kernel could walk)
     const bool ring = versioned && geo_stride != 0;
     const bool tab_versions = versioned && oldest_live_version() != tab_ver;  // (else: one version of the tables, wherever it sits)
     v.nodes = ring ? ring_nodes.p : bvh.nodes;
     v.tri_isect = ring ? ring_isect.p : bvh.tri_isect;
     v.tri_shade = ring ? ring_shade.p : bvh.tri_shade;
     v.geo = ring ? pack_geo(geo_base, geo_stride, geo_log2) : 0u;
+    v.static_slots = split ? static_slots : 0u;
     // slot 0 = the base the <VER> kernels add their offset to, or the slot of the one live version (slot 0 again whenever the
     // plain kernels run: lane_enqueue moves it there)
     const uint8_t* tb = tables.p + (versioned && !tab_versions ? (size_t)tab_slot(tab_ver) * tab_slot_bytes : 0);
@@ -991,7 +1058,6 @@ struct gsp_context {
     v.tables_bytes = (uint32_t)tables_bytes;
     v.num_lights = num_lights;
     v.inv_num_lights = num_lights ? 1.0f / (float)num_lights : 0.0f;
-    v.root = bvh.root;
     if (textured) {
       v.tex.tri_uv = num_textures ? tri_uv.p : nullptr;
       v.tex.textures = textures.p;
@@ -1029,7 +1095,7 @@ struct gsp_context {
   }
   int ensure_spill() {
     // a descent pushes at most one node group per level of the wide tree (+ sentinel, slack)
-    const uint32_t bound = bvh.depth + 2;
+    const uint32_t bound = std::max(bvh.depth, split ? dyn.depth : 0u) + 2;
     const uint32_t need = (bound > (uint32_t)kLdsStackDepth ? bound - kLdsStackDepth : 1) * kStackWords;
     spill_stride = std::max(max_blocks(false), max_blocks(true)) * kBlock;
     for (uint32_t l = 0; l < num_lanes; ++l) GSP_HIP_TRY(lanes[l].spill.ensure((size_t)need * spill_stride, &bytes));
@@ -1196,6 +1262,7 @@ void gsp_ctx_destroy(gsp_context* ctx) {
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   free_bvh(ctx->bvh);
+  free_bvh(ctx->dyn);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1326,6 +1393,14 @@ static void drop_geo_ring(gsp_context* ctx) {
     ctx->bvh.nodes = ctx->bvh.tri_isect = ctx->bvh.tri_shade = nullptr;
     ctx->bvh.arrays_external = false;
   }
+  if (ctx->split) {  // ... and so were the edited instances' tree's
+    ctx->dyn.nodes = ctx->dyn.tri_isect = ctx->dyn.tri_shade = nullptr;
+    ctx->dyn.arrays_external = false;
+    ctx->bytes -= std::min(ctx->bytes, ctx->dyn.bytes);
+    free_bvh(ctx->dyn);
+    ctx->split = false;
+    ctx->static_slots = 0;
+  }
   for (DevBuf<q4>* b : {&ctx->ring_nodes, &ctx->ring_isect, &ctx->ring_shade}) {
     if (b->p) ctx->bytes -= b->count * sizeof(q4);
     b->release();
@@ -1396,6 +1471,185 @@ static void point_bvh_at(gsp_context* ctx, uint32_t v) {
   ctx->bvh.tri_shade = ctx->ring_shade.p + off * 4;
 }
 
+// ---- split scene -----------------------------------------------------------------------------------------------------------
+// device tables of one subset of ctx->h_inst (which = 0 static / 1 edited) for build_bvh / refit_bvh
+static int upload_subset(gsp_context* ctx, int which, BuildInput& bi) {
+  const std::vector<uint32_t>& idx = ctx->sub_index[which];
+  const uint32_t ni = (uint32_t)idx.size();
+  std::vector<gsp_instance> inst(ni);
+  std::vector<float> inv_t(16ull * ni);
+  std::vector<uint32_t> first(ni + 1ull), idfirst(ni + 1ull);
+  std::vector<uint32_t> scene_first(ctx->h_inst.size() + 1ull);
+  uint32_t acc = 0;
+  for (size_t i = 0; i < ctx->h_inst.size(); ++i) scene_first[i] = acc, acc += ctx->h_inst[i].vertex_count / 3;
+  acc = 0;
+  for (uint32_t k = 0; k < ni; ++k) {
+    inst[k] = ctx->h_inst[idx[k]];
+    float tr[16];
+    transpose4(inst[k].transform, tr);
+    inverse4(tr, &inv_t[16ull * k]);
+    first[k] = acc;
+    idfirst[k] = scene_first[idx[k]];
+    acc += inst[k].vertex_count / 3;
+  }
+  first[ni] = acc;
+  idfirst[ni] = 0;
+  hipStream_t st = ctx->stream;
+  CTX_TRY(ctx, ctx->d_inst_sub[which].upload(inst.data(), ni, st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->d_invt_sub[which].upload(inv_t.data(), inv_t.size(), st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->d_first_sub[which].upload(first.data(), first.size(), st, &ctx->bytes));
+  CTX_TRY(ctx, ctx->d_idfirst_sub[which].upload(idfirst.data(), idfirst.size(), st, &ctx->bytes));
+  CTX_TRY(ctx, hipStreamSynchronize(st));  // (the host vectors go out of scope)
+  bi = BuildInput{};
+  bi.instances = ctx->d_inst_sub[which].p;
+  bi.inv_t = ctx->d_invt_sub[which].p;
+  bi.tri_first = ctx->d_first_sub[which].p;
+  bi.tri_id_first = ctx->d_idfirst_sub[which].p;
+  bi.num_instances = ni;
+  bi.positions = ctx->d_pos.p;
+  bi.normals = ctx->d_nrm.p;
+  bi.num_tris = acc;
+  bi.reinsert_rounds = (int)ctx->opt.reinsert_rounds - 1;
+  return GSP_OK;
+}
+
+// Builds the two trees of a split scene from ctx->h_inst / ctx->inst_dynamic and lays them out: [static tree | ring of the edited
+// instances' tree].  Needs an idle pipeline.  *made = false (and nothing changed) when the scene does not lend itself to a split:
+// textures, nothing or too much edited (more than a quarter of the triangles), no room for at least four versions.
+static int make_split(gsp_context* ctx, bool* made) {
+  *made = false;
+  if (ctx->num_textures != 0 || ctx->opt.refit_growth <= 1.0 || ctx->opt.geometry_versions < 4 || ctx->geo_ring_failed) return GSP_OK;
+  uint64_t tris[2] = {0, 0};
+  ctx->sub_index[0].clear();
+  ctx->sub_index[1].clear();
+  for (size_t i = 0; i < ctx->h_inst.size(); ++i) {
+    const int w = ctx->inst_dynamic[i] ? 1 : 0;
+    ctx->sub_index[w].push_back((uint32_t)i);
+    tris[w] += ctx->h_inst[i].vertex_count / 3;
+  }
+  if (tris[1] == 0 || tris[0] == 0 || tris[1] * 4 > tris[0] + tris[1]) return GSP_OK;
+  hipStream_t st = ctx->stream;
+  BuildInput bi[2];
+  DeviceBvh t[2];
+  for (int w = 0; w < 2; ++w) {
+    int rc = upload_subset(ctx, w, bi[w]);
+    if (rc == GSP_OK) rc = build_bvh(st, bi[w], t[w], ctx->err);
+    if (rc != GSP_OK) {
+      (void)hipStreamSynchronize(st);
+      free_bvh(t[0]);
+      free_bvh(t[1]);
+      return rc;
+    }
+  }
+  CTX_TRY(ctx, hipStreamSynchronize(st));
+  uint64_t slots[2], stride[2];
+  for (int w = 0; w < 2; ++w) {
+    slots[w] = (uint64_t)t[w].num_tris + t[w].first_slot + (kWide - 1);
+    stride[w] = std::max<uint64_t>(slots[w], kNodeAllocMin / kNodeBytes);
+  }
+  size_t free_b = 0, total_b = 0;
+  CTX_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+  uint32_t lg = 0;
+  while ((2u << lg) <= std::min<uint32_t>(ctx->opt.geometry_versions, kGeoVersions)) ++lg;
+  auto total_slots = [&](uint32_t l) { return stride[0] + (stride[1] << l); };
+  while (lg > 0 && (total_slots(lg) * kNodeBytes >= (1ull << 32) || total_slots(lg) >= (1ull << 28) || total_slots(lg) * 11 * sizeof(q4) > free_b / 4)) --lg;
+  if (lg < 2 || stride[1] > kGeoMaxStride || t[0].num_nodes > stride[0] || t[1].num_nodes > stride[1]) {
+    free_bvh(t[0]);
+    free_bvh(t[1]);
+    return GSP_OK;
+  }
+  // from here on the old tree goes away
+  drop_geo_ring(ctx);
+  ctx->bytes -= std::min(ctx->bytes, ctx->bvh.bytes);
+  free_bvh(ctx->bvh);
+  const size_t total = (size_t)total_slots(lg);
+  if (ctx->ring_nodes.ensure(total * kNodeQuads, &ctx->bytes) != hipSuccess || ctx->ring_isect.ensure(total * 3, &ctx->bytes) != hipSuccess ||
+      ctx->ring_shade.ensure(total * 4, &ctx->bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    drop_geo_ring(ctx);
+    free_bvh(t[0]);
+    free_bvh(t[1]);
+    ctx->geo_ring_failed = true;
+    ctx->err = "split scene: no memory for the geometry ring";
+    return GSP_ERR_NOMEM;  // (the caller rebuilds the scene as one tree)
+  }
+  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_nodes.p, 0, total * kNodeQuads * sizeof(q4), st));
+  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_isect.p, 0, total * 3 * sizeof(q4), st));
+  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_shade.p, 0, total * 4 * sizeof(q4), st));
+  const size_t at[2] = {0, (size_t)stride[0]};  // (version 0 of the edited tree sits in slot 0 of the ring)
+  for (int w = 0; w < 2; ++w) {
+    CTX_TRY(ctx, hipMemcpyAsync(ctx->ring_nodes.p + at[w] * kNodeQuads, t[w].nodes, (size_t)t[w].num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, st));
+    CTX_TRY(ctx, hipMemcpyAsync(ctx->ring_isect.p + at[w] * 3, t[w].tri_isect, slots[w] * 3 * sizeof(q4), hipMemcpyDeviceToDevice, st));
+    CTX_TRY(ctx, hipMemcpyAsync(ctx->ring_shade.p + at[w] * 4, t[w].tri_shade, slots[w] * 4 * sizeof(q4), hipMemcpyDeviceToDevice, st));
+  }
+  CTX_TRY(ctx, hipStreamSynchronize(st));
+  ctx->s2g_all_valid = false;  // (gsp_trace makes it when it needs it: a megabyte-sized host loop)
+  for (int w = 0; w < 2; ++w) {
+    const size_t freed = (size_t)t[w].num_nodes * kNodeBytes + slots[w] * 7 * sizeof(q4);
+    (void)hipFree(t[w].nodes);
+    (void)hipFree(t[w].tri_isect);
+    (void)hipFree(t[w].tri_shade);
+    t[w].bytes -= std::min(t[w].bytes, freed);
+    t[w].nodes = ctx->ring_nodes.p + at[w] * kNodeQuads;
+    t[w].tri_isect = ctx->ring_isect.p + at[w] * 3;
+    t[w].tri_shade = ctx->ring_shade.p + at[w] * 4;
+    t[w].arrays_external = true;
+    ctx->bytes += t[w].bytes;
+  }
+  ctx->bvh = std::move(t[0]);
+  ctx->dyn = std::move(t[1]);
+  ctx->split = true;
+  ctx->static_slots = (uint32_t)stride[0];
+  ctx->geo_stride = (uint32_t)stride[1];
+  ctx->geo_log2 = lg;
+  ctx->geo_ver = 0;
+  ctx->geo_base = 0;
+  *made = true;
+  return ctx->ensure_spill();
+}
+// slot counted through both trees -> scene triangle index, for gsp_trace on a split scene (made on first use)
+static int make_split_s2g(gsp_context* ctx) {
+  hipStream_t st = ctx->stream;
+  const DeviceBvh* t[2] = {&ctx->bvh, &ctx->dyn};
+  const size_t at[2] = {0, (size_t)ctx->static_slots};
+  std::vector<uint32_t> all((size_t)ctx->static_slots + ctx->geo_stride, 0xffffffffu);
+  std::vector<uint32_t> scene_first(ctx->h_inst.size() + 1ull);
+  uint32_t acc = 0;
+  for (size_t i = 0; i < ctx->h_inst.size(); ++i) scene_first[i] = acc, acc += ctx->h_inst[i].vertex_count / 3;
+  for (int w = 0; w < 2; ++w) {
+    const uint64_t nslots = (uint64_t)t[w]->num_tris + t[w]->first_slot + (kWide - 1);
+    std::vector<uint32_t> s2g(nslots);
+    CTX_TRY(ctx, hipMemcpyAsync(s2g.data(), t[w]->slot_to_global, nslots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    CTX_TRY(ctx, hipStreamSynchronize(st));
+    const std::vector<uint32_t>& idx = ctx->sub_index[w];
+    std::vector<uint32_t> first(idx.size() + 1), idfirst(idx.size());
+    acc = 0;
+    for (size_t k = 0; k < idx.size(); ++k) {
+      first[k] = acc;
+      idfirst[k] = scene_first[idx[k]];
+      acc += ctx->h_inst[idx[k]].vertex_count / 3;
+    }
+    first[idx.size()] = acc;
+    for (uint64_t sl = t[w]->first_slot; sl < (uint64_t)t[w]->first_slot + t[w]->num_tris; ++sl) {
+      const uint32_t lt = s2g[sl];
+      const size_t k = (size_t)(std::upper_bound(first.begin(), first.end(), lt) - first.begin()) - 1;
+      all[(size_t)(at[w] + sl)] = idfirst[k] + (lt - first[k]);
+    }
+  }
+  CTX_TRY(ctx, ctx->s2g_all.upload(all.data(), all.size(), st, &ctx->bytes));
+  CTX_TRY(ctx, hipStreamSynchronize(st));
+  ctx->s2g_all_valid = true;
+  return GSP_OK;
+}
+
+// the edited instances' tree := its slot of version v
+static void point_dyn_at(gsp_context* ctx, uint32_t v) {
+  const size_t off = (size_t)ctx->static_slots + (size_t)ctx->geo_phys(v) * ctx->geo_stride;
+  ctx->dyn.nodes = ctx->ring_nodes.p + off * kNodeQuads;
+  ctx->dyn.tri_isect = ctx->ring_isect.p + off * 3;
+  ctx->dyn.tri_shade = ctx->ring_shade.p + off * 4;
+}
+
 // instance table (ctx->h_inst) -> device, transformInvT per instance, world-space bake + BVH build from the RESIDENT vertex
 // arrays, per-slot uv gather of a textured scene, traversal spill region
 // refit == true (gsp_update_instances): keep the tree's topology if its boxes stay within gsp_ctx_options.refit_growth of what
@@ -1445,7 +1699,7 @@ static int bake_and_build(gsp_context* ctx, bool refit = false, bool* refitted =
   }
   // a new tree: its arrays are its own again, and whatever is in flight ends on the old ones first (the committed version's:
   // a refit into the next slot of the ring that grew too much is abandoned here)
-  if (ctx->geo_stride) point_bvh_at(ctx, ctx->geo_ver);
+  if (ctx->geo_stride && !ctx->split) point_bvh_at(ctx, ctx->geo_ver);
   if (ctx->pipe_active) {
     ++ctx->stats.scene_drains;
     int rc_ = pipeline_drain(ctx);
@@ -1485,6 +1739,8 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   ctx->have_scene = false;
   for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
   ctx->geo_ring_failed = false;
+  ctx->inst_dynamic.clear();
+  ctx->split_declined = false;
   // ---- validate ----
   if ((sc->num_instances && !sc->instances) || (sc->num_vertices && (!sc->positions || !sc->normals)) ||
       (sc->num_lights && !sc->lights)) {
@@ -1565,6 +1821,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* sc) {
   ctx->stats.scene_updates = 0;
   ctx->stats.scene_refits = 0;
   ctx->stats.scene_drains = 0;
+  ctx->stats.scene_splits = 0;
   ctx->have_scene = true;
   return GSP_OK;
 }
@@ -1617,6 +1874,82 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   rc = check_instances(ctx, instances, num_instances, ctx->num_bsdfs, ctx->num_vertices, nullptr);
   if (rc != GSP_OK) return rc;
   if (num_instances == 0 || std::memcmp(ctx->h_inst.data(), instances, num_instances * sizeof(gsp_instance)) == 0) return GSP_OK;
+  // r05, split scene.  The host that edits while samples are in flight (a viewer) usually moves a few objects of many: the first
+  // such edit -- and every later one that touches an instance not edited before -- builds TWO trees, one over the instances that
+  // have never changed and one over the edited ones (make_split: behind a drain, two builds); from then on an edit of those
+  // instances refits the small tree only, into the next slot of its ring, and the versions in flight share the large one.
+  if (ctx->inst_dynamic.size() != num_instances) ctx->inst_dynamic.assign(num_instances, 0);
+  bool only_edited = ctx->split;
+  for (uint32_t i = 0; i < num_instances; ++i)
+    if (std::memcmp(&instances[i], &ctx->h_inst[i], sizeof(gsp_instance)) != 0 && !ctx->inst_dynamic[i]) only_edited = false;
+  if (ctx->split && only_edited) {
+    const bool in_slot = ctx->pipe_active && ctx->caps_allow_versions() && ctx->geo_ver + 1 - ctx->oldest_live_geo() < ctx->geo_slots();
+    if (!in_slot && ctx->pipe_active) {
+      ++ctx->stats.scene_drains;
+      rc = pipeline_drain(ctx);
+      if (rc != GSP_OK) return rc;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    ctx->have_scene = false;
+    for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
+    ctx->h_inst.assign(instances, instances + num_instances);
+    BuildInput bi;
+    rc = upload_subset(ctx, 1, bi);
+    if (rc != GSP_OK) return rc;
+    if (in_slot) {
+      const q4* from = ctx->dyn.nodes;
+      point_dyn_at(ctx, ctx->geo_ver + 1);
+      CTX_TRY(ctx, hipMemcpyAsync(ctx->dyn.nodes, from, (size_t)ctx->dyn.num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    double growth = 0.0;
+    const size_t held = ctx->dyn.bytes;
+    rc = refit_bvh(ctx->stream, bi, ctx->dyn, &growth, ctx->err);
+    ctx->bytes += ctx->dyn.bytes - held;
+    if (rc != GSP_OK) {
+      (void)hipStreamSynchronize(ctx->stream);
+      point_dyn_at(ctx, ctx->geo_ver);
+      return rc;
+    }
+    if (growth <= ctx->opt.refit_growth) {
+      if (in_slot) ++ctx->geo_ver;
+      ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      ctx->have_scene = true;
+      ++ctx->stats.scene_updates;
+      ++ctx->stats.scene_refits;
+      return GSP_OK;
+    }
+    // the edited tree has degraded: both trees are built again (below), behind a drain
+    point_dyn_at(ctx, ctx->geo_ver);
+  }
+  if (ctx->split || (!ctx->split_declined && ctx->pipe_active && ctx->opt.refit_growth > 1.0 && ctx->opt.geometry_versions >= 4 &&
+                     ctx->num_textures == 0)) {
+    if (ctx->pipe_active) {
+      ++ctx->stats.scene_drains;
+      rc = pipeline_drain(ctx);
+      if (rc != GSP_OK) return rc;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < num_instances; ++i)
+      if (std::memcmp(&instances[i], &ctx->h_inst[i], sizeof(gsp_instance)) != 0) ctx->inst_dynamic[i] = 1;
+    ctx->have_scene = false;
+    for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
+    ctx->h_inst.assign(instances, instances + num_instances);
+    bool made = false;
+    rc = make_split(ctx, &made);
+    if (rc != GSP_OK && rc != GSP_ERR_NOMEM) return rc;
+    if (made) {
+      ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      ctx->have_scene = true;
+      ++ctx->stats.scene_updates;
+      ++ctx->stats.scene_splits;
+      return GSP_OK;
+    }
+    // no split to be had (too much of the scene is being edited, textures, no memory): the scene stays / becomes ONE tree with the
+    // ring of whole trees -- below, with the pipeline idle now -- and the question is not asked again for this scene
+    ctx->split_declined = true;
+    ctx->have_scene = true;
+    (void)t0;
+  }
   // r05: NO DRAIN when the tree has its geometry ring and a slot of it is free: the refit -- re-bake of every packet, node boxes
   // bottom-up in the existing topology -- goes into the NEXT slot, on the context's stream, while the lanes' streams finish the
   // samples in flight in the slots they were generated under (a path carries its slot in its flags word, pt_stages.h); the next
@@ -1629,7 +1962,10 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
     if (ctx->pipe_active) ++ctx->stats.scene_drains;
     rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
-    if (ctx->opt.refit_growth > 1.0) {
+    // (the ring of WHOLE trees only where a split scene is not to be had: an edit that arrives with nothing in flight refits in
+    // place, and the first one that arrives with samples in flight asks for the split first, above)
+    const bool may_split = !ctx->split_declined && ctx->opt.geometry_versions >= 4 && ctx->num_textures == 0;
+    if (ctx->opt.refit_growth > 1.0 && !may_split) {
       rc = make_geo_ring(ctx);
       if (rc != GSP_OK) return rc;
     }
@@ -1841,7 +2177,8 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   // that did not drain: then k_shade / k_finish read every vertex's tables through the version its path carries)
   // ... or to more than one version of the geometry (gsp_update_instances without a drain: then the traversal kernels too take
   // every ray's geometry from the slot its path names)
-  const bool multi_version = ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver;
+  const bool multi_version = ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver ||
+                             ctx->split;  // (a split scene is always walked by the <VER> kernels: there is no whole tree in one place)
   if (!multi_version) ctx->geo_base = ctx->geo_phys(ctx->geo_ver);  // stamp 0 = the one live version (no copy: the kernels get its slot's pointers)
   if (!multi_version && ctx->tab_rot != ctx->tab_ver) {
     // the edits are over and the samples of the older versions have ended: the one live version moves into slot 0 and the
@@ -1855,7 +2192,10 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   const SceneView vview = multi_version ? ctx->view(true) : view;
   const uint32_t gen_ver_bits = (ctx->tab_slot(ctx->tab_ver) << kVerShift) |  // (0 unless an edit is in flight)
                                 (ctx->geo_phys(ctx->geo_ver + ctx->geo_slots() - ctx->geo_base) << kGeoShift);
-  const GeoRing gring{vview.geo, (uint32_t)((size_t)ctx->geo_phys(ctx->geo_ver) * ctx->geo_stride * kNodeBytes)};
+  // (split scene: the static tree's top goes into LDS -- every ray walks it, whatever its version)
+  const GeoRing gring{vview.geo, ctx->split ? 0u : (uint32_t)((size_t)ctx->geo_phys(ctx->geo_ver) * ctx->geo_stride * kNodeBytes),
+                      ctx->split ? ctx->static_slots : 0u};
+  const uint32_t gen_stamp = ctx->geo_phys(ctx->geo_ver + ctx->geo_slots() - ctx->geo_base);
 
   CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
   const bool use_memo = ctx->primary_memo && !stats_mode;
@@ -1864,6 +2204,15 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
     CTX_TRY(ctx, hipMemsetAsync(L.counters.p + C_WORK_EXT, 0, kWorkShards * kWorkStride * sizeof(uint32_t), st));
     const MemoIO io{rcst, ctx->subset ? ctx->pixel_ids.p : nullptr, L.index, ctx->num_lanes, L.memo.p};
     const uint32_t chunk = npix >= (1u << 20) ? kChunkLarge : kChunkSmall;
+    if (ctx->split) {
+      MemoSplitIO sio;
+      static_cast<MemoIO&>(sio) = io;
+      sio.g = gring;
+      sio.stamp = gen_stamp;
+      hipLaunchKernelGGL((k_trace<false, false, MemoSplitIO>), dim3(ctx->trace_grid(npix, chunk)), dim3(kTraceBlock), 0, st, vview.nodes,
+                         vview.tri_isect, (const uint32_t*)nullptr, (uint32_t)npix, 0u, chunk, sio, L.counters.p + C_WORK_EXT, L.spill.p,
+                         ctx->spill_stride, so_ext);
+    } else
     hipLaunchKernelGGL((k_trace<false, false, MemoIO>), dim3(ctx->trace_grid(npix, chunk)), dim3(kTraceBlock), 0, st, view.nodes,
                        view.tri_isect, (const uint32_t*)nullptr, (uint32_t)npix, 0u, chunk, io, L.counters.p + C_WORK_EXT, L.spill.p,
                        ctx->spill_stride, so_ext);
@@ -1874,7 +2223,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   const uint64_t front = use_memo ? P.front : 0;  // (a stats pass traces everything: its counters describe all rays)
   I.front = front;
   if (drain && exact && P.remaining == 0 && n > 0 && n <= ctx->finish_paths && !stats_mode &&
-      ctx->bvh.depth + 2 <= kFinishLevels) {
+      std::max(ctx->bvh.depth, ctx->split ? ctx->dyn.depth : 0u) + 2 <= kFinishLevels) {
     // the caller waits for the image, nothing is left to inject and few paths are alive: every path runs to its end
     // on its own lane (not when gsp_render merely queues work: those paths ride along with the next call's)
     const dim3 fgrid((uint32_t)((n + kBlock - 1) / kBlock));
@@ -1947,7 +2296,12 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       {
         const ExtendIO io{Q[cur], L.hits[cur].p};
         uint32_t* work = L.counters.p + C_WORK_EXT;
-        if (multi_version) {
+        if (ctx->split) {
+          const ExtendSplitIO vio{io, gring};
+          hipLaunchKernelGGL((k_trace<false, false, ExtendSplitIO>), dim3(grid), dim3(kTraceBlock), 0, st, vview.nodes, vview.tri_isect,
+                             (const uint32_t*)(tails_in + T_NEXT), 0u, (uint32_t)front, chunk, vio, work, L.spill.p, ctx->spill_stride,
+                             so_ext);
+        } else if (multi_version) {
           const ExtendVerIO vio{io, gring};
           hipLaunchKernelGGL((k_trace<false, false, ExtendVerIO>), dim3(grid), dim3(kTraceBlock), 0, st, vview.nodes, vview.tri_isect,
                              (const uint32_t*)(tails_in + T_NEXT), 0u, (uint32_t)front, chunk, vio, work, L.spill.p, ctx->spill_stride,
@@ -1985,7 +2339,12 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
         const ConnectIO io{SQ, Q[cur ^ 1].P2, Q[cur ^ 1].P3, L.result.p, rcst.clamp};
         uint32_t* work = L.counters.p + C_WORK_SH;
         const uint32_t grid_any = ctx->trace_grid(std::max<uint64_t>(n, 1), chunk, true);
-        if (multi_version) {
+        if (ctx->split) {
+          const ConnectSplitIO vio{io, gring};
+          hipLaunchKernelGGL((k_trace<true, false, ConnectSplitIO>), dim3(grid_any), dim3(kTraceBlock), 0, st, vview.nodes, vview.tri_isect,
+                             (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, vio, work, L.spill.p,
+                             ctx->spill_stride, so_sh);
+        } else if (multi_version) {
           const ConnectVerIO vio{io, gring};
           hipLaunchKernelGGL((k_trace<true, false, ConnectVerIO>), dim3(grid_any), dim3(kTraceBlock), 0, st, vview.nodes, vview.tri_isect,
                              (const uint32_t*)(tails_out + T_SHADOW), 0u, 0u, chunk, vio, work, L.spill.p,
@@ -2172,7 +2531,25 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     int rc = pipeline_drain(ctx);
     if (rc != GSP_OK) return rc;
   }
+  if (rp->collect_traversal_stats != 0 && ctx->split) {
+    // the statistics instantiations of k_trace walk ONE tree: the queued samples finish, the two trees are built as one again
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ == GSP_OK) {
+      ctx->have_scene = false;
+      rc_ = bake_and_build(ctx);
+      ctx->have_scene = rc_ == GSP_OK;
+      ctx->split_declined = true;  // (a host that asks for statistics gets the scene in one piece from here on)
+    }
+    if (rc_ != GSP_OK) return rc_;
+  }
+  if (rp->collect_traversal_stats != 0 && ctx->pipe_active &&
+      (ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver)) {
+    // the statistics instantiations of k_trace know one version of the scene: samples of older ones finish first
+    int rc_ = pipeline_drain(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   if (!ctx->pipe_active) {
+    if (ctx->split) ctx->geo_base = ctx->geo_phys(ctx->geo_ver);  // (nothing in flight: stamp 0 = the current version again)
     // Streaming path pool, per lane.  Samples enter in batches of Kb timestamps (>= ~1M paths); a new batch
     // is injected whenever the pool has room, so every launch works on millions of paths even though 95 %
     // of a batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
@@ -2242,12 +2619,6 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
       P.active = true;
     }
     ctx->pipe_active = true;
-  }
-  if (rp->collect_traversal_stats != 0 && ctx->pipe_active &&
-      (ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver)) {
-    // the statistics instantiations of k_trace know one version of the scene: samples of older ones finish first
-    int rc_ = pipeline_drain(ctx);
-    if (rc_ != GSP_OK) return rc_;
   }
   ctx->pipe_params = *rp;  // (stats / timing flags may change from call to call)
   if (rp->collect_traversal_stats >= 2) {
@@ -2427,9 +2798,9 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
     ctx->stats.shadow_stat_no_triangle = d.sh_no_tri;
   }
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
-  ctx->stats.num_triangles = ctx->bvh.num_tris;
-  ctx->stats.num_bvh_nodes = ctx->bvh.num_nodes;
-  ctx->stats.bvh_depth = ctx->bvh.depth;
+  ctx->stats.num_triangles = ctx->bvh.num_tris + (ctx->split ? ctx->dyn.num_tris : 0u);  // (a split scene: both trees)
+  ctx->stats.num_bvh_nodes = ctx->bvh.num_nodes + (ctx->split ? ctx->dyn.num_nodes : 0u);
+  ctx->stats.bvh_depth = std::max(ctx->bvh.depth, ctx->split ? ctx->dyn.depth : 0u);
   ctx->stats.device_bytes = ctx->bytes;
   ctx->stats.algorithmic_bytes = 48ull * ctx->stats.stat_rays + (uint64_t)kNodeBytes * ctx->stats.nodes_visited + 48ull * ctx->stats.tris_tested +
                                  32ull * ctx->stats.shadow_stat_rays + 36ull * ctx->stats.shadow_stat_occluded +
@@ -2445,11 +2816,13 @@ int gsp_reset_stats(gsp_context* ctx) {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
-  const uint64_t updates = ctx->stats.scene_updates, refits = ctx->stats.scene_refits, drains = ctx->stats.scene_drains;  // (counts since the last gsp_upload_scene, not since the last reset)
+  const uint64_t updates = ctx->stats.scene_updates, refits = ctx->stats.scene_refits, drains = ctx->stats.scene_drains,
+                 splits = ctx->stats.scene_splits;  // (counts since the last gsp_upload_scene, not since the last reset)
   ctx->stats = gsp_stats{};
   ctx->stats.scene_updates = updates;
   ctx->stats.scene_refits = refits;
   ctx->stats.scene_drains = drains;
+  ctx->stats.scene_splits = splits;
   if (ctx->dstats.p) {
     CTX_TRY(ctx, hipMemsetAsync(ctx->dstats.p, 0, sizeof(DevStats), ctx->stream));
     CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2492,10 +2865,28 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   CTX_TRY(ctx, d_hits.ensure(n, nullptr));
   CTX_TRY(ctx, d_work.ensure(kWorkShards * kWorkStride, nullptr));
   CTX_TRY(ctx, hipMemsetAsync(d_work.p, 0, kWorkShards * kWorkStride * sizeof(uint32_t), ctx->stream));
+  if (ctx->split && !ctx->s2g_all_valid) {
+    int rc_ = make_split_s2g(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   const SceneView view = ctx->view();
-  const TestIO io{d_rays.p, d_hits.p, ctx->bvh.slot_to_global, any_hit, ctx->bvh.num_tris};
+  const TestIO io{d_rays.p, d_hits.p, ctx->split ? ctx->s2g_all.p : ctx->bvh.slot_to_global, any_hit,
+                  ctx->bvh.num_tris + (ctx->split ? ctx->dyn.num_tris : 0u)};
   const TraceStatsOut none{nullptr, nullptr, nullptr};
-  if (any_hit)
+  if (ctx->split) {  // both trees, the newest version of the edited one
+    TestSplitIO sio;
+    static_cast<TestIO&>(sio) = io;
+    sio.g = GeoRing{view.geo, 0u, ctx->static_slots};
+    sio.stamp = ctx->geo_phys(ctx->geo_ver + ctx->geo_slots() - ctx->geo_base);
+    if (any_hit)
+      hipLaunchKernelGGL((k_trace<true, false, TestSplitIO>), dim3(ctx->trace_grid(n, kChunkSmall, true)), dim3(kTraceBlock), 0, ctx->stream,
+                         view.nodes, view.tri_isect, (const uint32_t*)nullptr, (uint32_t)n, 0u, kChunkSmall, sio, d_work.p,
+                         ctx->lanes[0].spill.p, ctx->spill_stride, none);
+    else
+      hipLaunchKernelGGL((k_trace<false, false, TestSplitIO>), dim3(ctx->trace_grid(n, kChunkSmall)), dim3(kTraceBlock), 0, ctx->stream,
+                         view.nodes, view.tri_isect, (const uint32_t*)nullptr, (uint32_t)n, 0u, kChunkSmall, sio, d_work.p,
+                         ctx->lanes[0].spill.p, ctx->spill_stride, none);
+  } else if (any_hit)
     hipLaunchKernelGGL((k_trace<true, false, TestIO>), dim3(ctx->trace_grid(n, kChunkSmall, true)), dim3(kTraceBlock), 0, ctx->stream,
                        view.nodes, view.tri_isect, (const uint32_t*)nullptr, (uint32_t)n, 0u, kChunkSmall, io, d_work.p,
                        ctx->lanes[0].spill.p, ctx->spill_stride, none);

@@ -44,7 +44,8 @@ struct SceneView {
   const gsp_triangle_light* lights;  // baked records (pt_shading.h bake_light), as is the diffuse table (bake_diffuse)
   uint32_t num_lights;
   float inv_num_lights = 0.0f;       // 1.0f / (float)num_lights (rayhit.rchit:151), formed once on the host
-  int32_t root;
+  uint32_t static_slots = 0;        // <VER = true>, split scene: triangle slots (and 64-B node records) of the STATIC tree that sits in front
+                                    // of the geometry ring -- slots below it are the same in every version; 0 = the ring holds whole trees
   uint32_t geo = 0;                 // <VER = true>: geometry ring (below): phys slot that stamp 0 stands for << 29 | triangle slots per version
   const uint8_t* tables = nullptr;  // the BSDF tables + lights back to back (device: one allocation), for LDS staging
   uint32_t tables_bytes = 0;
@@ -163,7 +164,8 @@ GSP_HD void shade_vertex(const SceneView& S, const RenderConsts& rc, const PathS
   const BsdfTables& T = VER ? Tv : S.bsdf;
   const gsp_triangle_light* lights = VER ? lights_v : S.lights;
   GSP_PROF_BEGIN(PR_PACKET);
-  const q4* sp = S.tri_shade + 4ll * ((long long)hit.slot + (VER ? (long long)geo_slot_offset(S.geo, geo_stamp(in.flags)) : 0ll));
+  const q4* sp = S.tri_shade + 4ll * ((long long)hit.slot +
+                                      (VER && (uint32_t)hit.slot >= S.static_slots ? (long long)geo_slot_offset(S.geo, geo_stamp(in.flags)) : 0ll));
   const q4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
   const uint32_t material = f2u(s0.w);                                    // :672 (instance record, baked per triangle)
   const uint32_t bsdf = material & 0x7fffffffu;

@@ -682,7 +682,7 @@ struct StepTableRef {
 // STACK: push(uint32_t) / pop() of 32-bit words; at most one group (one word) per tree level.
 template <bool ANY, class STACK, class TAB>
 GSP_HD bool trace_ray(const q4* __restrict__ nodes, const q4* __restrict__ tris, f3 o, f3 d, float tmin, float tmax, HitRec& h,
-                      uint32_t& aux, STACK& stk, const TAB& tab) {
+                      uint32_t& aux, STACK& stk, const TAB& tab, uint32_t* key_out = nullptr) {
   const RayBox rb = make_raybox(o, d);
   RayShear rs = make_shear(d);
   rs.Sz = comp(rb.inv, rs.kz);  // = 1 / d[kz], the same correctly rounded quotient make_shear computes
@@ -738,6 +738,7 @@ GSP_HD bool trace_ray(const q4* __restrict__ nodes, const q4* __restrict__ tris,
       gs = ngs;
     }
   }
+  if (key_out) *key_out = best_id;  // the tie-break key of the hit: a caller that walks two trees picks min (t, key) of the two
   return h.slot >= 0;
 }
 

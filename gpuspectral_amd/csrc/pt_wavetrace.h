@@ -184,6 +184,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 //                                                  node records from `nodes`, slot offset of its triangles
 //   __device__ uint32_t top_offset() const;        // node_off of the version whose top of the tree the blocks stage into LDS
 //                                                  kVersioned == false: the kernel is what it was before versions existed
+//   static constexpr bool kSplit (versioned sources): the scene is split -- a STATIC tree at offset 0 that every version shares
+//                                                  and, behind it, the ring with the tree of the EDITED instances: geometry()
+//                                                  names the ray's version of that one (node_off != 0), the ray walks it first
+//                                                  and the static tree second, with the same hit record (the closest-hit rule does
+//                                                  not care which tree a triangle lives in; an any-hit ray that was stopped skips
+//                                                  the second walk).  Also  __device__ uint32_t static_slots() const;  -- hit slots
+//                                                  are counted through both trees: static ones first
 // Rays [first, n) of the queue are traced (first > 0: the leading entries carry memoised results, pt_render.hip).
 template <bool ANY, bool STATS, class IO>
 __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_WAVES) void k_trace(const q4* __restrict__ nodes, const q4* __restrict__ tris,
@@ -260,6 +267,20 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
     // batched like the refill: the commit path (for shadow rays: three loads, the firefly test, two stores) is
     // issued for the whole wave, so it waits until enough lanes are out of work (A/B: any-hit kernel -13 % at 32,
     // closest-hit -1.6 % at 24; 40+ starves the wave)
+    if constexpr (IO::kVersioned && IO::kSplit) {
+      // a ray that has finished the tree of the edited instances (node_off != 0) goes on in the static one
+      const bool second = ri != 0xffffffffu && group_empty<ANY>(gs) && tris_empty(tm) && node_off != 0u && !(ANY && h.slot >= 0);
+      if (second) {
+        node_off = 0u;
+        tri_base = 0u;
+        stk.sp = 0;
+        stk.push_group(0u, no_group<ANY>());
+        gb = 0u;
+        gs = root_group<ANY>();
+      } else if (ri != 0xffffffffu && group_empty<ANY>(gs) && tris_empty(tm)) {
+        node_off = 0u;  // (done: an any-hit ray stopped in the first tree must not look unfinished)
+      }
+    }
     {
       const bool pending = ri != 0xffffffffu && group_empty<ANY>(gs) && tris_empty(tm);
       const uint64_t pend_m = __ballot(pending);
@@ -454,9 +475,11 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
         ray_tris += act ? 1u : 0u;
         if (act && so.tri_hist) atomicAdd(so.tri_hist + slot, 1u);
       }
+      uint32_t gslot = slot;  // hit slots of a split scene are counted through both trees
+      if constexpr (IO::kVersioned && IO::kSplit) gslot = slot + (node_off != 0u ? io.static_slots() : 0u);
       if (ANY) {  // the first accepted triangle ends the ray
         h.t = hit ? t : h.t;
-        h.slot = hit ? (int32_t)slot : h.slot;
+        h.slot = hit ? (int32_t)gslot : h.slot;
         gs = hit ? no_group<ANY>() : gs;
         tm = hit ? 0u : tm;
         tm2 = hit ? 0u : tm2;
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
         h.t = better ? t : h.t;
         h.u = better ? u : h.u;
         h.v = better ? v : h.v;
-        h.slot = better ? (int32_t)slot : h.slot;
+        h.slot = better ? (int32_t)gslot : h.slot;
         best_id = better ? id : best_id;
       }
       const bool up = act & tris_empty(tm);  // the second group, if any, moves up

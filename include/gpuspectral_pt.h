@@ -300,6 +300,9 @@ typedef struct gsp_stats {
                                        (the ray's shear constants Sx, Sy were computed for nothing: VERDICT r04 item 7) */
   uint64_t scene_drains;     /* (ABI 7) of scene_updates: calls that first let the samples in flight finish (a test hook: an edited
                                 BSDF record / light / transform does not, once the version rings exist: INTEGRATION.md) */
+  uint64_t scene_splits;     /* (ABI 7) of scene_updates: gsp_update_instances calls that built the scene as TWO trees -- the instances
+                                edited so far and the rest (the first edit that arrives while samples are in flight, and every later
+                                one that touches an instance not edited before); edits of those instances then refit the small tree */
 } gsp_stats;
 
 typedef struct gsp_context gsp_context;

@@ -24,6 +24,17 @@ with g.Context(0, options=abi.CtxOptions(lanes=LANES) if LANES != 1 else None) a
         ctx.frame_begin(W, H)
         ctx.render(spp=4)
         ctx.sync()
+        if what == "transform":  # the first edits of a scene are one-offs (refit in place, then the scene is built as two trees): timed apart
+            for w in range(2):
+                i = sc.instances.copy()
+                t = i["transform"][len(i) - 1].copy()
+                t[13] += np.float32(0.0005)
+                i["transform"][len(i) - 1] = t
+                sc.instances = i
+                t0 = time.time()
+                ctx.update_instances(i)
+                print("          one-off edit %d: %.2f ms" % (w, 1e3 * (time.time() - t0)))
+                ctx.render(spp=1, first_timestamp=1000 + w)
         tt = np.zeros(3)
         edits = []
         n = 60
@@ -57,6 +68,6 @@ with g.Context(0, options=abi.CtxOptions(lanes=LANES) if LANES != 1 else None) a
         st = ctx.stats()
         rays = st["extension_rays"] + st["shadow_rays"] - st0["extension_rays"] - st0["shadow_rays"]
         print("%-9s %dx%d: %7.1f frames/s | per frame: edit %.3f ms, render %.3f ms, peek %.3f ms | %.1f Mrays/s | updates %d refits %d drains %d, %.1f GB held" %
-              (what, W, H, n / el, *(1e3 * tt / n), rays / el / 1e6, st["scene_updates"], st["scene_refits"], st["scene_drains"], st["device_bytes"] / 1e9))
+              (what, W, H, n / el, *(1e3 * tt / n), rays / el / 1e6, st["scene_updates"], st["scene_refits"], st["scene_drains"], st["device_bytes"] / 1e9) + (", splits %d" % st["scene_splits"] if st.get("scene_splits") else ""))
         if what == "transform":
             print("          edit call, ms: first %.2f, median %.3f, max of the rest %.3f" % (edits[0], float(np.median(edits)), max(edits[1:])))

@@ -56,7 +56,7 @@ with g.Context(0) as ctx:
             i["transform"][len(i) - 1] = t
             sc.instances = i
             ctx.update_instances(i)
-        n = 60 if sc.num_triangles > 100000 else 300
+        n = 300  # (r05: an edit of one object refits a small tree: the 988 k scene affords as many frames as Cornell)
         print("   a transform every frame   : %7.1f frames/s (re-bake + refit of the tree into the next slot of the geometry ring, the samples in flight finish in theirs; ABI 5 rebuilt the tree: 29.6 on the 988 k scene)" % loop(ctx, sc, n, inst))
         st = ctx.stats()
         print("   (edits that changed something %d, refits %d, edits that first let the samples in flight finish %d; %.1f GB held)" %

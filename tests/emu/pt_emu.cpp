@@ -227,7 +227,7 @@ struct Emu {
     view.lights = lights.data();
     view.num_lights = sc.num_lights;
     view.inv_num_lights = sc.num_lights ? 1.0f / (float)sc.num_lights : 0.0f;
-    view.root = 0;
+    view.static_slots = 0;
     if (textured) {  // what gsp_context::view() fills
       view.tex.tri_uv = textures.empty() ? nullptr : tri_uv.data();
       view.tex.textures = textures.data();

@@ -501,8 +501,13 @@ def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which)
         img = ctx.download().reshape(-1, 4)
         assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(1).sum())
         st = ctx.stats()
-        assert st["scene_refits"] == frames, st
-        assert st["scene_drains"] == 0, st  # (the first edit makes the ring: nothing was in flight yet); every later one found a free slot
+        # every edit either refitted a tree or -- when it touched an instance no edit had touched before -- built the scene as two
+        # trees (the edited instances / the rest); only those, and one attempt that found too much of the scene edited, waited
+        # (... or, once, went back to one tree when more than a quarter of the scene had become "edited")
+        assert frames - 1 <= st["scene_refits"] + st["scene_splits"] <= frames, st
+        assert st["scene_drains"] <= st["scene_splits"] + 2, st  # (+ the attempt that said no, + the ring of whole trees made after it)
+        if which == "interior":
+            assert 1 <= st["scene_splits"] <= 12, st
         # the edits are over: more samples of the last version, then one edit with nothing but that version in flight
         ctx.render(spp=3, first_timestamp=frames)
         acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=3, first_timestamp=frames, accum=acc)
@@ -515,12 +520,13 @@ def test_transform_edits_every_frame_without_a_drain(oracle_mod, cornell, which)
         # an object leaves the room while samples are in flight: refit abandoned, drain, rebuild -- and back (a new ring)
         ctx.render(spp=1, first_timestamp=frames + 5)
         acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=frames + 5, accum=acc)
-        refits = frames + 1  # (gsp_get_stats would drain: not asked here)
+        before = st["scene_refits"] + 1, st["scene_drains"]
         edit(frames + 3, far=True)
         ctx.update_instances(sc.instances)
         ctx.update_tables(sc)
-        if which == "interior":
-            assert ctx.stats()["scene_refits"] == refits and ctx.stats()["scene_drains"] == 1  # rebuilt, behind a drain
+        if which == "interior":  # the refit is abandoned, the samples in flight finish, the trees are built again
+            st = ctx.stats()
+            assert st["scene_refits"] == before[0] and st["scene_drains"] == before[1] + 1, (st, before)
         ctx.render(spp=1, first_timestamp=frames + 6)
         acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=frames + 6, accum=acc)
         for k in range(frames + 7, frames + 12):
@@ -608,6 +614,66 @@ def test_ring_and_drain_paths_agree_at_scale():
             drains.append(ctx.stats()["scene_drains"])
         sc.bsdfs = bs0
     sc.instances = base
-    assert drains[0] == 0 and drains[1] >= frames - 2, drains
+    assert drains[0] <= 6 and drains[1] >= frames - 2, drains  # (first road: only the edits that touched a new instance waited)
     assert np.array_equal(images[0], images[1]), "%d pixels differ" % int((images[0] != images[1]).any(-1).sum())
     assert np.isfinite(images[0]).all() and images[0][..., :3].max() > 0
+
+
+@pytest.mark.gpu
+def test_split_scene_trace_hook_and_statistics(oracle_mod, materials_scene):
+    """A viewer's edits split the scene into two trees (the edited instances / the rest: `scene_splits`).  gsp_trace on a split scene
+    walks both and reports scene-wide triangle indices, t, u, v equal to the oracle's bit for bit (closest and any hit); a statistics
+    run puts the scene back into one tree; frames stay equal to the oracle's throughout."""
+    import copy
+
+    import gpuspectral_amd as g
+
+    sc = copy.deepcopy(materials_scene)
+    W, H = 64, 48
+    base = sc.instances.copy()
+    small = int(np.argsort(base["vertex_count"])[len(base) // 2])
+    rng = np.random.RandomState(9)
+    lo = np.array([-1.2, 0.0, -1.2], np.float32)
+    hi = np.array([1.2, 2.2, 1.2], np.float32)
+    o_ = (lo + rng.rand(20000, 3).astype(np.float32) * (hi - lo)).astype(np.float32)
+    d_ = rng.normal(size=(20000, 3)).astype(np.float32)
+    d_ /= np.linalg.norm(d_, axis=1, keepdims=True)
+    rays = np.zeros((20000, 8), np.float32)
+    rays[:, :3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o_, 0.0, d_, 1e10
+    acc = None
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        for k in range(6):
+            inst = base.copy()
+            t = inst["transform"][small].copy()
+            t[12:15] += np.float32(0.02 * (k + 1)) * np.array([0.5, 0.1, -0.3], np.float32)
+            inst["transform"][small] = t
+            sc.instances = inst
+            ctx.update_instances(inst)
+            ctx.render(spp=1, first_timestamp=k)
+            acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+            if k == 3:  # with samples in flight
+                o = oracle_mod.Oracle(sc)
+                got, ref = ctx.trace(rays), o.trace(rays)
+                assert (got["prim"] == ref["prim"]).all(), int((got["prim"] != ref["prim"]).sum())
+                hit = ref["prim"] >= 0
+                assert hit.sum() > 5000
+                for f in ("t", "u", "v"):
+                    assert np.array_equal(np.ascontiguousarray(got[f][hit]).view(np.uint32), np.ascontiguousarray(ref[f][hit]).view(np.uint32)), f
+                sh = rays.copy()
+                sh[:, 3], sh[:, 7] = 0.01, rng.uniform(0.05, 3.0, len(sh))
+                assert (ctx.trace(sh, any_hit=True)["prim"] == o.trace(sh, any_hit=True)["prim"]).all()
+        assert np.array_equal(ctx.download().reshape(-1, 4), acc)
+        st = ctx.stats()
+        assert st["scene_splits"] == 1 and st["scene_refits"] == 5 and st["scene_drains"] == 1, st
+        nodes_split = st["num_bvh_nodes"]
+        # a statistics run: one tree again, counters as the oracle's
+        ctx.reset_stats()
+        ctx.frame_begin(W, H)
+        ctx.render(spp=2, collect_traversal_stats=1)
+        st = ctx.stats()
+        ref, so = oracle_mod.Oracle(sc).render(W, H, spp=2)
+        assert np.array_equal(ctx.download().reshape(-1, 4), ref)
+        assert st["extension_rays"] == so["extension_rays"] and st["shadow_rays"] == so["shadow_rays"] and st["stat_rays"] > 0
+        assert st["num_bvh_nodes"] != nodes_split and st["num_triangles"] == sc.num_triangles
