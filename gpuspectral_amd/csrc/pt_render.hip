@@ -1519,6 +1519,7 @@ static int upload_subset(gsp_context* ctx, int which, BuildInput& bi) {
 static int make_split(gsp_context* ctx, bool* made) {
   *made = false;
   if (ctx->num_textures != 0 || ctx->opt.refit_growth <= 1.0 || ctx->opt.geometry_versions < 4 || ctx->geo_ring_failed) return GSP_OK;
+  if (ctx->stats.scene_splits >= 8) return GSP_OK;  // a host that keeps touching new objects: two builds per edit are no bargain
   uint64_t tris[2] = {0, 0};
   ctx->sub_index[0].clear();
   ctx->sub_index[1].clear();

@@ -390,10 +390,14 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
  *                         TLAS; when the boxes have grown past gsp_ctx_options.refit_growth (an object has moved far
  *                         from where the tree was built for) the BVH is rebuilt instead (16 ms).  Images do not
  *                         depend on which of the two happened: the closest-hit rule is independent of the tree.
- *                         The first edit of a tree moves it into a ring of up to 64 versions (176 B per triangle and
- *                         version, at most a quarter of the free device memory); every later refit goes into the next
- *                         slot while the samples in flight finish in theirs.  A rebuild, a ring without a free slot or a
- *                         scene above 8 M triangles first complete the samples already queued.
+ *                         An edit that arrives while samples are in flight (a viewer) builds the scene as TWO trees once --
+ *                         the instances edited so far and the rest (gsp_stats.scene_splits; behind one wait) -- and later
+ *                         edits of those instances refit only their small tree (0.08 ms) into the next slot of a ring of
+ *                         up to 64 versions while the samples in flight finish in theirs.  Scenes that do not split (more
+ *                         than a quarter of the triangles edited, textures, the ninth split) keep a ring of whole refitted
+ *                         trees instead (176 B per triangle and version, at most a quarter of the free device memory).
+ *                         A rebuild, a ring without a free slot or a scene above 8 M triangles first complete the samples
+ *                         already queued; an edit that arrives with nothing in flight refits in place.
  *   gsp_update_tables     the eight BSDF arrays + num_bsdfs and the lights + num_lights of `scene` replace the resident
  *                         ones (all other fields of `scene` are ignored); every resident instance's handle must stay in
  *                         range.  No geometry work.  Textured scenes (dormant-feature extension): has_texture values are

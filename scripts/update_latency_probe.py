@@ -57,10 +57,10 @@ with g.Context(0) as ctx:
             sc.instances = i
             ctx.update_instances(i)
         n = 300  # (r05: an edit of one object refits a small tree: the 988 k scene affords as many frames as Cornell)
-        print("   a transform every frame   : %7.1f frames/s (re-bake + refit of the tree into the next slot of the geometry ring, the samples in flight finish in theirs; ABI 5 rebuilt the tree: 29.6 on the 988 k scene)" % loop(ctx, sc, n, inst))
+        print("   a transform every frame   : %7.1f frames/s (the scene is built as two trees at the second edit, then the edited object's small tree is refitted into the next slot of its ring each frame; Cornell is too small to split: whole trees through the ring; ABI 5 rebuilt the tree: 29.6 on the 988 k scene)" % loop(ctx, sc, n, inst))
         st = ctx.stats()
-        print("   (edits that changed something %d, refits %d, edits that first let the samples in flight finish %d; %.1f GB held)" %
-              (st["scene_updates"], st["scene_refits"], st["scene_drains"], st["device_bytes"] / 1e9))
+        print("   (edits that changed something %d, refits %d, edits that first let the samples in flight finish %d, scene built as two trees %d times; %.1f GB held)" %
+              (st["scene_updates"], st["scene_refits"], st["scene_drains"], st["scene_splits"], st["device_bytes"] / 1e9))
         # bare latencies with an idle pipeline
         for what, fn in (("gsp_update_camera", lambda k: ctx.update_camera(moved(sc.to_world, 1000 + k), sc.fov)), ("gsp_update_tables", lambda k: tables(1000 + k)),
                          ("gsp_update_instances", lambda k: inst(k))):
