@@ -816,6 +816,29 @@ __global__ __launch_bounds__(kBlock) void k_gather_uv(uint32_t num_tris, uint32_
   dst[6] = dst[7] = 0.0f;
 }
 
+// split scene: the triangles of the instances that have moved into the edited instances' tree leave the static one -- their
+// slots become all-zero triangles (det == 0: never hit, like the padding slots); the boxes above them stay as they were
+__global__ __launch_bounds__(kBlock) void k_retire_triangles(uint32_t num_tris, uint32_t first_slot, const uint32_t* __restrict__ slot_to_global,
+                                                             const uint32_t* __restrict__ tri_first, uint32_t num_instances,
+                                                             const uint8_t* __restrict__ retired, q4* __restrict__ isect) {
+  uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= num_tris) return;
+  s += first_slot;
+  const uint32_t g = slot_to_global[s];
+  uint32_t lo = 0, hi = num_instances;  // last instance with tri_first <= g
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) / 2;
+    if (tri_first[mid] <= g) lo = mid;
+    else hi = mid;
+  }
+  if (retired[lo]) {
+    const q4 z = mkq(0.0f, 0.0f, 0.0f, 0.0f);
+    isect[3ull * s + 0] = z;
+    isect[3ull * s + 1] = z;
+    isect[3ull * s + 2] = z;
+  }
+}
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -902,6 +925,7 @@ struct gsp_context {
   DevBuf<gsp_instance> d_inst_sub[2];
   DevBuf<float> d_invt_sub[2];
   DevBuf<uint32_t> d_first_sub[2], d_idfirst_sub[2];
+  DevBuf<uint8_t> d_retired;           // per instance: its triangles have left the static tree
   DevBuf<uint32_t> s2g_all;            // slot counted through both trees -> scene triangle index (gsp_trace)
   bool s2g_all_valid = false;
   uint32_t geo_slots() const { return 1u << geo_log2; }
@@ -1513,13 +1537,19 @@ static int upload_subset(gsp_context* ctx, int which, BuildInput& bi) {
   return GSP_OK;
 }
 
-// Builds the two trees of a split scene from ctx->h_inst / ctx->inst_dynamic and lays them out: [static tree | ring of the edited
-// instances' tree].  Needs an idle pipeline.  *made = false (and nothing changed) when the scene does not lend itself to a split:
-// textures, nothing or too much edited (more than a quarter of the triangles), no room for at least four versions.
+// Makes (or re-makes, when an edit touches an instance not edited before) the two trees of a split scene and lays them out:
+// [static tree | ring of the edited instances' tree].  The static tree IS the tree of the whole scene as it stands, minus the
+// triangles of the edited instances (k_retire_triangles: their slots become all-zero triangles; the boxes above them keep what
+// they enclosed): nothing is rebuilt but the small tree.  Needs an idle pipeline.  *made = false (and nothing changed) when the
+// scene does not lend itself to a split: textures, nothing or too much edited (more than a quarter of the triangles), no room for
+// at least four versions.
 static int make_split(gsp_context* ctx, bool* made) {
   *made = false;
   if (ctx->num_textures != 0 || ctx->opt.refit_growth <= 1.0 || ctx->opt.geometry_versions < 4 || ctx->geo_ring_failed) return GSP_OK;
-  if (ctx->stats.scene_splits >= 8) return GSP_OK;  // a host that keeps touching new objects: two builds per edit are no bargain
+  if (ctx->geo_stride != 0 && !ctx->split) return GSP_OK;  // (the scene lives in a ring of whole trees already)
+  if (ctx->stats.scene_splits >= 16) return GSP_OK;        // a host that keeps touching new objects: a wait per edit is no bargain
+  DeviceBvh& S = ctx->bvh;
+  if (!S.nodes || S.num_tris != ctx->total_tris || ctx->total_tris == 0) return GSP_OK;  // (the tree of the WHOLE scene: first split or a re-split)
   uint64_t tris[2] = {0, 0};
   ctx->sub_index[0].clear();
   ctx->sub_index[1].clear();
@@ -1530,99 +1560,129 @@ static int make_split(gsp_context* ctx, bool* made) {
   }
   if (tris[1] == 0 || tris[0] == 0 || tris[1] * 4 > tris[0] + tris[1]) return GSP_OK;
   hipStream_t st = ctx->stream;
-  BuildInput bi[2];
-  DeviceBvh t[2];
-  for (int w = 0; w < 2; ++w) {
-    int rc = upload_subset(ctx, w, bi[w]);
-    if (rc == GSP_OK) rc = build_bvh(st, bi[w], t[w], ctx->err);
-    if (rc != GSP_OK) {
-      (void)hipStreamSynchronize(st);
-      free_bvh(t[0]);
-      free_bvh(t[1]);
-      return rc;
-    }
+  // ---- the edited instances' tree ----
+  BuildInput bi;
+  DeviceBvh D;
+  int rc = upload_subset(ctx, 1, bi);
+  if (rc == GSP_OK) rc = build_bvh(st, bi, D, ctx->err);
+  if (rc != GSP_OK) {
+    (void)hipStreamSynchronize(st);
+    free_bvh(D);
+    return rc;
   }
   CTX_TRY(ctx, hipStreamSynchronize(st));
-  uint64_t slots[2], stride[2];
-  for (int w = 0; w < 2; ++w) {
-    slots[w] = (uint64_t)t[w].num_tris + t[w].first_slot + (kWide - 1);
-    stride[w] = std::max<uint64_t>(slots[w], kNodeAllocMin / kNodeBytes);
-  }
+  const uint64_t slots_s = (uint64_t)S.num_tris + S.first_slot + (kWide - 1), slots_d = (uint64_t)D.num_tris + D.first_slot + (kWide - 1);
+  const uint64_t stride_s = std::max<uint64_t>(slots_s, kNodeAllocMin / kNodeBytes), stride_d = std::max<uint64_t>(slots_d, kNodeAllocMin / kNodeBytes);
   size_t free_b = 0, total_b = 0;
   CTX_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
   uint32_t lg = 0;
   while ((2u << lg) <= std::min<uint32_t>(ctx->opt.geometry_versions, kGeoVersions)) ++lg;
-  auto total_slots = [&](uint32_t l) { return stride[0] + (stride[1] << l); };
+  auto total_slots = [&](uint32_t l) { return stride_s + (stride_d << l); };
   while (lg > 0 && (total_slots(lg) * kNodeBytes >= (1ull << 32) || total_slots(lg) >= (1ull << 28) || total_slots(lg) * 11 * sizeof(q4) > free_b / 4)) --lg;
-  if (lg < 2 || stride[1] > kGeoMaxStride || t[0].num_nodes > stride[0] || t[1].num_nodes > stride[1]) {
-    free_bvh(t[0]);
-    free_bvh(t[1]);
+  if (lg < 2 || stride_d > kGeoMaxStride || S.num_nodes > stride_s || D.num_nodes > stride_d) {
+    free_bvh(D);
     return GSP_OK;
   }
-  // from here on the old tree goes away
-  drop_geo_ring(ctx);
-  ctx->bytes -= std::min(ctx->bytes, ctx->bvh.bytes);
-  free_bvh(ctx->bvh);
+  // ---- the new layout: [static | ring]; the static tree's arrays are copied into it, wherever they were ----
   const size_t total = (size_t)total_slots(lg);
-  if (ctx->ring_nodes.ensure(total * kNodeQuads, &ctx->bytes) != hipSuccess || ctx->ring_isect.ensure(total * 3, &ctx->bytes) != hipSuccess ||
-      ctx->ring_shade.ensure(total * 4, &ctx->bytes) != hipSuccess) {
+  DevBuf<q4> nn, ni, ns;
+  if (nn.ensure(total * kNodeQuads, nullptr) != hipSuccess || ni.ensure(total * 3, nullptr) != hipSuccess || ns.ensure(total * 4, nullptr) != hipSuccess) {
     (void)hipGetLastError();
-    drop_geo_ring(ctx);
-    free_bvh(t[0]);
-    free_bvh(t[1]);
+    free_bvh(D);
     ctx->geo_ring_failed = true;
-    ctx->err = "split scene: no memory for the geometry ring";
-    return GSP_ERR_NOMEM;  // (the caller rebuilds the scene as one tree)
+    return GSP_OK;  // (nothing has changed: the scene stays one tree)
   }
-  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_nodes.p, 0, total * kNodeQuads * sizeof(q4), st));
-  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_isect.p, 0, total * 3 * sizeof(q4), st));
-  CTX_TRY(ctx, hipMemsetAsync(ctx->ring_shade.p, 0, total * 4 * sizeof(q4), st));
-  const size_t at[2] = {0, (size_t)stride[0]};  // (version 0 of the edited tree sits in slot 0 of the ring)
-  for (int w = 0; w < 2; ++w) {
-    CTX_TRY(ctx, hipMemcpyAsync(ctx->ring_nodes.p + at[w] * kNodeQuads, t[w].nodes, (size_t)t[w].num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, st));
-    CTX_TRY(ctx, hipMemcpyAsync(ctx->ring_isect.p + at[w] * 3, t[w].tri_isect, slots[w] * 3 * sizeof(q4), hipMemcpyDeviceToDevice, st));
-    CTX_TRY(ctx, hipMemcpyAsync(ctx->ring_shade.p + at[w] * 4, t[w].tri_shade, slots[w] * 4 * sizeof(q4), hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemsetAsync(nn.p, 0, total * kNodeQuads * sizeof(q4), st));
+  CTX_TRY(ctx, hipMemsetAsync(ni.p, 0, total * 3 * sizeof(q4), st));
+  CTX_TRY(ctx, hipMemsetAsync(ns.p, 0, total * 4 * sizeof(q4), st));
+  CTX_TRY(ctx, hipMemcpyAsync(nn.p, S.nodes, (size_t)S.num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemcpyAsync(ni.p, S.tri_isect, slots_s * 3 * sizeof(q4), hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemcpyAsync(ns.p, S.tri_shade, slots_s * 4 * sizeof(q4), hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemcpyAsync(nn.p + stride_s * kNodeQuads, D.nodes, (size_t)D.num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemcpyAsync(ni.p + stride_s * 3, D.tri_isect, slots_d * 3 * sizeof(q4), hipMemcpyDeviceToDevice, st));
+  CTX_TRY(ctx, hipMemcpyAsync(ns.p + stride_s * 4, D.tri_shade, slots_d * 4 * sizeof(q4), hipMemcpyDeviceToDevice, st));
+  // the edited instances' triangles leave the static tree
+  {
+    std::vector<uint32_t> first(ctx->h_inst.size() + 1ull);
+    uint32_t acc = 0;
+    for (size_t i = 0; i < ctx->h_inst.size(); ++i) first[i] = acc, acc += ctx->h_inst[i].vertex_count / 3;
+    first[ctx->h_inst.size()] = acc;
+    CTX_TRY(ctx, ctx->d_first.upload(first.data(), first.size(), st, &ctx->bytes));
+    CTX_TRY(ctx, ctx->d_retired.upload(ctx->inst_dynamic.data(), ctx->inst_dynamic.size(), st, &ctx->bytes));
+    hipLaunchKernelGGL(k_retire_triangles, dim3((uint32_t)((S.num_tris + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, S.num_tris, S.first_slot,
+                       (const uint32_t*)S.slot_to_global, (const uint32_t*)ctx->d_first.p, (uint32_t)ctx->h_inst.size(),
+                       (const uint8_t*)ctx->d_retired.p, ni.p);
+    CTX_TRY(ctx, hipGetLastError());
   }
   CTX_TRY(ctx, hipStreamSynchronize(st));
-  ctx->s2g_all_valid = false;  // (gsp_trace makes it when it needs it: a megabyte-sized host loop)
-  for (int w = 0; w < 2; ++w) {
-    const size_t freed = (size_t)t[w].num_nodes * kNodeBytes + slots[w] * 7 * sizeof(q4);
-    (void)hipFree(t[w].nodes);
-    (void)hipFree(t[w].tri_isect);
-    (void)hipFree(t[w].tri_shade);
-    t[w].bytes -= std::min(t[w].bytes, freed);
-    t[w].nodes = ctx->ring_nodes.p + at[w] * kNodeQuads;
-    t[w].tri_isect = ctx->ring_isect.p + at[w] * 3;
-    t[w].tri_shade = ctx->ring_shade.p + at[w] * 4;
-    t[w].arrays_external = true;
-    ctx->bytes += t[w].bytes;
+  // ---- swap the new arrays in ----
+  if (ctx->split) {  // a re-split: the old edited tree goes
+    ctx->dyn.nodes = ctx->dyn.tri_isect = ctx->dyn.tri_shade = nullptr;
+    ctx->dyn.arrays_external = false;
+    ctx->bytes -= std::min(ctx->bytes, ctx->dyn.bytes);
+    free_bvh(ctx->dyn);
   }
-  ctx->bvh = std::move(t[0]);
-  ctx->dyn = std::move(t[1]);
+  if (!S.arrays_external) {  // the first split: the tree owned its arrays
+    const size_t freed = (size_t)S.num_nodes * kNodeBytes + slots_s * 7 * sizeof(q4);
+    (void)hipFree(S.nodes);
+    (void)hipFree(S.tri_isect);
+    (void)hipFree(S.tri_shade);
+    S.bytes -= std::min(S.bytes, freed);
+    ctx->bytes -= std::min(ctx->bytes, freed);
+  }
+  for (DevBuf<q4>* old : {&ctx->ring_nodes, &ctx->ring_isect, &ctx->ring_shade})
+    if (old->p) ctx->bytes -= std::min(ctx->bytes, old->count * sizeof(q4));
+  std::swap(ctx->ring_nodes.p, nn.p), std::swap(ctx->ring_nodes.count, nn.count);  // (nn, ni, ns release the old arrays on return)
+  std::swap(ctx->ring_isect.p, ni.p), std::swap(ctx->ring_isect.count, ni.count);
+  std::swap(ctx->ring_shade.p, ns.p), std::swap(ctx->ring_shade.count, ns.count);
+  ctx->bytes += (ctx->ring_nodes.count + ctx->ring_isect.count + ctx->ring_shade.count) * sizeof(q4);
+  S.nodes = ctx->ring_nodes.p;
+  S.tri_isect = ctx->ring_isect.p;
+  S.tri_shade = ctx->ring_shade.p;
+  S.arrays_external = true;
+  {
+    const size_t freed = (size_t)D.num_nodes * kNodeBytes + slots_d * 7 * sizeof(q4);
+    (void)hipFree(D.nodes);
+    (void)hipFree(D.tri_isect);
+    (void)hipFree(D.tri_shade);
+    D.bytes -= std::min(D.bytes, freed);
+    D.nodes = ctx->ring_nodes.p + stride_s * kNodeQuads;
+    D.tri_isect = ctx->ring_isect.p + stride_s * 3;
+    D.tri_shade = ctx->ring_shade.p + stride_s * 4;
+    D.arrays_external = true;
+    ctx->bytes += D.bytes;
+  }
+  ctx->dyn = std::move(D);
   ctx->split = true;
-  ctx->static_slots = (uint32_t)stride[0];
-  ctx->geo_stride = (uint32_t)stride[1];
+  ctx->static_slots = (uint32_t)stride_s;
+  ctx->geo_stride = (uint32_t)stride_d;
   ctx->geo_log2 = lg;
   ctx->geo_ver = 0;
   ctx->geo_base = 0;
+  ctx->s2g_all_valid = false;  // (gsp_trace makes it when it needs it)
   *made = true;
   return ctx->ensure_spill();
 }
+
 // slot counted through both trees -> scene triangle index, for gsp_trace on a split scene (made on first use)
 static int make_split_s2g(gsp_context* ctx) {
   hipStream_t st = ctx->stream;
-  const DeviceBvh* t[2] = {&ctx->bvh, &ctx->dyn};
-  const size_t at[2] = {0, (size_t)ctx->static_slots};
   std::vector<uint32_t> all((size_t)ctx->static_slots + ctx->geo_stride, 0xffffffffu);
-  std::vector<uint32_t> scene_first(ctx->h_inst.size() + 1ull);
-  uint32_t acc = 0;
-  for (size_t i = 0; i < ctx->h_inst.size(); ++i) scene_first[i] = acc, acc += ctx->h_inst[i].vertex_count / 3;
-  for (int w = 0; w < 2; ++w) {
-    const uint64_t nslots = (uint64_t)t[w]->num_tris + t[w]->first_slot + (kWide - 1);
-    std::vector<uint32_t> s2g(nslots);
-    CTX_TRY(ctx, hipMemcpyAsync(s2g.data(), t[w]->slot_to_global, nslots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  {  // the static tree is the tree of the whole scene: its slots name scene triangles already
+    const uint64_t nslots = (uint64_t)ctx->bvh.num_tris + ctx->bvh.first_slot + (kWide - 1);
+    CTX_TRY(ctx, hipMemcpyAsync(all.data(), ctx->bvh.slot_to_global, nslots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     CTX_TRY(ctx, hipStreamSynchronize(st));
-    const std::vector<uint32_t>& idx = ctx->sub_index[w];
+  }
+  {  // the edited instances' tree counts the triangles of ITS instance list
+    const DeviceBvh& D = ctx->dyn;
+    const uint64_t nslots = (uint64_t)D.num_tris + D.first_slot + (kWide - 1);
+    std::vector<uint32_t> s2g(nslots);
+    CTX_TRY(ctx, hipMemcpyAsync(s2g.data(), D.slot_to_global, nslots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    CTX_TRY(ctx, hipStreamSynchronize(st));
+    std::vector<uint32_t> scene_first(ctx->h_inst.size() + 1ull);
+    uint32_t acc = 0;
+    for (size_t i = 0; i < ctx->h_inst.size(); ++i) scene_first[i] = acc, acc += ctx->h_inst[i].vertex_count / 3;
+    const std::vector<uint32_t>& idx = ctx->sub_index[1];
     std::vector<uint32_t> first(idx.size() + 1), idfirst(idx.size());
     acc = 0;
     for (size_t k = 0; k < idx.size(); ++k) {
@@ -1631,10 +1691,10 @@ static int make_split_s2g(gsp_context* ctx) {
       acc += ctx->h_inst[idx[k]].vertex_count / 3;
     }
     first[idx.size()] = acc;
-    for (uint64_t sl = t[w]->first_slot; sl < (uint64_t)t[w]->first_slot + t[w]->num_tris; ++sl) {
+    for (uint64_t sl = D.first_slot; sl < (uint64_t)D.first_slot + D.num_tris; ++sl) {
       const uint32_t lt = s2g[sl];
       const size_t k = (size_t)(std::upper_bound(first.begin(), first.end(), lt) - first.begin()) - 1;
-      all[(size_t)(at[w] + sl)] = idfirst[k] + (lt - first[k]);
+      all[(size_t)ctx->static_slots + sl] = idfirst[k] + (lt - first[k]);
     }
   }
   CTX_TRY(ctx, ctx->s2g_all.upload(all.data(), all.size(), st, &ctx->bytes));
@@ -1684,7 +1744,7 @@ static int bake_and_build(gsp_context* ctx, bool refit = false, bool* refitted =
   bi.normals = ctx->d_nrm.p;
   bi.num_tris = (uint32_t)ctx->total_tris;
   bi.reinsert_rounds = (int)ctx->opt.reinsert_rounds - 1;
-  if (refit && ctx->opt.refit_growth > 1.0 && ctx->bvh.nodes && ctx->bvh.num_tris == bi.num_tris && bi.num_tris > 0) {
+  if (refit && !ctx->split && ctx->opt.refit_growth > 1.0 && ctx->bvh.nodes && ctx->bvh.num_tris == bi.num_tris && bi.num_tris > 0) {  // (a split scene goes back to one tree by a build)
     double growth = 0.0;
     const size_t held = ctx->bvh.bytes;
     int rc = refit_bvh(st, bi, ctx->bvh, &growth, ctx->err);  // (synchronises the stream)
@@ -2799,7 +2859,7 @@ int gsp_get_stats(gsp_context* ctx, gsp_stats* out) {
     ctx->stats.shadow_stat_no_triangle = d.sh_no_tri;
   }
   ctx->stats.bvh_build_ms = ctx->bvh_build_ms;
-  ctx->stats.num_triangles = ctx->bvh.num_tris + (ctx->split ? ctx->dyn.num_tris : 0u);  // (a split scene: both trees)
+  ctx->stats.num_triangles = ctx->bvh.num_tris;  // (a split scene: the static tree keeps a slot for every triangle of the scene)
   ctx->stats.num_bvh_nodes = ctx->bvh.num_nodes + (ctx->split ? ctx->dyn.num_nodes : 0u);
   ctx->stats.bvh_depth = std::max(ctx->bvh.depth, ctx->split ? ctx->dyn.depth : 0u);
   ctx->stats.device_bytes = ctx->bytes;
@@ -2872,7 +2932,7 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
   }
   const SceneView view = ctx->view();
   const TestIO io{d_rays.p, d_hits.p, ctx->split ? ctx->s2g_all.p : ctx->bvh.slot_to_global, any_hit,
-                  ctx->bvh.num_tris + (ctx->split ? ctx->dyn.num_tris : 0u)};
+                  ctx->bvh.num_tris};
   const TraceStatsOut none{nullptr, nullptr, nullptr};
   if (ctx->split) {  // both trees, the newest version of the edited one
     TestSplitIO sio;
