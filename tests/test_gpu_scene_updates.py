@@ -677,3 +677,34 @@ def test_split_scene_trace_hook_and_statistics(oracle_mod, materials_scene):
         assert np.array_equal(ctx.download().reshape(-1, 4), ref)
         assert st["extension_rays"] == so["extension_rays"] and st["shadow_rays"] == so["shadow_rays"] and st["stat_rays"] > 0
         assert st["num_bvh_nodes"] != nodes_split and st["num_triangles"] == sc.num_triangles
+
+
+@pytest.mark.gpu
+def test_split_scene_ring_wraps(oracle_mod, materials_scene):
+    """90 one-sample frames with one object moved before each, no sync: the ring of the edited instances' tree (64 slots) goes round
+    once and a half while paths of up to 52 frames ago are still in flight; every frame on the scene it was generated under."""
+    import copy
+
+    import gpuspectral_amd as g
+
+    sc = copy.deepcopy(materials_scene)
+    W, H, frames = 40, 30, 90
+    base = sc.instances.copy()
+    small = int(np.argsort(base["vertex_count"])[len(base) // 2])
+    acc = None
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        for k in range(frames):
+            inst = base.copy()
+            t = inst["transform"][small].copy()
+            t[12:15] += np.float32(0.004 * (1 + k % 23)) * np.array([0.6, 0.1, -0.4], np.float32)
+            inst["transform"][small] = t
+            sc.instances = inst
+            ctx.update_instances(inst)
+            ctx.render(spp=1, first_timestamp=k)
+            acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+        img = ctx.download().reshape(-1, 4)
+        assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(1).sum())
+        st = ctx.stats()
+        assert st["scene_splits"] == 1 and st["scene_drains"] == 1 and st["scene_refits"] == frames - 1, st
