@@ -1984,7 +1984,12 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   }
   if (ctx->split || (!ctx->split_declined && ctx->pipe_active && ctx->opt.refit_growth > 1.0 && ctx->opt.geometry_versions >= 4 &&
                      ctx->num_textures == 0)) {
-    if (ctx->pipe_active) {
+    // The FIRST split needs no wait: the edited instances' tree is built where they WERE (version 0: with the static tree it is,
+    // triangle for triangle, the scene the samples in flight were generated under -- they carry stamp 0 -- and the hit records
+    // the memo has handed out name slots of the static tree whose shading packets stay), and the edit itself is version 1, a
+    // refit into the next slot like every later one.  Nothing is queued between two gsp_render calls, so the arrays can change hands.
+    const bool no_wait = !ctx->split && ctx->pipe_active && ctx->geo_ver == 0 && ctx->geo_stride == 0 && ctx->caps_allow_versions();
+    if (ctx->pipe_active && !no_wait) {
       ++ctx->stats.scene_drains;
       rc = pipeline_drain(ctx);
       if (rc != GSP_OK) return rc;
@@ -1994,10 +1999,38 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
       if (std::memcmp(&instances[i], &ctx->h_inst[i], sizeof(gsp_instance)) != 0) ctx->inst_dynamic[i] = 1;
     ctx->have_scene = false;
     for (gsp_context::Lane& L : ctx->lanes) L.memo_valid = false;
-    ctx->h_inst.assign(instances, instances + num_instances);
+    if (!no_wait) ctx->h_inst.assign(instances, instances + num_instances);
     bool made = false;
     rc = make_split(ctx, &made);
     if (rc != GSP_OK && rc != GSP_ERR_NOMEM) return rc;
+    if (made && no_wait) {
+      ctx->h_inst.assign(instances, instances + num_instances);
+      BuildInput bi;
+      rc = upload_subset(ctx, 1, bi);
+      if (rc != GSP_OK) return rc;
+      const q4* from = ctx->dyn.nodes;
+      point_dyn_at(ctx, 1);
+      CTX_TRY(ctx, hipMemcpyAsync(ctx->dyn.nodes, from, (size_t)ctx->dyn.num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, ctx->stream));
+      double growth = 0.0;
+      const size_t held = ctx->dyn.bytes;
+      rc = refit_bvh(ctx->stream, bi, ctx->dyn, &growth, ctx->err);
+      ctx->bytes += ctx->dyn.bytes - held;
+      if (rc != GSP_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+      }
+      if (growth <= ctx->opt.refit_growth) {
+        ctx->geo_ver = 1;
+      } else {  // the object has moved far in one step: the small tree is built where it IS, behind a wait after all
+        point_dyn_at(ctx, 0);
+        ++ctx->stats.scene_drains;
+        rc = pipeline_drain(ctx);
+        if (rc != GSP_OK) return rc;
+        made = false;
+        rc = make_split(ctx, &made);
+        if (rc != GSP_OK && rc != GSP_ERR_NOMEM) return rc;
+      }
+    }
     if (made) {
       ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       ctx->have_scene = true;

@@ -391,7 +391,7 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
  *                         from where the tree was built for) the BVH is rebuilt instead (16 ms).  Images do not
  *                         depend on which of the two happened: the closest-hit rule is independent of the tree.
  *                         An edit that arrives while samples are in flight (a viewer) builds the scene as TWO trees once --
- *                         the instances edited so far and the rest (gsp_stats.scene_splits; behind one wait) -- and later
+ *                         the instances edited so far and the rest (gsp_stats.scene_splits; no wait the first time) -- and later
  *                         edits of those instances refit only their small tree (0.08 ms) into the next slot of a ring of
  *                         up to 64 versions while the samples in flight finish in theirs.  Scenes that do not split (more
  *                         than a quarter of the triangles edited, textures, the ninth split) keep a ring of whole refitted
