@@ -1570,6 +1570,12 @@ static int make_split(gsp_context* ctx, bool* made) {
     free_bvh(D);
     return rc;
   }
+  struct Guard {  // (an early return below gives the small tree back)
+    DeviceBvh* d;
+    ~Guard() {
+      if (d) free_bvh(*d);
+    }
+  } guard{&D};
   CTX_TRY(ctx, hipStreamSynchronize(st));
   const uint64_t slots_s = (uint64_t)S.num_tris + S.first_slot + (kWide - 1), slots_d = (uint64_t)D.num_tris + D.first_slot + (kWide - 1);
   const uint64_t stride_s = std::max<uint64_t>(slots_s, kNodeAllocMin / kNodeBytes), stride_d = std::max<uint64_t>(slots_d, kNodeAllocMin / kNodeBytes);
@@ -1579,16 +1585,12 @@ static int make_split(gsp_context* ctx, bool* made) {
   while ((2u << lg) <= std::min<uint32_t>(ctx->opt.geometry_versions, kGeoVersions)) ++lg;
   auto total_slots = [&](uint32_t l) { return stride_s + (stride_d << l); };
   while (lg > 0 && (total_slots(lg) * kNodeBytes >= (1ull << 32) || total_slots(lg) >= (1ull << 28) || total_slots(lg) * 11 * sizeof(q4) > free_b / 4)) --lg;
-  if (lg < 2 || stride_d > kGeoMaxStride || S.num_nodes > stride_s || D.num_nodes > stride_d) {
-    free_bvh(D);
-    return GSP_OK;
-  }
+  if (lg < 2 || stride_d > kGeoMaxStride || S.num_nodes > stride_s || D.num_nodes > stride_d) return GSP_OK;
   // ---- the new layout: [static | ring]; the static tree's arrays are copied into it, wherever they were ----
   const size_t total = (size_t)total_slots(lg);
   DevBuf<q4> nn, ni, ns;
   if (nn.ensure(total * kNodeQuads, nullptr) != hipSuccess || ni.ensure(total * 3, nullptr) != hipSuccess || ns.ensure(total * 4, nullptr) != hipSuccess) {
     (void)hipGetLastError();
-    free_bvh(D);
     ctx->geo_ring_failed = true;
     return GSP_OK;  // (nothing has changed: the scene stays one tree)
   }
@@ -1653,6 +1655,7 @@ static int make_split(gsp_context* ctx, bool* made) {
     ctx->bytes += D.bytes;
   }
   ctx->dyn = std::move(D);
+  guard.d = nullptr;
   ctx->split = true;
   ctx->static_slots = (uint32_t)stride_s;
   ctx->geo_stride = (uint32_t)stride_d;
