@@ -708,3 +708,58 @@ def test_split_scene_ring_wraps(oracle_mod, materials_scene):
         assert np.array_equal(img, acc), "%d pixels differ" % int((img != acc).any(1).sum())
         st = ctx.stats()
         assert st["scene_splits"] == 1 and st["scene_drains"] == 0 and st["scene_refits"] == frames - 1, st
+
+
+@pytest.mark.gpu
+def test_reference_frame_loop_against_the_c_abi(oracle_mod, materials_scene):
+    """INTEGRATION.md's frame loop -- the reference's Renderer::run: re-read camera, objects and tables, trace one sample, show the
+    accumulate buffer from device memory -- 40 frames with all three edited before each and no call that waits: what is shown is
+    always the running mean of a prefix of the samples, the final image equals the oracle's, bit for bit."""
+    import copy
+    import ctypes as C
+
+    import gpuspectral_amd as g
+
+    sc = copy.deepcopy(materials_scene)
+    W, H, frames = 48, 36, 40
+    base = sc.instances.copy()
+    small = int(np.argsort(base["vertex_count"])[len(base) // 2])
+    cam0 = np.array(sc.to_world, np.float32).copy()
+    hip = C.CDLL("libamdhip64.so")
+    dptr = C.c_void_p()
+    nbytes = W * H * 16
+    means = {0: np.zeros((W * H, 4), np.float32)}
+    acc = None
+    with g.Context(0) as ctx:
+        ctx.upload_scene(sc)
+        ctx.frame_begin(W, H)
+        assert hip.hipMalloc(C.byref(dptr), C.c_size_t(nbytes)) == 0
+        try:
+            shown_before = 0
+            for k in range(frames):
+                sc.to_world = moved(cam0, dx=0.004 * (k % 7), dy=0.002 * (k % 3))
+                inst = base.copy()
+                t = inst["transform"][small].copy()
+                t[12:15] += np.float32(0.01 * (1 + k % 11)) * np.array([0.5, 0.1, -0.4], np.float32)
+                inst["transform"][small] = t
+                sc.instances = inst
+                bs = [b.copy() for b in sc.bsdfs]
+                bs[0]["reflectance"][k % len(bs[0])] = (0.2 + 0.015 * k, 0.45, 0.8 - 0.015 * k)
+                sc.bsdfs = bs
+                ctx.update_camera(sc.to_world, sc.fov)
+                ctx.update_instances(inst)
+                ctx.update_tables(sc)
+                ctx.render(spp=1, first_timestamp=k)
+                acc, _ = oracle_mod.Oracle(sc).render(W, H, spp=1, first_timestamp=k, accum=acc)
+                means[k + 1] = acc.copy()
+                shown = ctx.peek_to_device(dptr.value, nbytes)
+                assert shown_before <= shown <= k + 1
+                shown_before = shown
+                back = np.zeros((W * H, 4), np.float32)
+                assert hip.hipMemcpy(C.c_void_p(back.ctypes.data), dptr, C.c_size_t(nbytes), 2) == 0
+                assert np.array_equal(back, means[shown]), (k, shown)
+            st = ctx.stats()  # (waits for the rest)
+            assert st["scene_drains"] == 0 and st["scene_splits"] == 1, st
+            assert np.array_equal(ctx.download().reshape(-1, 4), acc)
+        finally:
+            hip.hipFree(dptr)
