@@ -38,7 +38,9 @@ class PathTracerHip : public RenderPassCreator {
     p.first_timestamp = (uint32_t)timestamp++;  // renderState.params.timestamp, PathTracer.cpp:91-92
     check(gsp_render(ctx, &p));
   }
-  void download(float* rgba) { check(gsp_download(ctx, rgba)); }  // what the DrawTexture blit sampled
+  void download(float* rgba) { check(gsp_download(ctx, rgba)); }  // what the DrawTexture blit sampled, once every path has ended
+  // ... and as it stands this frame, into the device memory the blit reads (PathTracer.cpp:41-55): no wait, no trip through the host
+  void blitSource(void* deviceRgba, uint64_t bytes, uint32_t* samples = nullptr) { check(gsp_peek_to_device(ctx, deviceRgba, bytes, samples)); }
   void restart() {                                                // a viewer that wants a fresh running mean after an edit
     timestamp = 0;
     check(gsp_frame_begin(ctx, width, height, nullptr, 0));
