@@ -15,6 +15,20 @@
 
 namespace orc {
 
+// ---- bias attribution (tests/test_oracle_pins.py, tests/tools/quirk_probe.py) --------------------------------------
+// The reference's estimator departs from an unbiased MIS path tracer in four documented places.  A bit set in
+// g_quirks_off replaces that ONE departure by the textbook form, so that a render can be compared with the unbiased
+// third-party images the reference ships (TungstenRender.png) and each departure's share of the difference measured.
+// 0 (the default, and the only value oracle_render uses) is the reference as shipped.  Never set by a parity test.
+enum : uint32_t {
+  kQuirkNeeSampledPdf = 1u,        // rayhit.rchit:751  NEE weight takes the pdf of the SAMPLED direction wi, not of L
+  kQuirkDirectWeight = 2u,         // :763-765,785-790  emitter hit weighted with the pdf of the previous vertex's light
+                                   //                   SAMPLE (1 when that sample was shadowed), not of reaching this point
+  kQuirkFireflyClamp = 4u,         // raygen.rgen:60-63 vertex contributions with a channel >= cutoff are dropped
+  kQuirkRoughPlasticPdfFloor = 8u, // rayhit.rchit:577  max(D * cos, 0.01) in the eval pdf only
+};
+inline uint32_t g_quirks_off = 0;
+
 // ---- RNG: pt_common.glsl:86-120 ------------------------------------------
 struct Rng {
   uint32_t state;
@@ -430,6 +444,11 @@ static inline void roughPlasticBSDFSample(const gsp_rough_plastic_bsdf& b, Rng& 
 static inline void roughPlasticBSDFEval(const gsp_rough_plastic_bsdf& b, vec3 wo, vec3 wi, BSDFOutput& res) {
   vec3 wh;
   roughPlasticTerms(b, wo, wi, wh, res.bsdf);
+  if (g_quirks_off & kQuirkRoughPlasticPdfFloor) {  // bias attribution only: the pdf roughPlasticBSDFSample reports (:541)
+    res.pdf = ((0.5f * beckmannD(wh, b.alpha)) * gabs(wh.z)) / (4.0f * gabs(dot(wo, wh))) + 0.5f * cosineHemispherePdf(wi);
+    res.isDelta = false;
+    return;
+  }
   res.pdf = (0.5f * gmax(beckmannD(wh, b.alpha) * gabs(wh.z), 0.01f)) / (4.0f * gabs(dot(wo, wh))) +
             0.5f * cosineHemispherePdf(wi);
   res.isDelta = false;

@@ -397,6 +397,7 @@ struct HitPayload {
   float directWeight;
   uint32_t seed;
   int wasDelta, countEmitted, done;
+  float lastPdf = 0.0f;  // bias attribution only (kQuirkDirectWeight): pdf of the direction that produced this ray
 };
 
 struct Counters {
@@ -490,6 +491,7 @@ static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit,
       bool shadowed = anyHit(S.accel, position, L, 0.01f, Ldist - 0.01f, collect ? &C.trav : nullptr);  // :737-748
       if (!shadowed && lightPdf != 0.0f) {                                 // :750
         float w = powerHeuristic(1, lightPdf, 1, bsdfRes.pdf);             // :751
+        if (g_quirks_off & kQuirkNeeSampledPdf) w = powerHeuristic(1, lightPdf, 1, lightBsdfRes.pdf);  // pdf of L itself
         prd.emitted = prd.emitted + ((((w * NoL) * lightBsdfRes.bsdf) * prd.weight) * lightRes.emission) / lightPdf;  // :752
         neeDone = true;
       }
@@ -498,7 +500,16 @@ static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit,
   prd.seed = rng.state;                                                    // :759
   float lightFlag = dot(N, -rayDir) > 0.0f ? 1.0f : 0.0f;                  // :760
   if (NEE && prd.countEmitted == 0 && prd.wasDelta == 0) {                 // :763-765
-    prd.emitted = prd.emitted + ((prd.directWeight * emission) * lightFlag) * prd.weight;
+    float directWeight = prd.directWeight;
+    if (g_quirks_off & kQuirkDirectWeight) {
+      // the textbook weight: light sampling's solid-angle pdf of reaching THIS point of THIS emitter from the previous
+      // vertex (sampleTrangleLight's own formula, :141, with the hit triangle's area) against the pdf that sent the ray
+      const float A = 0.5f * gabs(length(cross(pos2 - pos0, pos1 - pos0)));
+      const float hitPdf = ((hit.t * hit.t) / (gabs(dot(-rayDir, N)) * A)) * (1.0f / (float)S.sc.num_lights);
+      const bool isLight = emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f;
+      directWeight = isLight ? powerHeuristic(1, prd.lastPdf, 1, hitPdf) : 1.0f;
+    }
+    prd.emitted = prd.emitted + ((directWeight * emission) * lightFlag) * prd.weight;
   }
   if (!NEE || prd.countEmitted == 1 || prd.wasDelta == 1) {                // :766-768
     prd.emitted = prd.emitted + (emission * lightFlag) * prd.weight;
@@ -521,6 +532,7 @@ static void closestHitShader(const SceneCtx& S, HitPayload& prd, const Hit& hit,
     prd.directWeight = 1.0f;
   }
   prd.countEmitted = 0;                                                    // :792
+  prd.lastPdf = bsdfRes.pdf;
   prd.origin = position + 0.0001f * faceforward(N, -wi, N);                // :793
   prd.direction = wi;                                                      // :794
   prd.weight = prd.weight * ((bsdfRes.bsdf * NoW) / bsdfRes.pdf);          // :795
@@ -582,7 +594,8 @@ static vec3 samplePixel(const SceneCtx& S, const RenderCfg& cfg, uint32_t px, ui
       if (S.sc.envmap.texels) prd.emitted = envmapLookup(S.sc, prd.direction) * prd.weight;
     }
     rng.state = prd.seed;                                                  // :59
-    if (prd.emitted.x < cfg.clamp && prd.emitted.y < cfg.clamp && prd.emitted.z < cfg.clamp) {  // :60-63
+    if ((prd.emitted.x < cfg.clamp && prd.emitted.y < cfg.clamp && prd.emitted.z < cfg.clamp) ||  // :60-63
+        (g_quirks_off & kQuirkFireflyClamp)) {
       result = result + prd.emitted;
     }
     if (depth > cfg.rr_start_depth) {                                      // :66-71
@@ -779,6 +792,11 @@ int oracle_render(void* h, uint32_t width, uint32_t height, const uint32_t* pixe
   return 0;
 }
 
+// Bias attribution (oracle_bsdf.h, kQuirk*): the mask stays set until the next call; 0 = the reference as shipped.
+// Process-wide and not synchronised with a running oracle_render: set it between renders.
+void oracle_set_quirks_off(uint32_t mask) { g_quirks_off = mask; }
+uint32_t oracle_get_quirks_off() { return g_quirks_off; }
+
 // enable != 0: start logging the extension rays of single-threaded oracle_render calls; 0: stop and drop the log.
 // oracle_ray_log_read copies up to cap rays (8 floats each) and returns how many were logged.
 void oracle_ray_log(int enable) {
@@ -886,6 +904,20 @@ void oracle_sample_light(void* h, const float* pos, uint32_t seed, float* out8) 
   out8[6] = r.pdf;
   out8[7] = u2f(g.state);
 }
+// Onb (pt_common.glsl:122-151): out15 = {tangent, binormal, normal, onbTransform(v), onbUntransform(v)}
+void oracle_onb(const float* nrm, const float* v, float* out15) {
+  Onb o = onbCreate(V(nrm[0], nrm[1], nrm[2]));
+  vec3 a = onbTransform(o, V(v[0], v[1], v[2])), b = onbUntransform(o, V(v[0], v[1], v[2]));
+  const vec3 r[5] = {o.tangent, o.binormal, o.normal, a, b};
+  for (int k = 0; k < 5; ++k) {
+    out15[3 * k] = r[k].x;
+    out15[3 * k + 1] = r[k].y;
+    out15[3 * k + 2] = r[k].z;
+  }
+}
+float oracle_power_heuristic(float f, float g) { return powerHeuristic(1, f, 1, g); }
+float oracle_cosine_pdf(float z) { return cosineHemispherePdf(V(0.0f, 0.0f, z)); }
+int oracle_is_transmission(uint32_t handle) { return isTransimissionBSDF(handle >> 16) ? 1 : 0; }
 // deterministic transcendentals (for the accuracy test against libm)
 void oracle_det_math(const float* x, uint64_t n, float* s, float* c, float* lg, float* ex) {
   for (uint64_t i = 0; i < n; ++i) {

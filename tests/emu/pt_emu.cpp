@@ -494,6 +494,30 @@ void emu_transform_inv_t(const float* m, float* out) {
   transpose4(m, tr);
   inverse4(tr, out);
 }
+// the product's frame / RNG / helper functions one by one (tests/test_glsl_vectors.py)
+void emu_onb(const float* nrm, const float* v, float* out15) {
+  Frame f = make_frame(mk3(nrm[0], nrm[1], nrm[2]));
+  f3 a = to_local(f, mk3(v[0], v[1], v[2])), b = to_world(f, mk3(v[0], v[1], v[2]));
+  const f3 r[5] = {f.t, f.b, f.n, a, b};
+  for (int k = 0; k < 5; ++k) {
+    out15[3 * k] = r[k].x;
+    out15[3 * k + 1] = r[k].y;
+    out15[3 * k + 2] = r[k].z;
+  }
+}
+// out6 = {tea(a, b), pcgHash(a), then from state a: randPcg, randPcg, randUniform bits, state afterwards}
+void emu_rng(uint32_t a, uint32_t b, uint32_t* out6) {
+  out6[0] = tea(a, b);
+  out6[1] = pcg_hash(a);
+  uint32_t st = a;
+  out6[2] = pcg_next(st);
+  out6[3] = pcg_next(st);
+  out6[4] = f2u(rand_uniform(st));
+  out6[5] = st;
+}
+float emu_power_heuristic(float f, float g) { return power_heuristic(f, g); }
+float emu_cosine_pdf(float z) { return cosine_pdf(mk3(0.0f, 0.0f, z)); }
+int emu_is_transmission(uint32_t handle) { return bsdf_transmits(handle) ? 1 : 0; }
 uint32_t emu_seed(uint32_t width, uint32_t px, uint32_t py, uint32_t timestamp) {
   return pcg_hash(tea(width * py + px, timestamp));
 }

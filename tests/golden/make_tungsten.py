@@ -17,7 +17,10 @@ single exposure that fits; under the inverse filmic curve all three channels of 
 render to 1-5 % (profiles/r02_tungsten_compare.txt).  The curve is inverted in closed form below.
 
 Per scene the file holds: `lin` [h/8, w/8, 3] linear radiance, `sat` [h/8, w/8, 3] = some pixel of the 8x8 block is
-clipped (>= 254) or in the toe (<= 2) in that channel of the PNG, i.e. the block's radiance is not recoverable.
+clipped (>= 254) or in the toe (<= 2) in that channel of the PNG, i.e. the block's radiance is not recoverable;
+`shoulder` [h/8, w/8, 3] (r06) = some pixel of the block is >= 232 in that channel: on the curve's shoulder one 8-bit level is
+> 5 % of radiance (17 % at 248, 51 % at 252 -- the Cornell light is written as 252 / 250 / 243 for radiance 17 / 12 / 4), so
+such blocks pass the `sat` test but carry no usable number.  Tests that claim a few per cent exclude them too.
 """
 import os
 
@@ -46,7 +49,8 @@ def main():
         lin = lin.reshape(h // BLOCK, BLOCK, w // BLOCK, BLOCK, 3).mean(axis=(1, 3))
         bad = ((raw >= 254) | (raw <= 2)).reshape(h // BLOCK, BLOCK, w // BLOCK, BLOCK, 3).any(axis=(1, 3))
         out = os.path.join(HERE, "ref_scenes", "tungsten_%s.npz" % name)
-        np.savez_compressed(out, lin=lin.astype(np.float32), sat=bad)
+        shoulder = (raw >= 232).reshape(h // BLOCK, BLOCK, w // BLOCK, BLOCK, 3).any(axis=(1, 3))
+        np.savez_compressed(out, lin=lin.astype(np.float32), sat=bad, shoulder=shoulder)
         print(out, lin.shape, lin.mean((0, 1)), "unrecoverable blocks: %.1f %%" % (100.0 * bad.mean()))
 
 

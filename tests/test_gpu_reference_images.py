@@ -36,10 +36,25 @@ def _render(sc, W, H, spp=SPP):
     return img[..., :3].astype(np.float64).reshape(H // 8, 8, W // 8, 8, 3).mean(axis=(1, 3))
 
 
-def _cells(ours, fix):
-    """Per-cell, per-channel ratio ours / Tungsten over the recoverable blocks (NaN where too few)."""
+def _cells(ours, fix, strict=False):
+    """Per-cell, per-channel ratio ours / Tungsten over the recoverable blocks (NaN where too few).
+    strict: also leave out the blocks on the tone curve's shoulder (fixture key `shoulder`, PNG level >= 232: one
+    8-bit level there is 5-50 % of radiance -- the light source itself, which `sat` lets through at level 252)."""
     t = fix["lin"].astype(np.float64)
     ok = ~fix["sat"] & (t > 0.02)
+    if strict:
+        # what a comparison to a few per cent may use: no block next to the shoulder (the light and its antialiased rim),
+        # nothing below PNG level ~40 (radiance 0.03: one level is > 3 % there), and no block on a silhouette -- the two
+        # renderers' pixel grids are a pixel apart (raygen.rgen:21 has no half-pixel offset, Tungsten filters with a
+        # tent), which moves a block mean by the edge contrast / 8
+        def grow(m):
+            p = np.pad(m, ((1, 1), (1, 1), (0, 0)), mode="edge")
+            return np.stack([p[i:i + m.shape[0], j:j + m.shape[1]] for i in range(3) for j in range(3)]).any(axis=0)
+
+        p = np.pad(t, ((1, 1), (1, 1), (0, 0)), mode="edge")
+        nb = np.stack([p[i:i + t.shape[0], j:j + t.shape[1]] for i in range(3) for j in range(3)])
+        edge = nb.max(axis=0) > 1.25 * nb.min(axis=0)
+        ok &= ~grow(fix["shoulder"].any(axis=2, keepdims=True) | np.zeros_like(fix["sat"])) & (t > 0.03) & ~edge
     h, w = t.shape[:2]
     hc, wc = h // CELL, w // CELL
     cut = (slice(0, hc * CELL), slice(0, wc * CELL))
@@ -53,8 +68,13 @@ def _cells(ours, fix):
 def test_cornell_box_against_tungsten():
     """Diffuse-only scene, square film, level camera: every recoverable cell of the image takes part.
     Measured (1024 spp): 146 cell-channels, ratio 1.011 .. 1.299, median 1.031; the lit walls (rows 1-2) 1.011 .. 1.028.
-    The excess over 1 is the reference integrator's own bias (NEE weighted with the pdf of the *sampled* direction,
-    rayhit.rchit:751; largest on the tall box and in its shadow, 1.09 .. 1.30) and is reproduced, not corrected.
+    The excess over 1 is the reference integrator's own bias and is reproduced, not corrected.  Which bias, measured on the
+    CPU oracle by switching the reference's four departures from a textbook MIS estimator off one at a time
+    (tests/test_oracle_pins.py::test_bias_attribution_against_tungsten, profiles/r06_quirk_attribution.txt): all of it is the
+    emitter-hit weight of rayhit.rchit:763-765,785-790 (the pdf of the previous vertex's light SAMPLE instead of the pdf of
+    reaching the hit point, and 1 when that sample was shadowed -- largest on the tall box and in its shadow, 1.06 .. 1.29);
+    the NEE weight of :751 changes < 0.1 % on this scene and the cutoff nothing.  With the four off the oracle is within
+    0.998 .. 1.028 of Tungsten on every cell.
     Excluded by the fixture's mask: the light source (clipped in the PNG) and the near-black short box front."""
     from gpuspectral_amd import host
 
