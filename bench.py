@@ -166,6 +166,7 @@ def parse():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--scene", default="interior", choices=["interior", "materials", "caustics", "cornell"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip BASELINE's other configs after the timed region (N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--dump", default="", help="write the gathered frame as .npy (rank 0)")
     ap.add_argument("--force-dist", action="store_true",
@@ -230,6 +231,48 @@ def cpu_baseline(sc, args, scene_name):
         "sample": "%s, %dx%d, %d spp on %d pixels (every %d-th 16x16 tile), %.1f s, scalar C++ oracle with %d std::threads (= the CPUs the cgroup grants); BVH build %.2f s excluded"
         % (scene_name, W, H, spp_c, len(ids), parts, st["seconds"], threads, o.build_seconds),
     }
+
+
+def other_workloads(g, seconds=1.0):
+    """BASELINE.json's other single-GPU configs, after the timed region and OUTSIDE `value`: ~`seconds` of rendering
+    each, so that the driver's record carries them too (r05 review, item 3).  Config 2 = Cornell + full BSDF set at 1024 x
+    1024; Config 3 = the ~600 k-triangle interior at 1080p; Config 5 = the dielectric caustics scene at 4096 x 4096,
+    max depth 32 -- the tile share rank 0 of the 8-GPU job owns.  Same call sequence as the headline (gsp_upload_scene,
+    gsp_frame_begin, gsp_render with HIP-event kernel times, gsp_sync), wall-clock around render + sync."""
+    from gpuspectral_amd import abi, multigpu, scenes
+
+    todo = [
+        ("config2: Cornell + full BSDF set: scenes.cornell_materials(96)", lambda: scenes.cornell_materials(96), 1024, 1024, None, {}),
+        ("config3: bathroom2 stand-in: scenes.interior(target_tris=600000, seed=7)", lambda: scenes.interior(600_000, seed=7), 1920, 1080, None, {}),
+        ("config5: dielectric caustics: scenes.caustics(1000000, seed=11), rank 0's share of 8", lambda: scenes.caustics(1_000_000, seed=11),
+         4096, 4096, (0, 8), {"max_depth": 32}),
+    ]
+    out = []
+    for name, make, W, H, share, over in todo:
+        with g.Context(0) as ctx:
+            ctx.upload_scene(make())
+            ctx.frame_begin(W, H, multigpu.partition(W, H, *share) if share else None)
+            p = abi.default_render_params()
+            for k, v in over.items():
+                setattr(p, k, v)
+            ctx.render(spp=8, first_timestamp=0, params=p)  # pool sized, queues touched
+            ctx.sync()
+            t = time.perf_counter()
+            ctx.render(spp=8, first_timestamp=8, params=p)
+            ctx.sync()
+            probe = time.perf_counter() - t
+            spp = int(max(8, min(4096, 8 * seconds / max(probe, 1e-4))))
+            ctx.reset_stats()
+            t = time.perf_counter()
+            ctx.render(spp=spp, first_timestamp=16, params=p, collect_kernel_times=1)
+            ctx.sync()
+            dt = time.perf_counter() - t
+            st = ctx.stats()
+            out.append({"workload": name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "pixels": int(ctx.num_pixels),
+                        "max_depth": int(p.max_depth), "spp": spp, "seconds": dt, "mrays_per_s": st["traced_rays"] / dt / 1e6,
+                        "msamples_per_s": st["samples"] / dt / 1e6, "extend_ms": st["extend_kernel_ms"], "shade_ms": st["shade_kernel_ms"],
+                        "connect_ms": st["connect_kernel_ms"], "launches": int(st["extend_launches"]), "bvh_build_ms": st["bvh_build_ms"]})
+    return out
 
 
 def _launch_ranks(args):
@@ -368,6 +411,8 @@ def _main():
         # untimed rehearsal of the job's one collective: RCCL sets its point-to-point channels up on first use
         multigpu.gather_frame(local_t, W, H, rank, world, dist, force=args.force_dist)
 
+    # the host's framebuffer exists before the job starts (a viewer owns one): allocated and touched outside the timed region
+    host_frame = np.ones((H, W, 4), np.float32) if dist is None else None
     barrier()
     t_begin = time.perf_counter()
     for _ in range(args.steps):
@@ -375,6 +420,14 @@ def _main():
         ts += S
     frame = None
     gather_s = 0.0
+    download_s = 0.0
+    if dist is None:
+        # north_star's entry point is render(scene) -> HOST framebuffer: the read-back of the HDR frame (gsp_download,
+        # S/renderer/PathTracer.cpp's blit source) belongs to the job and is INSIDE the timed region, like the gather of N > 1
+        ctx.sync()  # (the tracer drained first, as in front of the gather: download_ms is the read-back alone)
+        t_d = time.perf_counter()
+        ctx.download(out=host_frame)
+        download_s = time.perf_counter() - t_d
     if dist is not None:
         # the single collective of the job: HDR tiles -> rank 0 over xGMI.  Its own time (this rank's tracer drained first, so
         # that the clock does not charge the gather with the tail of the render; device-synchronised on both sides) goes into
@@ -420,10 +473,7 @@ def _main():
     else:
         tot = local
     if rank == 0 and args.dump:
-        if frame is not None:
-            np.save(args.dump, frame.cpu().numpy().reshape(H, W, 4))
-        else:
-            np.save(args.dump, ctx.download())
+        np.save(args.dump, frame.cpu().numpy().reshape(H, W, 4) if frame is not None else host_frame)
 
     if rank == 0:
         ext_rays, sh_rays, samples = tot[1], tot[2], tot[3]
@@ -499,9 +549,9 @@ def _main():
         survey_gbs = alg_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else None
         roof = {
             "kernel": "k_trace<ExtendIO> (closest-hit traversal of the wide BVH)",
-            # VALU issue against the guide's datasheet peak: the ceiling this kernel runs against (no MFMA by design, HBM ~1/3)
-            "bound": "valu_issue",
-            "achieved": ext["valu_ginstr_s"], "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instr/s", "frac": ext["issue_frac"],
+            # bound / achieved / peak / frac: the LARGEST of the three datasheet ceilings this kernel can run against (no MFMA
+            # by design), picked from the data -- VALU issue, the vector-memory request path, HBM; all three stay in `fractions`
+            "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
             "fractions": {"valu_issue": ext["issue_frac"], "valu_issue_weighted": ext["issue_frac_weighted"],
                           "valu_issue_weighted_static": ext["issue_frac_weighted_static"],
                           "valu_issue_weighted_at_clock": ext["issue_frac_weighted_at_clock"],
@@ -533,6 +583,12 @@ def _main():
             "counters_from": ("committed PMC file " + pmc_src) if pmc else None,
             "pmc": pmc_src,
         }
+        rows = {"valu_issue": (ext["valu_ginstr_s"], VALU_PEAK_GINST, "G wave64 VALU instr/s", ext["issue_frac"]),
+                "l1_request": (ext["lane_loads_g_s"], L1_REQUEST_PEAK_G, "G 16-B lane loads/s", ext["l1_request_frac"]),
+                "hbm": (ext["hbm_gbs"], HBM_PEAK_GBS, "GB/s", ext["hbm_frac"])}
+        if ext["bound"] in rows:
+            roof["bound"] = ext["bound"]
+            roof["achieved"], roof["peak"], roof["unit"], roof["frac"] = rows[ext["bound"]]
         if pmc and pmc.get("k_trace_extend") and ext_traced0 > 0:
             c = pmc["k_trace_extend"]
             if "SQ_INSTS_VALU" in c:
@@ -565,6 +621,8 @@ def _main():
                 "collective": ("%s, %d rank(s), one gather of HDR tiles" % (dist.get_backend(), world)) if dist is not None else None,
                 # the gather alone (device copy of the accumulate buffer + dist.gather + rank 0's scatter), max over ranks; inside `elapsed`
                 "gather_ms": gather_s * 1e3 if dist is not None else None,
+                # N = 1: gsp_download of the frame into host memory (drain + fold + one device-to-host copy); inside `elapsed`
+                "download_ms": download_s * 1e3 if dist is None else None,
                 "extension_rays": int(traced_ext),
                 "shadow_rays": int(sh_rays),
                 "primary_memo": bool(memoised > 0),
@@ -582,6 +640,10 @@ def _main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args, scene_name)
+        ctx.close()  # (the other workloads size their own path pools from free memory)
+        if world == 1 and not args.no_other_workloads:
+            # after the timed region, outside `value`: BASELINE's configs 2, 3 and 5 (rank-0 share), ~1 s of rendering each
+            out["config"]["other_workloads"] = other_workloads(g)
         print(json.dumps(out), flush=True)
 
     ctx.close()

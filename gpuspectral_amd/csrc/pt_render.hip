@@ -45,6 +45,7 @@
 
 #include "pt_hostmath.h"
 #include "pt_internal.h"
+#include "pt_versions.h"
 #include "pt_wavetrace.h"
 
 namespace gsp {
@@ -619,10 +620,13 @@ __global__ __launch_bounds__(kShadeBlock, GSP_SHADE_MINWAVES) void k_shade(Scene
     for (uint32_t k = a0 + threadIdx.x; k < e0; k += kShadeBlock) {
       qst(&nxt.P0[k], mkq(1e30f, 1e30f, 1e30f, 1.0f));
       qst(&nxt.P1[k], mkq(1.0f, 1.0f, 0.0f, ub(kFillerSid)));
+      // the versioned ray sources read a record's geometry stamp from P3.w (ExtendVerIOT::geometry): a filler names stamp 0, not
+      // whatever the slot held before (r05 ADVICE: it worked only because geo_slot_offset masks to the ring and the ring is zeroed)
+      if (VER) qst(&nxt.P3[k], mkq(0.0f, 0.0f, 0.0f, ub(0u)));
     }
     for (uint32_t k = a1 + threadIdx.x; k < e1; k += kShadeBlock) {
       qst(&sq.S0[k], mkq(1e30f, 1e30f, 1e30f, -1.0f));  // tmax < tmin: the ray is over before the root
-      qst(&sq.S1[k], mkq(1.0f, 1.0f, 1.0f, ub(0xffffffffu)));
+      qst(&sq.S1[k], mkq(1.0f, 1.0f, 1.0f, ub(VER ? kNoNextBit : 0xffffffffu)));  // (VER: "no next path", stamp 0 -- ConnectVerIOT::geometry)
     }
     if (threadIdx.x == 0 && e0 != a0) atomicAdd(&tails[T_HOLES_NEXT], e0 - a0);
     if (threadIdx.x == 0 && e1 != a1) atomicAdd(&tails[T_HOLES_SHADOW], e1 - a1);
@@ -889,27 +893,21 @@ struct gsp_context {
   DeviceBvh bvh;
   // the eight BSDF tables and the light table live back to back in ONE allocation (16-B aligned each), so that a kernel
   // can stage all of them into LDS with one cooperative copy when they are small (k_shade)
-  // r05: `tables` is a RING of kTableVersions slots of tab_slot_bytes each; version v of the tables sits in slot
-  // (v - tab_rot) % kTableVersions.  A sample carries its slot in its path flags, so gsp_update_tables need not wait for the
+  // r05: `tables` is a RING of tab.slots slots (1 until an edit arrives with samples in flight, then up to kTableVersions: r06)
+  // of tab.slot_bytes each; version v of the tables sits in slot (v - tab.rot) % tab.slots.  A sample carries its slot in its path flags, so gsp_update_tables need not wait for the
   // samples in flight (they finish on the version they started with) as long as the new tables have the layout of the old ones
-  // and a slot is free.  While only ONE version is live it sits in slot 0 (tab_rot == tab_ver) and the flags field is 0.
+  // and a slot is free.  While only ONE version is live it sits in slot 0 (tab.rot == tab.ver) and the flags field is 0.
   DevBuf<uint8_t> tables;
   size_t table_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // byte offsets inside a slot: BSDF types 0..7, then the lights
   size_t tables_bytes = 0;
-  size_t tab_slot_bytes = 0;
-  uint32_t tab_ver = 0;  // version the next sample is generated under (monotonic)
-  uint32_t tab_rot = 0;  // version that slot 0 / flags field 0 stand for
-  uint32_t tab_slot(uint32_t v) const { return (v - tab_rot) % kTableVersions; }
+  TableRing tab;  // slots, slot size, current version, rotation (pt_versions.h: pure bookkeeping, model-tested on the CPU)
   uint32_t num_lights = 0;
-  // r05: the GEOMETRY ring (pt_stages.h): 2^geo_log2 <= kGeoVersions slots of geo_stride triangle slots each -- node records, intersection
+  // r05: the GEOMETRY ring (pt_stages.h): 2^geo.log2 <= kGeoVersions slots of geo.stride triangle slots each -- node records, intersection
   // triangles, shading packets -- so that gsp_update_instances need not wait for the samples in flight either: the refit goes
   // into the next slot, new samples are stamped with it, the old ones finish in theirs.  Made by the first gsp_update_instances
   // of a tree (which drains, as every one did until r04); `bvh.nodes / tri_isect / tri_shade` then point at the NEWEST slot.
   DevBuf<q4> ring_nodes, ring_isect, ring_shade;
-  uint32_t geo_stride = 0;  // triangle slots per version; 0 = no ring (the tree owns its arrays)
-  uint32_t geo_log2 = 0;    // log2 of the slots of the ring
-  uint32_t geo_ver = 0;     // version the next sample is generated under (monotonic); its slot: geo_ver % slots
-  uint32_t geo_base = 0;    // slot that stamp 0 stands for
+  GeoVersions geo;  // stride (0 = no ring), log2 of the slots, current version, base slot (pt_versions.h)
   bool geo_ring_failed = false;  // no memory for it: edits drain, as before
   // r05: SPLIT scene (gsp_update_instances): the instances the host has edited since the last full build live in a tree of their
   // own, `dyn`, and only THAT tree goes through the ring; `bvh` holds the instances that never changed, once, in front of the ring
@@ -928,8 +926,6 @@ struct gsp_context {
   DevBuf<uint8_t> d_retired;           // per instance: its triangles have left the static tree
   DevBuf<uint32_t> s2g_all;            // slot counted through both trees -> scene triangle index (gsp_trace)
   bool s2g_all_valid = false;
-  uint32_t geo_slots() const { return 1u << geo_log2; }
-  uint32_t geo_phys(uint32_t v) const { return v & (geo_slots() - 1u); }
   gsp_camera camera{};
   double bvh_build_ms = 0.0;
   // what gsp_upload_scene leaves resident for the per-frame edits (gsp_update_instances re-bakes from it, as the reference
@@ -961,6 +957,12 @@ struct gsp_context {
   uint32_t num_textures = 0, env_width = 0, env_height = 0;
   float env_to_local[16] = {};
   bool textured = false;
+  // frame read-back (gsp_download / gsp_peek): two pinned staging buffers; chunk k + 1 crosses PCIe while chunk k is copied
+  // into the caller's (pageable) framebuffer -- a plain hipMemcpy into pageable memory stages through ONE bounce buffer and
+  // took 10 ms for the 33-MB frame of 1080p (r06: inside bench.py's timed region)
+  static constexpr size_t kStageBytes = 4u << 20;
+  uint8_t* h_stage[2] = {nullptr, nullptr};
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
   DevBuf<float> trace_rays;  // gsp_trace: grow-only staging, kept across calls
   DevBuf<q4> trace_hits;
   DevBuf<uint32_t> trace_work;
@@ -1034,15 +1036,15 @@ struct gsp_context {
   double memory_share = 0.4;        // of the free device memory, for the path pool + result ring (gsp_ctx_options.memory_share)
   bool pipe_active = false;
 
-  // oldest table version a sample in flight may carry (= tab_ver when none is)
+  // oldest table version a sample in flight may carry (= tab.ver when none is)
   uint32_t oldest_live_version() const {
-    uint32_t o = tab_ver;
+    uint32_t o = tab.ver;
     for (uint32_t l = 0; l < num_lanes; ++l)
       if (lanes[l].pipe.active && !lanes[l].pipe.inflight.empty()) o = std::min(o, lanes[l].pipe.inflight.front().ver);
     return o;
   }
   uint32_t oldest_live_geo() const {
-    uint32_t o = geo_ver;
+    uint32_t o = geo.ver;
     for (uint32_t l = 0; l < num_lanes; ++l)
       if (lanes[l].pipe.active && !lanes[l].pipe.inflight.empty()) o = std::min(o, lanes[l].pipe.inflight.front().gver);
     return o;
@@ -1058,17 +1060,17 @@ struct gsp_context {
   SceneView view(bool versioned = false) const {
     SceneView v;
     if (split) versioned = true;  // (a split scene has no array a plain kernel could walk)
-    const bool ring = versioned && geo_stride != 0;
-    const bool tab_versions = versioned && oldest_live_version() != tab_ver;  // (else: one version of the tables, wherever it sits)
+    const bool ring = versioned && geo.stride != 0;
+    const bool tab_versions = versioned && oldest_live_version() != tab.ver;  // (else: one version of the tables, wherever it sits)
     v.nodes = ring ? ring_nodes.p : bvh.nodes;
     v.tri_isect = ring ? ring_isect.p : bvh.tri_isect;
     v.tri_shade = ring ? ring_shade.p : bvh.tri_shade;
-    v.geo = ring ? pack_geo(geo_base, geo_stride, geo_log2) : 0u;
+    v.geo = ring ? pack_geo(geo.base, geo.stride, geo.log2) : 0u;
     v.static_slots = split ? static_slots : 0u;
     // slot 0 = the base the <VER> kernels add their offset to, or the slot of the one live version (slot 0 again whenever the
     // plain kernels run: lane_enqueue moves it there)
-    const uint8_t* tb = tables.p + (versioned && !tab_versions ? (size_t)tab_slot(tab_ver) * tab_slot_bytes : 0);
-    v.ver_stride = tab_versions ? (uint32_t)tab_slot_bytes : 0u;
+    const uint8_t* tb = tables.p + (versioned && !tab_versions ? (size_t)tab.slot_of(tab.ver) * tab.slot_bytes : 0);
+    v.ver_stride = tab_versions ? (uint32_t)tab.slot_bytes : 0u;
     v.bsdf.diffuse = (const gsp_diffuse_bsdf*)(tb + table_off[0]);
     v.bsdf.smooth_dielectric = (const gsp_smooth_dielectric_bsdf*)(tb + table_off[1]);
     v.bsdf.smooth_conductor = (const gsp_smooth_conductor_bsdf*)(tb + table_off[2]);
@@ -1175,6 +1177,7 @@ static void set_create_error(const std::string& s) {
 }
 
 static int pipeline_drain(gsp_context* ctx);
+static int ensure_read_back_stage(gsp_context* ctx);
 void gsp_ctx_destroy(gsp_context* ctx);
 int gsp_ctx_create_ex(int device, const gsp_ctx_options* options, gsp_context** out);
 
@@ -1287,6 +1290,10 @@ void gsp_ctx_destroy(gsp_context* ctx) {
   }
   free_bvh(ctx->bvh);
   free_bvh(ctx->dyn);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
+    if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1370,19 +1377,23 @@ static int pack_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& i
 }
 // image -> device, as the NEXT version of the tables (queued on the context's stream; the image becomes the context's host copy,
 // so the source stays alive).  next_version == false: the pipeline is drained -- the ring is (re)allocated if the layout has
-// changed and the image becomes version tab_ver; true (gsp_update_tables with samples in flight, same layout, a free slot): the
-// image goes into the slot of tab_ver + 1, which no sample in flight reads, and becomes current.
+// changed and the image becomes version tab.ver; true (gsp_update_tables with samples in flight, same layout, a free slot): the
+// image goes into the slot of tab.ver + 1, which no sample in flight reads, and becomes current.
 static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage& img, bool next_version = false) {
   const size_t slot = (std::max<size_t>(img.total, 16) + 255) & ~(size_t)255;
-  if (!next_version && (slot != ctx->tab_slot_bytes || !ctx->tables.p)) {
-    if (ctx->tables.p) ctx->bytes -= ctx->tables.count;
-    ctx->tables.release();
-    CTX_TRY(ctx, ctx->tables.ensure(slot * kTableVersions, &ctx->bytes));
-    ctx->tab_slot_bytes = slot;
+  uint32_t write_slot = 0;
+  if (!next_version) {
+    // behind a drain (or the first upload): ONE slot -- the ring is made by the first edit that arrives with samples in flight
+    // (grow_table_ring), not at upload: 64 slots of a large light table are gigabytes (r05 review)
+    if (ctx->tab.upload_behind_drain(slot) || !ctx->tables.p) {  // (another slot size starts with one slot again)
+      if (ctx->tables.p) ctx->bytes -= std::min(ctx->bytes, ctx->tables.count);
+      ctx->tables.release();
+      CTX_TRY(ctx, ctx->tables.ensure(ctx->tab.allocation_bytes(), &ctx->bytes));
+    }
+  } else {
+    write_slot = ctx->tab.begin_next_version();
   }
-  if (next_version) ++ctx->tab_ver;
-  else ctx->tab_rot = ctx->tab_ver;  // nothing in flight: the tables go into slot 0
-  uint8_t* const base = ctx->tables.p + (size_t)ctx->tab_slot(ctx->tab_ver) * ctx->tab_slot_bytes;
+  uint8_t* const base = ctx->tables.p + (size_t)write_slot * ctx->tab.slot_bytes;
   ctx->h_tables.swap(img.bytes);
   CTX_TRY(ctx, hipMemcpyAsync(base, ctx->h_tables.data() + TableImage::kHead, std::max<size_t>(img.total, 16), hipMemcpyHostToDevice, ctx->stream));
   for (int k = 0; k < 9; ++k) ctx->table_off[k] = img.off[k];
@@ -1410,6 +1421,28 @@ static int upload_tables(gsp_context* ctx, const gsp_scene_desc* sc, TableImage&
   return GSP_OK;
 }
 
+// r06: the table ring is made when an edit first arrives with samples in flight.  The live version (the one-slot allocation,
+// flags field 0) is copied into slot 0 of the new ring and the old allocation released: between two gsp_render calls no launch
+// is queued (pipeline_run leaves every stream idle), so nothing reads it any more -- the samples in flight are records in the
+// path pool, and the launches that pick them up next get the new pointer.  GSP_OK with tab.slots still 1 when the memory is not
+// to be had (the edit then waits for the queued samples, as every edit did until r04).
+static int grow_table_ring(gsp_context* ctx, uint32_t slots) {
+  if (slots < 2 || ctx->tab.slots != 1 || !ctx->tables.p) return GSP_OK;
+  DevBuf<uint8_t> ring;
+  if (ring.ensure(ctx->tab.slot_bytes * slots, nullptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return GSP_OK;
+  }
+  CTX_TRY(ctx, hipMemcpyAsync(ring.p, ctx->tables.p, ctx->tab.slot_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->bytes -= std::min(ctx->bytes, ctx->tables.count);
+  std::swap(ctx->tables.p, ring.p);  // (`ring` now holds the one-slot allocation and frees it on return)
+  std::swap(ctx->tables.count, ring.count);
+  ctx->bytes += ctx->tables.count;
+  ctx->tab.on_grown(slots);
+  return GSP_OK;
+}
+
 // ---- geometry ring (gsp_context::ring_*) ----------------------------------------------------------------------------------
 // Both need an idle pipeline: nothing queued may name the arrays that go away.
 static void drop_geo_ring(gsp_context* ctx) {
@@ -1429,10 +1462,10 @@ static void drop_geo_ring(gsp_context* ctx) {
     if (b->p) ctx->bytes -= b->count * sizeof(q4);
     b->release();
   }
-  ctx->geo_stride = 0;
-  ctx->geo_log2 = 0;
-  ctx->geo_ver = 0;
-  ctx->geo_base = 0;
+  ctx->geo.stride = 0;
+  ctx->geo.log2 = 0;
+  ctx->geo.ver = 0;
+  ctx->geo.base = 0;
 }
 // Moves the tree's three arrays into slot 0 of a new ring of as many versions (a power of two, at most kGeoVersions) as 32-bit node
 // offsets and a quarter of the free device memory allow: 176 B per triangle and version, 11 GB for 64 versions of a million
@@ -1440,16 +1473,15 @@ static void drop_geo_ring(gsp_context* ctx) {
 // time, as before.
 static int make_geo_ring(gsp_context* ctx) {
   DeviceBvh& b = ctx->bvh;
-  if (ctx->geo_stride != 0 || ctx->geo_ring_failed || !b.nodes || b.num_tris == 0 || b.arrays_external) return GSP_OK;
+  if (ctx->geo.stride != 0 || ctx->geo_ring_failed || !b.nodes || b.num_tris == 0 || b.arrays_external) return GSP_OK;
   const uint64_t slots = (uint64_t)b.num_tris + b.first_slot + (kWide - 1);
-  const uint64_t stride = std::max<uint64_t>(slots, kNodeAllocMin / kNodeBytes);
-  if (stride > kGeoMaxStride || b.num_nodes > stride) return GSP_OK;
   size_t free_b = 0, total_b = 0;
   CTX_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  uint32_t lg = 0;  // log2 of the slots: at most what the options allow (default kGeoVersions)
-  while ((2u << lg) <= std::min<uint32_t>(std::max<uint32_t>(ctx->opt.geometry_versions, 1u), kGeoVersions)) ++lg;
-  while (lg > 0 && (((uint64_t)stride << lg) * kNodeBytes >= (1ull << 32) || ((uint64_t)stride << lg) * 11 * sizeof(q4) > free_b / 4)) --lg;
-  if (lg < 2) return GSP_OK;
+  // log2 of the slots: at most what the options allow (default kGeoVersions), 32-bit node offsets, a quarter of the free memory
+  const GeoRingPlan plan = plan_geo_ring(0, 0, slots, b.num_nodes, ctx->opt.geometry_versions, free_b, kNodeAllocMin / kNodeBytes, kGeoMaxStride, kNodeBytes);
+  if (plan.log2 < 2) return GSP_OK;
+  const uint64_t stride = plan.stride_ring;
+  const uint32_t lg = (uint32_t)plan.log2;
   hipStream_t st = ctx->stream;
   const size_t total = (size_t)stride << lg;
   if (ctx->ring_nodes.ensure(total * kNodeQuads, &ctx->bytes) != hipSuccess || ctx->ring_isect.ensure(total * 3, &ctx->bytes) != hipSuccess ||
@@ -1463,9 +1495,9 @@ static int make_geo_ring(gsp_context* ctx) {
   CTX_TRY(ctx, hipMemsetAsync(ctx->ring_nodes.p, 0, total * kNodeQuads * sizeof(q4), st));
   CTX_TRY(ctx, hipMemsetAsync(ctx->ring_isect.p, 0, total * 3 * sizeof(q4), st));
   CTX_TRY(ctx, hipMemsetAsync(ctx->ring_shade.p, 0, total * 4 * sizeof(q4), st));
-  ctx->geo_ver = 0;
-  ctx->geo_base = 0;
-  ctx->geo_log2 = lg;
+  ctx->geo.ver = 0;
+  ctx->geo.base = 0;
+  ctx->geo.log2 = lg;
   q4* nn = ctx->ring_nodes.p;  // (slot 0)
   q4* ni = ctx->ring_isect.p;
   q4* ns = ctx->ring_shade.p;
@@ -1484,12 +1516,12 @@ static int make_geo_ring(gsp_context* ctx) {
   b.tri_isect = ni;
   b.tri_shade = ns;
   b.arrays_external = true;
-  ctx->geo_stride = (uint32_t)stride;
+  ctx->geo.stride = (uint32_t)stride;
   return GSP_OK;
 }
 // the tree's arrays := the slot of version v
 static void point_bvh_at(gsp_context* ctx, uint32_t v) {
-  const size_t off = (size_t)ctx->geo_phys(v) * ctx->geo_stride;
+  const size_t off = (size_t)ctx->geo.phys(v) * ctx->geo.stride;
   ctx->bvh.nodes = ctx->ring_nodes.p + off * kNodeQuads;
   ctx->bvh.tri_isect = ctx->ring_isect.p + off * 3;
   ctx->bvh.tri_shade = ctx->ring_shade.p + off * 4;
@@ -1546,8 +1578,8 @@ static int upload_subset(gsp_context* ctx, int which, BuildInput& bi) {
 static int make_split(gsp_context* ctx, bool* made) {
   *made = false;
   if (ctx->num_textures != 0 || ctx->opt.refit_growth <= 1.0 || ctx->opt.geometry_versions < 4 || ctx->geo_ring_failed) return GSP_OK;
-  if (ctx->geo_stride != 0 && !ctx->split) return GSP_OK;  // (the scene lives in a ring of whole trees already)
-  if (ctx->stats.scene_splits >= 16) return GSP_OK;        // a host that keeps touching new objects: a wait per edit is no bargain
+  if (ctx->geo.stride != 0 && !ctx->split) return GSP_OK;  // (the scene lives in a ring of whole trees already)
+  if (ctx->stats.scene_splits >= kMaxSceneSplits) return GSP_OK;  // a host that keeps touching new objects: a wait per edit is no bargain
   DeviceBvh& S = ctx->bvh;
   if (!S.nodes || S.num_tris != ctx->total_tris || ctx->total_tris == 0) return GSP_OK;  // (the tree of the WHOLE scene: first split or a re-split)
   uint64_t tris[2] = {0, 0};
@@ -1558,7 +1590,7 @@ static int make_split(gsp_context* ctx, bool* made) {
     ctx->sub_index[w].push_back((uint32_t)i);
     tris[w] += ctx->h_inst[i].vertex_count / 3;
   }
-  if (tris[1] == 0 || tris[0] == 0 || tris[1] * 4 > tris[0] + tris[1]) return GSP_OK;
+  if (!split_worthwhile(tris[0], tris[1])) return GSP_OK;
   hipStream_t st = ctx->stream;
   // ---- the edited instances' tree ----
   BuildInput bi;
@@ -1578,14 +1610,13 @@ static int make_split(gsp_context* ctx, bool* made) {
   } guard{&D};
   CTX_TRY(ctx, hipStreamSynchronize(st));
   const uint64_t slots_s = (uint64_t)S.num_tris + S.first_slot + (kWide - 1), slots_d = (uint64_t)D.num_tris + D.first_slot + (kWide - 1);
-  const uint64_t stride_s = std::max<uint64_t>(slots_s, kNodeAllocMin / kNodeBytes), stride_d = std::max<uint64_t>(slots_d, kNodeAllocMin / kNodeBytes);
   size_t free_b = 0, total_b = 0;
   CTX_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-  uint32_t lg = 0;
-  while ((2u << lg) <= std::min<uint32_t>(ctx->opt.geometry_versions, kGeoVersions)) ++lg;
+  const GeoRingPlan plan = plan_geo_ring(slots_s, S.num_nodes, slots_d, D.num_nodes, ctx->opt.geometry_versions, free_b, kNodeAllocMin / kNodeBytes, kGeoMaxStride, kNodeBytes);
+  if (plan.log2 < 2) return GSP_OK;
+  const uint64_t stride_s = plan.stride_static, stride_d = plan.stride_ring;
+  const uint32_t lg = (uint32_t)plan.log2;
   auto total_slots = [&](uint32_t l) { return stride_s + (stride_d << l); };
-  while (lg > 0 && (total_slots(lg) * kNodeBytes >= (1ull << 32) || total_slots(lg) >= (1ull << 28) || total_slots(lg) * 11 * sizeof(q4) > free_b / 4)) --lg;
-  if (lg < 2 || stride_d > kGeoMaxStride || S.num_nodes > stride_s || D.num_nodes > stride_d) return GSP_OK;
   // ---- the new layout: [static | ring]; the static tree's arrays are copied into it, wherever they were ----
   const size_t total = (size_t)total_slots(lg);
   DevBuf<q4> nn, ni, ns;
@@ -1658,10 +1689,10 @@ static int make_split(gsp_context* ctx, bool* made) {
   guard.d = nullptr;
   ctx->split = true;
   ctx->static_slots = (uint32_t)stride_s;
-  ctx->geo_stride = (uint32_t)stride_d;
-  ctx->geo_log2 = lg;
-  ctx->geo_ver = 0;
-  ctx->geo_base = 0;
+  ctx->geo.stride = (uint32_t)stride_d;
+  ctx->geo.log2 = lg;
+  ctx->geo.ver = 0;
+  ctx->geo.base = 0;
   ctx->s2g_all_valid = false;  // (gsp_trace makes it when it needs it)
   *made = true;
   return ctx->ensure_spill();
@@ -1670,7 +1701,7 @@ static int make_split(gsp_context* ctx, bool* made) {
 // slot counted through both trees -> scene triangle index, for gsp_trace on a split scene (made on first use)
 static int make_split_s2g(gsp_context* ctx) {
   hipStream_t st = ctx->stream;
-  std::vector<uint32_t> all((size_t)ctx->static_slots + ctx->geo_stride, 0xffffffffu);
+  std::vector<uint32_t> all((size_t)ctx->static_slots + ctx->geo.stride, 0xffffffffu);
   {  // the static tree is the tree of the whole scene: its slots name scene triangles already
     const uint64_t nslots = (uint64_t)ctx->bvh.num_tris + ctx->bvh.first_slot + (kWide - 1);
     CTX_TRY(ctx, hipMemcpyAsync(all.data(), ctx->bvh.slot_to_global, nslots * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1708,7 +1739,7 @@ static int make_split_s2g(gsp_context* ctx) {
 
 // the edited instances' tree := its slot of version v
 static void point_dyn_at(gsp_context* ctx, uint32_t v) {
-  const size_t off = (size_t)ctx->static_slots + (size_t)ctx->geo_phys(v) * ctx->geo_stride;
+  const size_t off = (size_t)ctx->static_slots + (size_t)ctx->geo.phys(v) * ctx->geo.stride;
   ctx->dyn.nodes = ctx->ring_nodes.p + off * kNodeQuads;
   ctx->dyn.tri_isect = ctx->ring_isect.p + off * 3;
   ctx->dyn.tri_shade = ctx->ring_shade.p + off * 4;
@@ -1763,7 +1794,7 @@ static int bake_and_build(gsp_context* ctx, bool refit = false, bool* refitted =
   }
   // a new tree: its arrays are its own again, and whatever is in flight ends on the old ones first (the committed version's:
   // a refit into the next slot of the ring that grew too much is abandoned here)
-  if (ctx->geo_stride && !ctx->split) point_bvh_at(ctx, ctx->geo_ver);
+  if (ctx->geo.stride && !ctx->split) point_bvh_at(ctx, ctx->geo.ver);
   if (ctx->pipe_active) {
     ++ctx->stats.scene_drains;
     int rc_ = pipeline_drain(ctx);
@@ -1947,7 +1978,7 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   for (uint32_t i = 0; i < num_instances; ++i)
     if (std::memcmp(&instances[i], &ctx->h_inst[i], sizeof(gsp_instance)) != 0 && !ctx->inst_dynamic[i]) only_edited = false;
   if (ctx->split && only_edited) {
-    const bool in_slot = ctx->pipe_active && ctx->caps_allow_versions() && ctx->geo_ver + 1 - ctx->oldest_live_geo() < ctx->geo_slots();
+    const bool in_slot = ctx->pipe_active && ctx->caps_allow_versions() && ctx->geo.ver + 1 - ctx->oldest_live_geo() < ctx->geo.slots();
     if (!in_slot && ctx->pipe_active) {
       ++ctx->stats.scene_drains;
       rc = pipeline_drain(ctx);
@@ -1962,7 +1993,7 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
     if (rc != GSP_OK) return rc;
     if (in_slot) {
       const q4* from = ctx->dyn.nodes;
-      point_dyn_at(ctx, ctx->geo_ver + 1);
+      point_dyn_at(ctx, ctx->geo.ver + 1);
       CTX_TRY(ctx, hipMemcpyAsync(ctx->dyn.nodes, from, (size_t)ctx->dyn.num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
     double growth = 0.0;
@@ -1971,11 +2002,11 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
     ctx->bytes += ctx->dyn.bytes - held;
     if (rc != GSP_OK) {
       (void)hipStreamSynchronize(ctx->stream);
-      point_dyn_at(ctx, ctx->geo_ver);
+      point_dyn_at(ctx, ctx->geo.ver);
       return rc;
     }
     if (growth <= ctx->opt.refit_growth) {
-      if (in_slot) ++ctx->geo_ver;
+      if (in_slot) ++ctx->geo.ver;
       ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       ctx->have_scene = true;
       ++ctx->stats.scene_updates;
@@ -1983,7 +2014,7 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
       return GSP_OK;
     }
     // the edited tree has degraded: both trees are built again (below), behind a drain
-    point_dyn_at(ctx, ctx->geo_ver);
+    point_dyn_at(ctx, ctx->geo.ver);
   }
   if (ctx->split || (!ctx->split_declined && ctx->pipe_active && ctx->opt.refit_growth > 1.0 && ctx->opt.geometry_versions >= 4 &&
                      ctx->num_textures == 0)) {
@@ -1991,7 +2022,7 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
     // triangle for triangle, the scene the samples in flight were generated under -- they carry stamp 0 -- and the hit records
     // the memo has handed out name slots of the static tree whose shading packets stay), and the edit itself is version 1, a
     // refit into the next slot like every later one.  Nothing is queued between two gsp_render calls, so the arrays can change hands.
-    const bool no_wait = !ctx->split && ctx->pipe_active && ctx->geo_ver == 0 && ctx->geo_stride == 0 && ctx->caps_allow_versions();
+    const bool no_wait = !ctx->split && ctx->pipe_active && ctx->geo.ver == 0 && ctx->geo.stride == 0 && ctx->caps_allow_versions();
     if (ctx->pipe_active && !no_wait) {
       ++ctx->stats.scene_drains;
       rc = pipeline_drain(ctx);
@@ -2023,7 +2054,7 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
         return rc;
       }
       if (growth <= ctx->opt.refit_growth) {
-        ctx->geo_ver = 1;
+        ctx->geo.ver = 1;
       } else {  // the object has moved far in one step: the small tree is built where it IS, behind a wait after all
         point_dyn_at(ctx, 0);
         ++ctx->stats.scene_drains;
@@ -2053,8 +2084,8 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   // gsp_render stamps its samples with the new one.  Otherwise -- first edit of this tree (the ring is made then), as many edits
   // as the ring has slots within the life of one sample, a tree that degrades and is rebuilt -- the queued samples finish first,
   // as until r04.
-  const bool in_ring = ctx->pipe_active && ctx->geo_stride != 0 && ctx->opt.refit_growth > 1.0 && ctx->caps_allow_versions() &&
-                       ctx->geo_ver + 1 - ctx->oldest_live_geo() < ctx->geo_slots();
+  const bool in_ring = ctx->pipe_active && ctx->geo.stride != 0 && ctx->opt.refit_growth > 1.0 && ctx->caps_allow_versions() &&
+                       ctx->geo.ver + 1 - ctx->oldest_live_geo() < ctx->geo.slots();
   if (!in_ring) {
     if (ctx->pipe_active) ++ctx->stats.scene_drains;
     rc = pipeline_drain(ctx);
@@ -2075,15 +2106,15 @@ int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32
   if (in_ring) {
     // topology (child links, triangle ranges) of the current version -> next slot; refit_bvh rewrites every box and packet there
     const q4* from = ctx->bvh.nodes;
-    point_bvh_at(ctx, ctx->geo_ver + 1);
+    point_bvh_at(ctx, ctx->geo.ver + 1);
     CTX_TRY(ctx, hipMemcpyAsync(ctx->bvh.nodes, from, (size_t)ctx->bvh.num_nodes * kNodeBytes, hipMemcpyDeviceToDevice, ctx->stream));
   }
   rc = bake_and_build(ctx, true, &refitted);
   if (rc != GSP_OK) {
-    if (ctx->geo_stride) point_bvh_at(ctx, ctx->geo_ver);
+    if (ctx->geo.stride) point_bvh_at(ctx, ctx->geo.ver);
     return rc;
   }
-  if (in_ring && refitted) ++ctx->geo_ver;  // (not refitted: the tree was rebuilt behind a drain and owns its arrays again)
+  if (in_ring && refitted) ++ctx->geo.ver;  // (not refitted: the tree was rebuilt behind a drain and owns its arrays again)
   ctx->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->have_scene = true;
   ++ctx->stats.scene_updates;
@@ -2118,7 +2149,15 @@ int gsp_update_tables(gsp_context* ctx, const gsp_scene_desc* sc) {
   // the queued samples finish first, as until r04.
   bool same_layout = ctx->pipe_active && sc->num_lights == ctx->num_lights && img.total == ctx->tables_bytes && ctx->tables.p != nullptr;
   for (int k = 0; k < GSP_BSDF_TYPE_COUNT && same_layout; ++k) same_layout = sc->num_bsdfs[k] == ctx->num_bsdfs[k];
-  const bool in_place = same_layout && ctx->caps_allow_versions() && ctx->tab_ver + 1 - ctx->oldest_live_version() < kTableVersions;
+  size_t free_b = 0, total_b = 0;
+  if (same_layout && ctx->tab.slots == 1) CTX_TRY(ctx, hipMemGetInfo(&free_b, &total_b));  // (only the decision to grow asks)
+  TableRing::Update how = ctx->tab.decide(ctx->pipe_active, same_layout, ctx->caps_allow_versions(), ctx->oldest_live_version(), free_b);
+  if (how == TableRing::Update::kGrowThenInPlace) {
+    rc = grow_table_ring(ctx, TableRing::slots_for(ctx->tab.slot_bytes, TableRing::budget_for(free_b)));
+    if (rc != GSP_OK) return rc;
+    how = ctx->tab.slots > 1 ? TableRing::Update::kInPlace : TableRing::Update::kDrain;  // (no memory for it: wait, as until r04)
+  }
+  const bool in_place = how == TableRing::Update::kInPlace;
   if (!in_place) {
     if (ctx->pipe_active) ++ctx->stats.scene_drains;
     rc = pipeline_drain(ctx);
@@ -2169,6 +2208,10 @@ int gsp_frame_begin(gsp_context* ctx, uint32_t width, uint32_t height, const uin
   for (uint32_t l = 0; l < ctx->num_lanes; ++l)
     ctx->lanes[l].num_pixels = (num_pixels + ctx->num_lanes - 1 - l) / ctx->num_lanes;  // owned pixels lp with lp % lanes == l
   CTX_TRY(ctx, ctx->accum.ensure(num_pixels, &ctx->bytes));
+  if (num_pixels * sizeof(q4) > gsp_context::kStageBytes / 4) {
+    int rc_ = ensure_read_back_stage(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
   CTX_TRY(ctx, hipMemsetAsync(ctx->accum.p, 0, std::max<uint64_t>(num_pixels, 1) * sizeof(q4), ctx->stream));
   CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->folded_idle = 0;
@@ -2274,25 +2317,26 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
   // that did not drain: then k_shade / k_finish read every vertex's tables through the version its path carries)
   // ... or to more than one version of the geometry (gsp_update_instances without a drain: then the traversal kernels too take
   // every ray's geometry from the slot its path names)
-  const bool multi_version = ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver ||
+  const bool multi_version = ctx->oldest_live_version() != ctx->tab.ver || ctx->oldest_live_geo() != ctx->geo.ver ||
                              ctx->split;  // (a split scene is always walked by the <VER> kernels: there is no whole tree in one place)
-  if (!multi_version) ctx->geo_base = ctx->geo_phys(ctx->geo_ver);  // stamp 0 = the one live version (no copy: the kernels get its slot's pointers)
-  if (!multi_version && ctx->tab_rot != ctx->tab_ver) {
+  if (!multi_version) ctx->geo.base = ctx->geo.phys(ctx->geo.ver);  // stamp 0 = the one live version (no copy: the kernels get its slot's pointers)
+  if (!multi_version && ctx->tab.rot != ctx->tab.ver) {
     // the edits are over and the samples of the older versions have ended: the one live version moves into slot 0 and the
     // version field of the paths goes back to 0 (the <VER = false> kernels write 0).  Nothing reads slot 0 any more -- it held a
     // version whose last sample the host has seen end -- and nothing but the launches queued from here on reads the new copy.
-    CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->tables.p + (size_t)ctx->tab_slot(ctx->tab_ver) * ctx->tab_slot_bytes, ctx->tab_slot_bytes,
-                                hipMemcpyDeviceToDevice, ctx->stream));
-    CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->tab_rot = ctx->tab_ver;
+    const uint32_t from = ctx->tab.collapse();
+    if (from != 0) {
+      CTX_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->tables.p + (size_t)from * ctx->tab.slot_bytes, ctx->tab.slot_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
   }
   const SceneView vview = multi_version ? ctx->view(true) : view;
-  const uint32_t gen_ver_bits = (ctx->tab_slot(ctx->tab_ver) << kVerShift) |  // (0 unless an edit is in flight)
-                                (ctx->geo_phys(ctx->geo_ver + ctx->geo_slots() - ctx->geo_base) << kGeoShift);
+  const uint32_t gen_ver_bits = (ctx->tab.slot_of(ctx->tab.ver) << kVerShift) |  // (0 unless an edit is in flight)
+                                (ctx->geo.phys(ctx->geo.ver + ctx->geo.slots() - ctx->geo.base) << kGeoShift);
   // (split scene: the static tree's top goes into LDS -- every ray walks it, whatever its version)
-  const GeoRing gring{vview.geo, ctx->split ? 0u : (uint32_t)((size_t)ctx->geo_phys(ctx->geo_ver) * ctx->geo_stride * kNodeBytes),
+  const GeoRing gring{vview.geo, ctx->split ? 0u : (uint32_t)((size_t)ctx->geo.phys(ctx->geo.ver) * ctx->geo.stride * kNodeBytes),
                       ctx->split ? ctx->static_slots : 0u};
-  const uint32_t gen_stamp = ctx->geo_phys(ctx->geo_ver + ctx->geo_slots() - ctx->geo_base);
+  const uint32_t gen_stamp = ctx->geo.phys(ctx->geo.ver + ctx->geo.slots() - ctx->geo.base);
 
   CTX_TRY(ctx, hipMemsetAsync(tails_out, 0, kTailSet * sizeof(uint32_t), st));
   const bool use_memo = ctx->primary_memo && !stats_mode;
@@ -2378,7 +2422,7 @@ static int lane_enqueue(gsp_context* ctx, gsp_context::Lane& L, const RenderCons
       L.h_live[slot] = (uint32_t)paths;
       L.live_since[slot] = L.enq;  // read-backs of earlier iterations still show the slot's previous state
       P.slot_used[slot] = 1;
-      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot, ctx->tab_ver, ctx->geo_ver});
+      P.inflight.push_back(gsp_context::Batch{P.next_ts, kb, slot, ctx->tab.ver, ctx->geo.ver});
       inj += paths;
       P.next_ts += kb;
       P.remaining -= kb;
@@ -2640,13 +2684,13 @@ int gsp_render(gsp_context* ctx, const gsp_render_params* rp) {
     if (rc_ != GSP_OK) return rc_;
   }
   if (rp->collect_traversal_stats != 0 && ctx->pipe_active &&
-      (ctx->oldest_live_version() != ctx->tab_ver || ctx->oldest_live_geo() != ctx->geo_ver)) {
+      (ctx->oldest_live_version() != ctx->tab.ver || ctx->oldest_live_geo() != ctx->geo.ver)) {
     // the statistics instantiations of k_trace know one version of the scene: samples of older ones finish first
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
   if (!ctx->pipe_active) {
-    if (ctx->split) ctx->geo_base = ctx->geo_phys(ctx->geo_ver);  // (nothing in flight: stamp 0 = the current version again)
+    if (ctx->split) ctx->geo.base = ctx->geo.phys(ctx->geo.ver);  // (nothing in flight: stamp 0 = the current version again)
     // Streaming path pool, per lane.  Samples enter in batches of Kb timestamps (>= ~1M paths); a new batch
     // is injected whenever the pool has room, so every launch works on millions of paths even though 95 %
     // of a batch dies at the Russian-roulette depth and a few stragglers live for 52 bounces.  Each batch
@@ -2749,8 +2793,12 @@ extern "C" void gsp_debug_shade_profile(unsigned long long* out) {
 }
 #endif
 #ifdef GSP_WAVE_PROFILE
+// measurement build only (scripts/trace_phase_budget.py): read and clear the 2 x 24 counters of pt_wavetrace.h
 extern "C" void gsp_debug_wave_profile(unsigned long long* out) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsp::g_wave_profile), 16 * sizeof(unsigned long long));
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(gsp::g_wave_profile), 48 * sizeof(unsigned long long));
+  static const unsigned long long zero[48] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(gsp::g_wave_profile), zero, sizeof(zero));
 }
 #endif
 
@@ -2765,6 +2813,42 @@ int gsp_sync(gsp_context* ctx) {
   return GSP_OK;
 }
 
+// the two pinned staging buffers of the frame read-back (12 ms the first time: gsp_frame_begin makes them with the frame's other buffers)
+static int ensure_read_back_stage(gsp_context* ctx) {
+  for (int k = 0; k < 2; ++k) {
+    if (!ctx->h_stage[k]) CTX_TRY(ctx, hipHostMalloc((void**)&ctx->h_stage[k], gsp_context::kStageBytes, hipHostMallocDefault));
+    if (!ctx->stage_ev[k]) CTX_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+  }
+  return GSP_OK;
+}
+// the accumulate buffer -> caller's host memory, through the two pinned staging buffers (gsp_context::h_stage)
+static int read_back_frame(gsp_context* ctx, float* out) {
+  const size_t total = ctx->num_pixels * sizeof(q4);
+  if (total <= gsp_context::kStageBytes / 4) {  // small frames: one plain copy
+    CTX_TRY(ctx, hipMemcpyAsync(out, ctx->accum.p, total, hipMemcpyDeviceToHost, ctx->stream));
+    CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return GSP_OK;
+  }
+  {
+    int rc_ = ensure_read_back_stage(ctx);
+    if (rc_ != GSP_OK) return rc_;
+  }
+  const size_t chunks = (total + gsp_context::kStageBytes - 1) / gsp_context::kStageBytes;
+  const uint8_t* src = (const uint8_t*)ctx->accum.p;
+  auto bytes_of = [&](size_t c) { return std::min(gsp_context::kStageBytes, total - c * gsp_context::kStageBytes); };
+  CTX_TRY(ctx, hipMemcpyAsync(ctx->h_stage[0], src, bytes_of(0), hipMemcpyDeviceToHost, ctx->stream));
+  CTX_TRY(ctx, hipEventRecord(ctx->stage_ev[0], ctx->stream));
+  for (size_t c = 0; c < chunks; ++c) {
+    if (c + 1 < chunks) {  // (buffer (c + 1) & 1 was drained by the memcpy of chunk c - 1, below, before this point)
+      CTX_TRY(ctx, hipMemcpyAsync(ctx->h_stage[(c + 1) & 1], src + (c + 1) * gsp_context::kStageBytes, bytes_of(c + 1), hipMemcpyDeviceToHost, ctx->stream));
+      CTX_TRY(ctx, hipEventRecord(ctx->stage_ev[(c + 1) & 1], ctx->stream));
+    }
+    CTX_TRY(ctx, hipEventSynchronize(ctx->stage_ev[c & 1]));
+    std::memcpy((uint8_t*)out + c * gsp_context::kStageBytes, ctx->h_stage[c & 1], bytes_of(c));
+  }
+  return GSP_OK;
+}
+
 int gsp_download_compact(gsp_context* ctx, float* out) {
   if (!ctx || !out || !ctx->have_frame) return GSP_ERR_INVALID;
   CTX_TRY(ctx, hipSetDevice(ctx->device));
@@ -2772,9 +2856,7 @@ int gsp_download_compact(gsp_context* ctx, float* out) {
     int rc_ = pipeline_drain(ctx);
     if (rc_ != GSP_OK) return rc_;
   }
-  CTX_TRY(ctx, hipMemcpyAsync(out, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
-  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return GSP_OK;
+  return read_back_frame(ctx, out);
 }
 
 int gsp_peek(gsp_context* ctx, float* out, uint32_t* samples_folded) {
@@ -2788,8 +2870,10 @@ int gsp_peek(gsp_context* ctx, float* out, uint32_t* samples_folded) {
     CTX_TRY(ctx, hipStreamSynchronize(L.stream));
     folded = std::min(folded, ctx->pipe_active && L.pipe.active ? L.pipe.folded_end : ctx->folded_idle);
   }
-  CTX_TRY(ctx, hipMemcpyAsync(out, ctx->accum.p, ctx->num_pixels * sizeof(q4), hipMemcpyDeviceToHost, ctx->stream));
-  CTX_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    int rc_ = read_back_frame(ctx, out);
+    if (rc_ != GSP_OK) return rc_;
+  }
   if (samples_folded) *samples_folded = folded == 0xffffffffu ? 0u : folded;
   return GSP_OK;
 }
@@ -2974,7 +3058,7 @@ int gsp_trace(gsp_context* ctx, const float* rays, uint64_t n, int any_hit, void
     TestSplitIO sio;
     static_cast<TestIO&>(sio) = io;
     sio.g = GeoRing{view.geo, 0u, ctx->static_slots};
-    sio.stamp = ctx->geo_phys(ctx->geo_ver + ctx->geo_slots() - ctx->geo_base);
+    sio.stamp = ctx->geo.phys(ctx->geo.ver + ctx->geo.slots() - ctx->geo.base);
     if (any_hit)
       hipLaunchKernelGGL((k_trace<true, false, TestSplitIO>), dim3(ctx->trace_grid(n, kChunkSmall, true)), dim3(kTraceBlock), 0, ctx->stream,
                          view.nodes, view.tri_isect, (const uint32_t*)nullptr, (uint32_t)n, 0u, kChunkSmall, sio, d_work.p,

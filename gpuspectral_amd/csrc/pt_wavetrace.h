@@ -145,7 +145,10 @@ struct WaveStack {
 // [0] node steps (per wave) [1] lanes enabled in them [2] leaf steps [3] lanes enabled [4] loop passes
 // [5] refill passes [6] lanes refilled [7] lanes idle (no ray) summed over node steps [8] lanes stalled (triangles pending, no node step possible) over node steps
 // [9] node steps after the hand-out ran dry [10] lanes enabled in them
-__device__ unsigned long long g_wave_profile[16];
+// r06 (scripts/trace_phase_budget.py): [11] commit blocks executed [12] lanes committing in them [13] passes of the refill's inner
+// loop [14] node steps in which some lane fetched its record from HBM / L2 [15] lanes that did [16] node steps in which some lane
+// read the LDS copy [17] lanes that did [18] rays refilled.  One set per instantiation kind: [0][..] closest hit, [1][..] any hit
+__device__ unsigned long long g_wave_profile[2][24];
 #endif
 struct TraceStatsOut {
   unsigned long long* nodes;
@@ -158,6 +161,30 @@ struct TraceStatsOut {
   uint32_t* node_hist = nullptr;            // visits per node index / tests per triangle slot (collect_traversal_stats = 2):
   uint32_t* tri_hist = nullptr;             // which records would an LDS copy have to hold?
 };
+
+// r06 measurement builds (-DGSP_PAD_NODE=N / -DGSP_PAD_LEAF=N / -DGSP_PAD_BOOK=N): N more full-rate VALU instructions in that phase
+// of k_trace, under the phase's own exec mask, on ONE private register (no memory, no dependence on the traversal; 72 VGPRs).  The extra
+// kernel time per added instruction is what an issue slot of that phase is WORTH -- the bound on what removing slots can pay
+// (scripts/trace_phase_budget.py, profiles/r06_trace_phase_budget.txt).  Results are unchanged.
+template <int N>
+__device__ __forceinline__ void pad_valu(uint32_t& a) {
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) asm volatile("v_add_u32 %0, %0, %0\n\tv_xor_b32 %0, 0x5bd1e995, %0" : "+v"(a));
+}
+#ifndef GSP_LQ_PROXY
+#define GSP_LQ_PROXY 0  // (r06 measurement build: the machinery of a wave-level leaf queue bolted on, scripts/experiments/r06_lq_proxy.h)
+#else
+#include "../../scripts/experiments/r06_lq_proxy.h"
+#endif
+#ifndef GSP_PAD_NODE
+#define GSP_PAD_NODE 0
+#endif
+#ifndef GSP_PAD_LEAF
+#define GSP_PAD_LEAF 0
+#endif
+#ifndef GSP_PAD_BOOK
+#define GSP_PAD_BOOK 0
+#endif
 
 // lanes set in a ballot, as a 32-bit scalar: comparing the 64-bit result of __popcll with a constant is compiled
 // to a VALU v_cmp_*_u64 on broadcast values (five of them per loop pass)
@@ -257,7 +284,12 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   uint32_t c_nodes = 0, c_tris = 0, c_rays = 0, c_hits = 0, c_hit_nodes = 0, ray_nodes = 0, c_lds = 0, c_notri = 0, ray_tris = 0;  // (STATS instantiations only)
 
 #ifdef GSP_WAVE_PROFILE
-  unsigned long long wp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long wp[24] = {};
+#endif
+  uint32_t pad_a = lane;  // (GSP_PAD_* measurement builds only: unused and removed otherwise)
+#if GSP_LQ_PROXY
+  LQ_PROXY_SHARED
+  int lq_own = 0;
 #endif
   for (;;) {
 #ifdef GSP_WAVE_PROFILE
@@ -287,6 +319,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
       if (pend_m) {
         const uint64_t out_m = pend_m | __ballot(ri == 0xffffffffu);
         if (wave_count(out_m) >= GSP_BATCH_COMMIT || out_m == ~0ull) {
+#ifdef GSP_WAVE_PROFILE
+          ++wp[11];
+          wp[12] += __popcll(pend_m);
+#endif
           if (pending) {
             io.store(ri, h, best_id & 7u, pay);
             ri = 0xffffffffu;
@@ -319,6 +355,9 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           pool_next = (uint32_t)start;
           pool_end = (uint32_t)(start + chunk < n ? start + chunk : n);
         }
+#ifdef GSP_WAVE_PROFILE
+        ++wp[13];
+#endif
         // set bits of idle_m below this lane (v_mbcnt: no per-lane mask register)
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
         const uint32_t avail = pool_end - pool_next;
@@ -347,6 +386,9 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           }
         }
         const uint32_t want = (uint32_t)__popcll(idle_m);
+#ifdef GSP_WAVE_PROFILE
+        wp[18] += want < avail ? want : avail;
+#endif
         pool_next += want < avail ? want : avail;
         idle_m = __ballot(ri == 0xffffffffu);
       }
@@ -354,6 +396,7 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
     // ---- what can run? -------------------------------------------------------------------------
     // a lane takes a node step when it has a child node to visit and room for the triangle group the step may produce
     constexpr bool kPostpone = (ANY ? GSP_POSTPONE_ANY : GSP_POSTPONE_CLOSEST) != 0;
+    if constexpr (GSP_PAD_BOOK > 0) pad_valu<GSP_PAD_BOOK>(pad_a);
     const bool on_node = !group_empty<ANY>(gs) && tris_empty(kPostpone ? tm2 : tm);
     const uint64_t node_m = __ballot(on_node);
     const uint64_t leaf_m = __ballot(!tris_empty(tm));
@@ -396,12 +439,18 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           wp[10] += __popcll(__ballot(on));
         }
 #endif
+#ifdef GSP_WAVE_PROFILE
+        bool wp_from_lds = false;  // (counted behind the block, by all lanes: lane 0 reports and may not be `on`)
+#endif
         if (on) {
           // the nearest child of the current group (32-bit offset + uniform base, no 64-bit address arithmetic)
           const uint32_t noff_v = group_next<ANY>(gb, gs, rb, tab);
           const uint32_t noff = IO::kVersioned ? noff_v + node_off : noff_v;        // offset from `nodes`
           const uint32_t loff = IO::kVersioned ? noff - top_off : noff;             // offset inside the LDS copy, if below its size
           q4 nq[kNodeQuads];
+#ifdef GSP_WAVE_PROFILE
+          wp_from_lds = kTopNodes > 0 && loff < kTopNodes * kNodeBytes;
+#endif
           if (kTopNodes > 0 && loff < kTopNodes * kNodeBytes) {
             const lds_v4f* nd = (const lds_v4f*)((const __attribute__((address_space(3))) char*)lds_top + loff);
 #pragma unroll
@@ -422,6 +471,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           }
           uint32_t ngb, ngs, ntb, ntm;
           node_step<ANY>(nq, rb, tmin, h.t, tab, ngb, ngs, ntb, ntm);
+          if constexpr (GSP_PAD_NODE > 0) pad_valu<GSP_PAD_NODE>(pad_a);
+#if GSP_LQ_PROXY
+          LQ_PROXY_NODE(ntb, ntm)
+#endif
           if (!group_empty<ANY>(ngs)) {  // descend: the rest of the current group waits on the stack
             if (!group_empty<ANY>(gs)) stk.push_group(gb, gs);
             gb = ngb;
@@ -439,6 +492,15 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
             }
           }
         }
+#ifdef GSP_WAVE_PROFILE
+        {
+          const uint64_t lm = __ballot(on && wp_from_lds), hm = __ballot(on && !wp_from_lds);
+          wp[14] += hm != 0;
+          wp[15] += __popcll(hm);
+          wp[16] += lm != 0;
+          wp[17] += __popcll(lm);
+        }
+#endif
       }
       continue;
     }
@@ -464,12 +526,27 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
       float t, u, v, aw;
       asm("" : "=v"(t), "=v"(u), "=v"(v), "=v"(aw));  // any value
       bool hit = false;
+#if GSP_LQ_PROXY
+      f3 lq_o = rb.o;
+      RayShearRot lq_rs = rs;
+      float lq_tmax = tmax;
+      LQ_PROXY_LEAF_GATHER(lq_o, lq_rs, lq_tmax)
+      if (act) {
+        const q4* p = tris + 3ll * (IO::kVersioned ? slot + tri_base : slot);
+        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
+        aw = p0.w;
+        hit = intersect_tri_rot(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), lq_o, lq_rs, tmin, lq_tmax, t, u, v);
+      }
+      LQ_PROXY_LEAF_MERGE(hit, t, u, v, __float_as_uint(aw), slot, t)
+#else
       if (act) {
         const q4* p = tris + 3ll * (IO::kVersioned ? slot + tri_base : slot);
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
         aw = p0.w;
         hit = intersect_tri_rot(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u, v);
+        if constexpr (GSP_PAD_LEAF > 0) pad_valu<GSP_PAD_LEAF>(pad_a);
       }
+#endif
       if (STATS) {
         c_tris += act ? 1u : 0u;
         ray_tris += act ? 1u : 0u;
@@ -500,9 +577,10 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   }
 #undef tmin
 #undef tmax
+  if constexpr (GSP_PAD_NODE + GSP_PAD_LEAF + GSP_PAD_BOOK > 0) asm volatile("" ::"v"(pad_a));
 #ifdef GSP_WAVE_PROFILE
-  if (lane == 0 && !ANY)
-    for (int k = 0; k < 12; ++k) atomicAdd(&g_wave_profile[k], wp[k]);
+  if (lane == 0)
+    for (int k = 0; k < 24; ++k) atomicAdd(&g_wave_profile[ANY ? 1 : 0][k], wp[k]);
 #endif
   if (STATS) {
     const unsigned long long a = wave_sum_u64(c_nodes), b = wave_sum_u64(c_tris), c = wave_sum_u64(c_rays);

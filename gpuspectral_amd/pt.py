@@ -157,7 +157,7 @@ def build_info():
 
 
 # the files csrc/Makefile hashes into the digest, in its order
-DIGEST_SOURCES = ("pt_render.hip", "pt_bvh.hip", "pt_multi.hip", "pt_wavetrace.h", "pt_hostmath.h", "pt_math.h", "pt_shading.h",
+DIGEST_SOURCES = ("pt_render.hip", "pt_bvh.hip", "pt_multi.hip", "pt_wavetrace.h", "pt_versions.h", "pt_hostmath.h", "pt_math.h", "pt_shading.h",
                   "pt_trace.h", "pt_stages.h", "pt_internal.h", "../../include/gpuspectral_pt.h")
 
 
@@ -276,8 +276,11 @@ class Context:
         self._check(self._L.gsp_peek(self._h, out.ctypes.data, C.byref(folded)), "gsp_peek")
         return out, int(folded.value)
 
-    def download(self):
-        out = np.zeros((self.height, self.width, 4), np.float32)
+    def download(self, out=None):
+        """The frame as (height, width, 4) float32; `out`: the caller's own framebuffer (C-contiguous float32 of that size)."""
+        if out is None:
+            out = np.zeros((self.height, self.width, 4), np.float32)
+        assert out.dtype == np.float32 and out.size == self.height * self.width * 4 and out.flags.c_contiguous
         self._check(self._L.gsp_download(self._h, out.ctypes.data), "gsp_download")
         return out
 

@@ -394,7 +394,8 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
  *                         the instances edited so far and the rest (gsp_stats.scene_splits; no wait the first time) -- and later
  *                         edits of those instances refit only their small tree (0.08 ms) into the next slot of a ring of
  *                         up to 64 versions while the samples in flight finish in theirs.  Scenes that do not split (more
- *                         than a quarter of the triangles edited, textures, the ninth split) keep a ring of whole refitted
+ *                         than a quarter of the triangles edited, textures, a host that has touched new objects 16 times since the upload --
+ *                         kMaxSceneSplits = 16, gpuspectral_amd/csrc/pt_versions.h) keep a ring of whole refitted
  *                         trees instead (176 B per triangle and version, at most a quarter of the free device memory).
  *                         A rebuild, a ring without a free slot or a scene above 8 M triangles first complete the samples
  *                         already queued; an edit that arrives with nothing in flight refits in place.
@@ -402,7 +403,10 @@ int gsp_upload_scene(gsp_context* ctx, const gsp_scene_desc* scene);
  *                         ones (all other fields of `scene` are ignored); every resident instance's handle must stay in
  *                         range.  No geometry work.  Textured scenes (dormant-feature extension): has_texture values are
  *                         checked against the resident textures.  Same record counts as the resident tables: the next slot
- *                         of a ring of 64 versions, no wait; other counts first complete the samples already queued.
+ *                         of a ring of versions, no wait; other counts first complete the samples already queued.  The ring
+ *                         is made by the first such edit that arrives with samples in flight (gsp_upload_scene holds ONE
+ *                         copy of the tables): up to 64 versions, at most a sixteenth of the free device memory and 1 GiB
+ *                         (a 64-MB light table gets 16); where not even two fit, edits wait as they did before the ring.
  */
 int gsp_update_camera(gsp_context* ctx, const gsp_camera* camera);
 int gsp_update_instances(gsp_context* ctx, const gsp_instance* instances, uint32_t num_instances);
