@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-GSP_ABI_VERSION = 7
+GSP_ABI_VERSION = 8
 
 BSDF_DIFFUSE = 0
 BSDF_SMOOTH_DIELECTRIC = 1
@@ -129,6 +129,7 @@ class SceneDesc(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),  # (ABI 8) sizeof the host's struct; 0 = the ABI-8 layout
         ("spp", C.c_uint32),
         ("first_timestamp", C.c_uint32),
         ("max_depth", C.c_uint32),
@@ -143,7 +144,7 @@ class RenderParams(C.Structure):
 
 def default_render_params(spp=1, first_timestamp=0):
     """The reference's shader literals: raygen.rgen:27,60,66; rayhit.rchit:656."""
-    return RenderParams(spp, first_timestamp, 50, 10, 20.0, 0, 0, 0, 0)
+    return RenderParams(C.sizeof(RenderParams), spp, first_timestamp, 50, 10, 20.0, 0, 0, 0, 0)
 
 
 GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2

@@ -103,7 +103,7 @@ void PathTracer::check(int rc, const char* what) {
 
 // PathTracer.cpp:5-7
 void PathTracer::setup() {
-  // gsp_render_params / gsp_stats carry no struct_size: the header this file was compiled against must be the library's
+  // gsp_stats carries no struct_size (the library fills it at ITS size): the header this file was compiled against must be the library's
   if (gsp_abi_version() != GSP_ABI_VERSION)
     throw std::runtime_error("libgpuspectral_pt.so has ABI " + std::to_string(gsp_abi_version()) + ", this host was built against ABI " +
                              std::to_string(GSP_ABI_VERSION));

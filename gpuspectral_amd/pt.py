@@ -157,7 +157,7 @@ def build_info():
 
 
 # the files csrc/Makefile hashes into the digest, in its order
-DIGEST_SOURCES = ("pt_render.hip", "pt_bvh.hip", "pt_multi.hip", "pt_wavetrace.h", "pt_versions.h", "pt_hostmath.h", "pt_math.h", "pt_shading.h",
+DIGEST_SOURCES = ("pt_render.hip", "pt_bvh.hip", "pt_multi.hip", "pt_render_kernels.inc", "pt_render_scene.inc", "pt_render_pipeline.inc", "pt_wavetrace.h", "pt_versions.h", "pt_hostmath.h", "pt_math.h", "pt_shading.h",
                   "pt_trace.h", "pt_stages.h", "pt_internal.h", "../../include/gpuspectral_pt.h")
 
 

@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define GSP_ABI_VERSION 7 /* 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth;
+#define GSP_ABI_VERSION 8 /* 8: gsp_render_params.struct_size (first field); 2: gsp_multi_*, gsp_tile_partition, gsp_stats.algorithmic_bytes; 4: gsp_stats.memoised_rays, memo_build_rays, bvh_depth;
                              5: gsp_update_camera / _instances / _tables (+ gsp_multi_*), gsp_ctx_options + gsp_ctx_create_ex /
                                 gsp_multi_create_ex, gsp_render_params.nee, gsp_stats.scene_updates;
                              6: gsp_update_instances refits the tree (gsp_ctx_options.refit_growth, gsp_stats.scene_refits);
@@ -238,6 +238,10 @@ typedef struct gsp_scene_desc {
  * roulette when depth > 10 (raygen.rgen:66), firefly cutoff 20 (raygen.rgen:60).
  */
 typedef struct gsp_render_params {
+  uint32_t struct_size;     /* (ABI 8) sizeof(gsp_render_params) of the host's header; gsp_default_render_params sets it.  The library
+                               reads min(struct_size, its own size) bytes and takes the fields beyond as 0 (= the reference's
+                               behaviour, for every field added so far and from here on), so a host built against an older
+                               header of ABI >= 8 keeps working.  0 (a zero-initialised struct) = the ABI-8 layout */
   uint32_t spp;             /* samples per pixel to add in this call      */
   uint32_t first_timestamp; /* RenderParams.timestamp of the first sample */
   uint32_t max_depth;
@@ -310,9 +314,9 @@ typedef struct gsp_context gsp_context;
 /* Fill `p` with the reference's literals.  */
 void gsp_default_render_params(gsp_render_params* p);
 
-/* ABI version of the loaded library (== GSP_ABI_VERSION of this header).  gsp_render_params and gsp_stats carry no
- * struct_size: a C host MUST check gsp_abi_version() == GSP_ABI_VERSION once after loading the library (a host built
- * against an older header would hand gsp_render a shorter struct); gpuspectral_amd/pt.py and host/PathTracer.cpp do. */
+/* ABI version of the loaded library (== GSP_ABI_VERSION of this header).  gsp_stats carries no struct_size (the library FILLS it
+ * at its own size): a C host MUST check gsp_abi_version() == GSP_ABI_VERSION once after loading the library;
+ * gpuspectral_amd/pt.py and host/PathTracer.cpp do.  gsp_render_params and gsp_ctx_options are sized by their first field. */
 int gsp_abi_version(void);
 
 /* What the loaded library was built from: "arch=gfx950 digest=<sha256[:16] of csrc/{pt_render,pt_bvh,pt_multi}.hip + the

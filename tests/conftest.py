@@ -103,6 +103,7 @@ class Emu:
         so = os.path.join(d, "libpt_emu.so")
         src = os.path.join(d, "pt_emu.cpp")
         hdrs = [os.path.join(ROOT, "gpuspectral_amd", "csrc", h) for h in os.listdir(os.path.join(ROOT, "gpuspectral_amd", "csrc")) if h.endswith(".h")]
+        hdrs.append(os.path.join(ROOT, "include", "gpuspectral_pt.h"))  # (the ABI structs: gsp_render_params grew a field in ABI 8)
         newest = max(os.path.getmtime(p) for p in [src] + hdrs)
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
             subprocess.check_call(

@@ -105,7 +105,9 @@ def test_default_params_are_the_reference_literals():
     pt.load().gsp_default_render_params(C.byref(p))
     assert (p.spp, p.first_timestamp, p.max_depth, p.rr_start_depth, p.clamp) == (1, 0, 50, 10, 20.0)
     assert p.disable_nee == 0  # `#define NEE true`, rayhit.rchit:656
+    assert p.struct_size == C.sizeof(abi.RenderParams) and abi.RenderParams.struct_size.offset == 0  # (ABI 8: first field)
     q = abi.default_render_params()
+    assert q.struct_size == C.sizeof(abi.RenderParams)
     assert (q.max_depth, q.rr_start_depth, q.clamp, q.disable_nee) == (50, 10, 20.0, 0)
 
 
@@ -134,7 +136,7 @@ def test_library_reads_no_environment_and_links_no_rccl():
 
     csrc = os.path.join(ROOT, "gpuspectral_amd", "csrc")
     for f in os.listdir(csrc):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".inc")):
             txt = open(os.path.join(csrc, f)).read()
             assert "getenv" not in txt, f
             assert "GSP_WIDE" not in txt, f  # the rejected 8-wide variant is history, not a macro in the hot path

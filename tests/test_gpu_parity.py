@@ -772,6 +772,33 @@ def test_zeroed_render_params_are_the_reference(ctx, oracle_mod, cornell):
     assert np.array_equal(img, ref) and st["shadow_rays"] == ost["shadow_rays"] > 0
 
 
+def test_render_params_struct_size(ctx, oracle_mod, cornell):
+    """ABI 8: gsp_render_params is sized by its first field.  A host whose struct is LONGER than the library's (a newer header) is
+    read up to the library's size; one shorter than the ABI-8 layout is refused with a message, not read past its end."""
+    import ctypes as C
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import abi
+
+    ctx.upload_scene(cornell)
+    ctx.frame_begin(32, 24)
+    ref, _ = oracle_mod.Oracle(cornell).render(32, 24, spp=2)
+
+    class Longer(C.Structure):
+        _fields_ = [("p", abi.RenderParams), ("future_field", C.c_uint32 * 4)]
+
+    big = Longer()
+    big.p = abi.default_render_params(2, 0)
+    big.p.struct_size = C.sizeof(Longer)
+    big.future_field[0] = 0xDEADBEEF  # (not read: beyond the library's struct)
+    ctx._check(ctx._L.gsp_render(ctx._h, C.cast(C.byref(big), C.POINTER(abi.RenderParams))), "gsp_render")
+    assert np.array_equal(ctx.download().reshape(-1, 4), ref)
+    small = abi.default_render_params(2, 0)
+    small.struct_size = 12
+    with pytest.raises(g.pt.GspError, match="struct_size"):
+        ctx.render(spp=2, params=small)
+
+
 def test_random_scene_fuzz_matches_oracle(ctx, oracle_mod):
     """tests/tools/fuzz_parity.py: random small scenes with all eight BSDF types at ordinary and extreme parameters,
     mirrored / non-uniformly scaled instances, several lights, random cameras: frames (NaN pixels included) and

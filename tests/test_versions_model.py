@@ -56,7 +56,8 @@ def test_product_and_documentation_agree_on_the_limits():
     splits = int(re.search(r"kMaxSceneSplits = (\d+);", hdr).group(1))
     api = open(os.path.join(ROOT, "include", "gpuspectral_pt.h")).read()
     assert "kMaxSceneSplits = %d" % splits in api or "%d times" % splits in api, "the ABI header must quote the split limit"
-    render = open(os.path.join(ROOT, "gpuspectral_amd", "csrc", "pt_render.hip")).read()
+    csrc = os.path.join(ROOT, "gpuspectral_amd", "csrc")
+    render = "".join(open(os.path.join(csrc, f)).read() for f in ("pt_render.hip", "pt_render_kernels.inc", "pt_render_scene.inc", "pt_render_pipeline.inc"))
     assert "scene_splits >= kMaxSceneSplits" in render and not re.search(r"scene_splits >= \d", render)
     stages = open(os.path.join(ROOT, "gpuspectral_amd", "csrc", "pt_stages.h")).read()
     assert int(re.search(r"kTableVersions = (\d+)", stages).group(1)) == int(re.search(r"kMaxTableVersions = (\d+);", hdr).group(1))
