@@ -73,7 +73,7 @@ def pmc_for_run(config, timed_launches, digest, kernel_digest=None):
     equals the loaded library's; files from before r05 carry only the library's source digest and must match that."""
     import glob
 
-    want = {k: config[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}
+    want = {k: config[k] for k in ("workload", "triangles", "resolution", "spp_per_step")}  # (launch_shape: compared below, not here)
     if "primary_memo" in config:  # (the launches of a run without the primary-hit memo trace other ray sets)
         want["primary_memo"] = config["primary_memo"]
     cands, stale = [], 0
@@ -92,8 +92,14 @@ def pmc_for_run(config, timed_launches, digest, kernel_digest=None):
         cands.append((path, cand))
     if not cands:
         return None, ("stale build: %d PMC file(s) of this workload were taken with other device code (kernel / library digest)" % stale) if stale else "no PMC file for this workload"
+    def same_shape(c):  # (files from before r06 carry no launch_shape: launch count + command line decide, as they did)
+        ls, mine = c.get("launch_shape"), config.get("launch_shape")
+        if not ls or not mine:
+            return True
+        return all(ls.get(k) and mine.get(k) and abs(ls[k] / mine[k] - 1.0) < 0.005 for k in ("extension_rays", "shadow_rays"))
+
     exact = [(p, c) for p, c in cands if c.get("timed_launches") == timed_launches and c.get("steps") == config.get("steps")
-             and c.get("warmup") == config.get("warmup")]
+             and c.get("warmup") == config.get("warmup") and same_shape(c)]
     if exact:
         pm_path, pm = exact[0]
         scale = None
@@ -490,7 +496,8 @@ def _main():
         ext_traced0 = st["extension_rays"] - st["memoised_rays"] + st["memo_build_rays"]
         alg_bytes = ext_traced0 * b_ray
         cfg_key = {"workload": scene_name, "triangles": int(st["num_triangles"]), "resolution": "%dx%d" % (W, H), "spp_per_step": S,
-                   "steps": args.steps, "warmup": args.warmup, "primary_memo": bool(st["memoised_rays"] > 0)}
+                   "steps": args.steps, "warmup": args.warmup, "primary_memo": bool(st["memoised_rays"] > 0),
+                   "launch_shape": {"extension_rays": int(traced_ext), "shadow_rays": int(sh_rays)}}
         digest = g.pt.build_info()["digest"]
         # class tables + the digest of the render kernels' instruction streams, written next to the library by csrc/Makefile
         mixf = os.path.join(os.path.dirname(g.lib_path()), "valu_mix.json")

@@ -598,3 +598,9 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 }
 
 }  // namespace gsp
+
+#ifndef GSP_LEAFQ
+#define GSP_LEAFQ 0  // r06 experiment: the same kernel with a wave-level leaf queue (scripts/experiments/r06_pt_wavetrace_lq.h)
+#else
+#include "../../scripts/experiments/r06_pt_wavetrace_lq.h"
+#endif

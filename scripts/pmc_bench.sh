@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline $*"
+ARGS="--no-cpu-baseline --no-other-workloads $*"
 run() { # name, counters
   timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python3 $ROOT/bench.py $ARGS > $OUT/$1.log 2>&1 || echo "pass $1 failed"
 }

@@ -127,6 +127,11 @@ def main(root):
             out["library_digest"] = b["config"].get("library_digest")
             out["kernel_digest"] = b["config"].get("kernel_digest")  # bench.py refuses the file for any other device code
             out["bench_value_under_profiler"] = b["value"]
+            # what the host made of this workload: launch count and work per launch of the timed region.  bench.py takes the file as
+            # an EXACT match only when its own run agrees (a host-side change of the pool / chunk / grid heuristics moves these while
+            # the kernels' instruction streams -- kernel_digest -- stay the same: r05 ADVICE)
+            out["launch_shape"] = {"extension_rays": b["config"].get("extension_rays"), "shadow_rays": b["config"].get("shadow_rays"),
+                                   "launches": b["roofline"]["launches"]}
             print("== bench under the kernel-trace pass: %.1f %s, %d timed k_trace<ExtendIO> launches of %.3f ms (HIP events)" % (
                 b["value"], b["unit"], b["roofline"]["launches"], b["roofline"]["avg_launch_ms"]))
             k = out["kernels"].get("k_trace_extend")

@@ -91,7 +91,9 @@ def rate(op):
 def kernel_body(text, sym):
     m = re.search(r"^(%s[^\n:]*):" % ("_Z[^\n:]*" + re.escape(sym)), text, re.M)
     start = m.end()
-    end = text.index("s_endpgm", start)
+    # to the END of the function (.Lfunc_endN), not to the first s_endpgm: a kernel with an early exit has code behind it
+    # (r05 ADVICE: the digest must cover the whole instruction stream)
+    end = re.compile(r"^\.Lfunc_end\d+:", re.M).search(text, start).start()
     return m.group(1), text[start:end]
 
 
