@@ -171,11 +171,6 @@ __device__ __forceinline__ void pad_valu(uint32_t& a) {
 #pragma unroll
   for (int i = 0; i < N / 2; ++i) asm volatile("v_add_u32 %0, %0, %0\n\tv_xor_b32 %0, 0x5bd1e995, %0" : "+v"(a));
 }
-#ifndef GSP_LQ_PROXY
-#define GSP_LQ_PROXY 0  // (r06 measurement build: the machinery of a wave-level leaf queue bolted on, scripts/experiments/r06_lq_proxy.h)
-#else
-#include "../../scripts/experiments/r06_lq_proxy.h"
-#endif
 #ifndef GSP_PAD_NODE
 #define GSP_PAD_NODE 0
 #endif
@@ -287,10 +282,6 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
   unsigned long long wp[24] = {};
 #endif
   uint32_t pad_a = lane;  // (GSP_PAD_* measurement builds only: unused and removed otherwise)
-#if GSP_LQ_PROXY
-  LQ_PROXY_SHARED
-  int lq_own = 0;
-#endif
   for (;;) {
 #ifdef GSP_WAVE_PROFILE
     ++wp[4];
@@ -472,9 +463,6 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
           uint32_t ngb, ngs, ntb, ntm;
           node_step<ANY>(nq, rb, tmin, h.t, tab, ngb, ngs, ntb, ntm);
           if constexpr (GSP_PAD_NODE > 0) pad_valu<GSP_PAD_NODE>(pad_a);
-#if GSP_LQ_PROXY
-          LQ_PROXY_NODE(ntb, ntm)
-#endif
           if (!group_empty<ANY>(ngs)) {  // descend: the rest of the current group waits on the stack
             if (!group_empty<ANY>(gs)) stk.push_group(gb, gs);
             gb = ngb;
@@ -526,19 +514,6 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
       float t, u, v, aw;
       asm("" : "=v"(t), "=v"(u), "=v"(v), "=v"(aw));  // any value
       bool hit = false;
-#if GSP_LQ_PROXY
-      f3 lq_o = rb.o;
-      RayShearRot lq_rs = rs;
-      float lq_tmax = tmax;
-      LQ_PROXY_LEAF_GATHER(lq_o, lq_rs, lq_tmax)
-      if (act) {
-        const q4* p = tris + 3ll * (IO::kVersioned ? slot + tri_base : slot);
-        const q4 p0 = p[0], p1 = p[1], p2 = p[2];
-        aw = p0.w;
-        hit = intersect_tri_rot(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), lq_o, lq_rs, tmin, lq_tmax, t, u, v);
-      }
-      LQ_PROXY_LEAF_MERGE(hit, t, u, v, __float_as_uint(aw), slot, t)
-#else
       if (act) {
         const q4* p = tris + 3ll * (IO::kVersioned ? slot + tri_base : slot);
         const q4 p0 = p[0], p1 = p[1], p2 = p[2];
@@ -546,7 +521,6 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
         hit = intersect_tri_rot(mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), mk3(p2.x, p2.y, p2.z), rb.o, rs, tmin, tmax, t, u, v);
         if constexpr (GSP_PAD_LEAF > 0) pad_valu<GSP_PAD_LEAF>(pad_a);
       }
-#endif
       if (STATS) {
         c_tris += act ? 1u : 0u;
         ray_tris += act ? 1u : 0u;
@@ -599,8 +573,3 @@ __global__ __launch_bounds__(kTraceBlock, ANY ? GSP_TRACE_WAVES_ANY : GSP_TRACE_
 
 }  // namespace gsp
 
-#ifndef GSP_LEAFQ
-#define GSP_LEAFQ 0  // r06 experiment: the same kernel with a wave-level leaf queue (scripts/experiments/r06_pt_wavetrace_lq.h)
-#else
-#include "../../scripts/experiments/r06_pt_wavetrace_lq.h"
-#endif

@@ -12,6 +12,9 @@
 // The gathered values FEED the triangle test (or-ed in under an opaque zero), so the LDS round trips sit on the step's dependent
 // chain as they would in the real thing.  In the real queue a leaf step runs 2.3 x less often than here (4.1 instead of 9.4 per 64
 // rays) and a node step 0.8 x as often: scale the measured cost accordingly (scripts/trace_phase_budget.py does).
+// HOOKS (removed from the product after the measurement; live in commit 62b6528): pt_wavetrace.h includes this file when GSP_LQ_PROXY is
+// set and calls LQ_PROXY_SHARED behind the loop's locals, LQ_PROXY_NODE behind node_step and LQ_PROXY_LEAF_GATHER / _MERGE around the
+// triangle test.  RESULT: profiles/r06_ab_leaf_queue_proxy.txt.
 #pragma once
 
 #define LQ_PROXY_SHARED                                                            \

@@ -16,6 +16,10 @@
 // Budget: 6 waves per SIMD (the leaf step holds the lane's own ray AND the owner's: ~80 VGPRs; at 72 it spills, r06_lq_proxy.h),
 // LDS per block 13 stack levels (13 KB) + step table 2 KB + top of the tree 4 KB + 4 rings x 1 KB + records 2 KB + done 1 KB +
 // winner bytes 256 B = 26 880 B: six blocks per CU.
+// HOOKS (removed from the product after the measurement; live in commit 62b6528): pt_wavetrace.h includes this file behind k_trace when
+// GSP_LEAFQ is set, and pt_render_pipeline.inc launches k_trace_lq<false, ExtendIO> / k_trace_lq<true, ConnectIO> (grid capped at
+// num_cus x GSP_LQ_WAVES) in place of the plain k_trace launches for bits 1 / 2.  RESULT: bit-exact, +23 % / +28 % kernel time:
+// profiles/r06_ab_leaf_queue.txt.
 #pragma once
 
 namespace gsp {
