@@ -146,6 +146,36 @@ def test_product_headers_equal_the_executed_shader_text(emu, vec, tables):
         assert [int(x) for x in got] == [int(x) for x in vec["helpers"][i]], (i, f, g)
 
 
+def _image_cases(vec):
+    sys.path.insert(0, GOLDEN)
+    import make_glsl_vectors as M
+
+    for name, (w, h, spp) in M.IMAGES.items():
+        yield name, M.image_scene(name), w, h, spp, vec["img_" + name].reshape(-1, 4), vec["img_" + name + "_rays"]
+
+
+def test_oracle_image_equals_the_executed_shaders(oracle_mod, vec):
+    """Second step (r06): not only the pure functions but the shaders' main() functions -- raygen.rgen:29-108 (camera ray, bounce
+    loop, firefly cutoff, Russian roulette, running mean), rayhit.rchit:666-797 (the closest-hit shader: normals, twofaced flip, Onb,
+    sampleBSDF / sampleLight / evalBSDF, the NEE branch with its shadow ray, MIS weights, the termination tests, the payload
+    update), miss.rmiss, shadowmiss.rmiss -- were compiled from the reference's text and run for whole frames; traceRayEXT's
+    traversal is the oracle's (the driver's is vendor-opaque, oracle/README.md).  The oracle's restatement of those lines must produce
+    the same frame, bit for bit, and trace the same number of extension and shadow rays.  Cornell box (the reference's scene.xml)
+    96 x 96 x 8 spp; Cornell + all eight BSDF types (glass: delta paths to depth 50) 96 x 80 x 4 spp."""
+    for name, sc, w, h, spp, img, rays in _image_cases(vec):
+        got, st = oracle_mod.Oracle(sc).render(w, h, spp=spp)
+        assert np.array_equal(got.view(np.uint32), img.view(np.uint32)), (name, int((got != img).any(axis=1).sum()))
+        assert (st["extension_rays"], st["shadow_rays"]) == (int(rays[0]), int(rays[1])), name
+        assert np.isfinite(img).all() and img[:, :3].mean() > 0.05 and rays[1] > 0.3 * rays[0]
+
+
+def test_product_stage_headers_image_equals_the_executed_shaders(emu, vec):
+    """... and so must the product's own per-path stage code (pt_stages.h / pt_shading.h / pt_trace.h compiled for the host)."""
+    for name, sc, w, h, spp, img, _ in _image_cases(vec):
+        got = emu.scene(sc).render(w, h, spp=spp)
+        assert np.array_equal(got.view(np.uint32), img.view(np.uint32)), (name, int((got != img).any(axis=1).sum()))
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is mounted in the build container only")
 def test_fixture_is_what_the_reference_text_produces_today():
     """Where /root/reference exists: rebuild oracle/_ref/libglsl_ref.so from the shader files where they lie and regenerate

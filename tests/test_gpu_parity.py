@@ -958,3 +958,27 @@ def test_random_call_sequences_equal_one_shot_renders(oracle_mod):
     finally:
         a.close()
         b.close()
+
+
+def test_gpu_frames_equal_the_executed_reference_shaders(ctx):
+    """The HIP path against frames produced by the reference's OWN shader text -- raygen.rgen / rayhit.rchit / the miss shaders
+    compiled as C++ through oracle/glsl_shim.h and run over the oracle's traversal (tests/golden/make_glsl_vectors.py; fixture
+    tests/golden/glsl_vectors.npz, the only thing that travels) -- bit for bit, with no oracle render in between on this box."""
+    import sys
+
+    from conftest import GOLDEN
+
+    sys.path.insert(0, GOLDEN)
+    import make_glsl_vectors as M
+
+    with np.load(os.path.join(GOLDEN, "glsl_vectors.npz")) as z:
+        for name, (w, h, spp) in M.IMAGES.items():
+            want, rays = z["img_" + name], z["img_" + name + "_rays"]
+            ctx.upload_scene(M.image_scene(name))
+            ctx.frame_begin(w, h)
+            ctx.reset_stats()
+            ctx.render(spp=spp)
+            got = ctx.download()
+            st = ctx.stats()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, int((got != want).any(axis=2).sum()))
+            assert (st["extension_rays"], st["shadow_rays"]) == (int(rays[0]), int(rays[1])), name
