@@ -136,6 +136,7 @@ struct gsp_context {
   static constexpr size_t kStageBytes = 4u << 20;
   uint8_t* h_stage[2] = {nullptr, nullptr};
   hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  bool stage_warm = false;  // the staging buffers have been through one copy + one host read (gsp_frame_begin)
   DevBuf<float> trace_rays;  // gsp_trace: grow-only staging, kept across calls
   DevBuf<q4> trace_hits;
   DevBuf<uint32_t> trace_work;
