@@ -226,6 +226,10 @@ def run(lib):
 # whole frames through the shaders' main() functions (raygen.rgen:29-108, rayhit.rchit:666-797, the two miss shaders): name ->
 # (scene, width, height, spp).  The driver's traversal is the oracle's (oracle_trace); everything else is the reference's text.
 IMAGES = {"cornell": (96, 96, 8), "materials": (96, 80, 4)}
+# ... and random scenes of the parity fuzzer (tests/tools/fuzz_parity.py::random_scene: every BSDF type at ordinary and EXTREME
+# parameters -- alpha 1e-4, ior 1, zero / > 1 reflectance, k = 50 --, mirrored and sheared instance transforms, several lights, random
+# cameras): the corners where NaN / inf handling and the termination tests of rayhit.rchit:770-784 decide the image
+IMAGES.update({"fuzz%d" % seed: (40, 28, 3) for seed in range(1100000, 1100024)})
 
 
 def image_scene(name):
@@ -234,6 +238,11 @@ def image_scene(name):
 
     if name == "cornell":
         return ml.load_scene(os.path.join(HERE, "cornell-box", "scene.xml"))
+    if name.startswith("fuzz"):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+        import fuzz_parity
+
+        return fuzz_parity.random_scene(int(name[4:]))
     return scenes.cornell_materials(8)  # all eight BSDF types, glass (deep delta paths), a mirror
 
 

@@ -161,12 +161,14 @@ def test_oracle_image_equals_the_executed_shaders(oracle_mod, vec):
     update), miss.rmiss, shadowmiss.rmiss -- were compiled from the reference's text and run for whole frames; traceRayEXT's
     traversal is the oracle's (the driver's is vendor-opaque, oracle/README.md).  The oracle's restatement of those lines must produce
     the same frame, bit for bit, and trace the same number of extension and shadow rays.  Cornell box (the reference's scene.xml)
-    96 x 96 x 8 spp; Cornell + all eight BSDF types (glass: delta paths to depth 50) 96 x 80 x 4 spp."""
+    96 x 96 x 8 spp; Cornell + all eight BSDF types (glass: delta paths to depth 50) 96 x 80 x 4 spp; 24 random scenes of the parity
+    fuzzer (extreme BSDF parameters, mirrored / sheared transforms) 40 x 28 x 3 spp: 1.07 M rays through the executed shaders."""
     for name, sc, w, h, spp, img, rays in _image_cases(vec):
         got, st = oracle_mod.Oracle(sc).render(w, h, spp=spp)
         assert np.array_equal(got.view(np.uint32), img.view(np.uint32)), (name, int((got != img).any(axis=1).sum()))
         assert (st["extension_rays"], st["shadow_rays"]) == (int(rays[0]), int(rays[1])), name
-        assert np.isfinite(img).all() and img[:, :3].mean() > 0.05 and rays[1] > 0.3 * rays[0]
+        if not name.startswith("fuzz"):  # (the two lit rooms; a random scene may be dark or all-delta)
+            assert np.isfinite(img).all() and img[:, :3].mean() > 0.05 and rays[1] > 0.3 * rays[0]
 
 
 def test_product_stage_headers_image_equals_the_executed_shaders(emu, vec):
