@@ -227,10 +227,16 @@ def cpu_baseline(sc, args, scene_name):
     ids1 = scenes.tile_pixel_ids(W, H, 0, max(1, int(round(W * H * per_px / max(2.0 * rate / max(threads, 1), 1.0)))), tile=16)
     _, st1 = o.render(W, H, spp=1, pixel_ids=ids1, threads=1)
     rate1 = (st1["extension_rays"] + st1["shadow_rays"]) / max(st1["seconds"], 1e-9) / 1e6
+    cpu_model = None
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {
         "value": rays / st["seconds"] / 1e6,
         "unit": "Mrays/s",
         "cores": threads,
+        "cpu_model": cpu_model,  # core count and CPU model next to the figure
         "kind": "port",
         "single_thread_value": rate1,
         "msamples_per_s": st["samples"] / st["seconds"] / 1e6,
