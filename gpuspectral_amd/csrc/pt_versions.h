@@ -148,7 +148,35 @@ inline GeoRingPlan plan_geo_ring(uint64_t slots_static, uint64_t nodes_static, u
   return p;
 }
 
-// gsp_update_instances, first question: may this edit ask for a split (or re-split) of the scene?
+// ---- gsp_update_instances: the wait / no-wait decisions, one predicate each (pt_render_scene.inc walks them in this order) ------
+// `live`: samples are in flight (the pipeline is active); `caps_ok`: the path pools are small enough for the <VER> kernels'
+// queue-index flag; oldest_live: the oldest geometry version a sample in flight carries (== geo.ver when none is).
+//
+// (1) split scene, the edit touches only instances that already live in the small tree: the refit goes into the NEXT slot of the ring
+//     while the samples in flight finish in theirs -- else (no free slot, pools too large) they finish first and the refit is in place
+inline bool edited_tree_refit_needs_no_wait(bool live, bool caps_ok, const GeoVersions& geo, uint32_t oldest_live) {
+  return live && caps_ok && geo.next_slot_free(oldest_live);
+}
+// (2) the edit asks for a split (a first one, or a re-split because it touches an instance not edited before)
+inline bool edit_wants_split(bool is_split, bool split_declined, bool live, double refit_growth, uint32_t geometry_versions, uint32_t num_textures) {
+  return is_split || (!split_declined && live && refit_growth > 1.0 && geometry_versions >= 4 && num_textures == 0);
+}
+// ... and the FIRST split of a tree that has never been edited needs no wait: the small tree is built where the instances WERE as
+// version 0 -- with the static tree that is the scene the samples in flight were generated under (they carry stamp 0) -- and the
+// edit itself becomes version 1
+inline bool first_split_needs_no_wait(bool is_split, bool live, bool caps_ok, const GeoVersions& geo) {
+  return !is_split && live && geo.ver == 0 && geo.stride == 0 && caps_ok;
+}
+// (3) ring of whole trees (scenes that do not split): the refit goes into the next slot
+inline bool whole_tree_refit_needs_no_wait(bool live, bool caps_ok, double refit_growth, const GeoVersions& geo, uint32_t oldest_live) {
+  return live && geo.stride != 0 && refit_growth > 1.0 && caps_ok && geo.next_slot_free(oldest_live);
+}
+// ... and behind a wait the ring of whole trees is made only where a split is not to be had
+inline bool scene_may_still_split(bool split_declined, uint32_t geometry_versions, uint32_t num_textures) {
+  return !split_declined && geometry_versions >= 4 && num_textures == 0;
+}
+
+// gsp_update_instances, make_split: may this edit ask for a split (or re-split) of the scene?
 inline bool may_split(bool split_declined, uint32_t splits_so_far, double refit_growth, uint32_t geometry_versions, uint32_t num_textures,
                       bool ring_failed) {
   return !split_declined && splits_so_far < kMaxSceneSplits && refit_growth > 1.0 && geometry_versions >= 4 && num_textures == 0 && !ring_failed;

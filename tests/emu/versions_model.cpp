@@ -46,6 +46,7 @@ struct Mock {
   uint32_t geo_owned_version = 0; // ... the version of that implicit slot
   std::deque<Batch> inflight;
   bool pipe_active = false;
+  uint32_t retire_bias = 1;
   uint64_t drains = 0, in_place = 0, grown = 0, geo_in_ring = 0, collapses = 0;
   size_t free_mem = (size_t)200 << 30;
 
@@ -117,8 +118,10 @@ struct Mock {
     }
     pipe_active = true;
     iterate(multi);
-    // batches end in timestamp order (they are folded in that order); a few per iteration
-    uint32_t k = rnd(3);
+    // batches end in timestamp order (they are folded in that order); a few per iteration -- in phases: while retire_bias is 0 nothing
+    // ends (deep paths: 52 bounces = 52 frames of a viewer) and the rings fill up to the point where an edit has to wait
+    if (rnd(400) == 0) retire_bias = rnd(3);
+    uint32_t k = rnd(1 + retire_bias + (retire_bias ? 1 : 0));
     while (k-- && inflight.size() > 1) inflight.pop_front();
   }
 
@@ -165,7 +168,8 @@ struct Mock {
       ++in_place;
     } else {
       drain();
-      const size_t nb = same_layout ? tab.slot_bytes : (size_t)(256 * (1 + rnd(4096)));
+      // (another layout: from a few records to half a gigabyte of light records -- the byte budget then allows rings of 2 .. 64 slots)
+      const size_t nb = same_layout ? tab.slot_bytes : (size_t)256 * (1 + rnd(1u << (4 + rnd(18))));
       if (tab.slot_bytes != nb) free_tables();
       if (tab.upload_behind_drain(nb)) alloc_tables(tab.slot_bytes, tab.slots);
       tab_mem[0] = tab.ver;  // (the image replaces the one live version: slot 0, same version number -- nothing in flight can tell)
@@ -193,7 +197,12 @@ struct Mock {
       return;
     }
     const bool caps_ok = rnd(50) != 0;
-    if (pipe_active && caps_ok && geo.next_slot_free(oldest_geo())) {
+    // (the product asks edited_tree_refit_needs_no_wait for a split scene's small tree and whole_tree_refit_needs_no_wait for a ring of
+    // whole trees: the same slot test behind different preconditions -- the model's ring stands for either)
+    const bool no_wait = rnd(2) ? edited_tree_refit_needs_no_wait(pipe_active, caps_ok, geo, oldest_geo())
+                                : whole_tree_refit_needs_no_wait(pipe_active, caps_ok, 1.25, geo, oldest_geo());
+    CHECK(no_wait == (pipe_active && caps_ok && geo.next_slot_free(oldest_geo())), "the two slot predicates disagree");
+    if (no_wait) {
       const uint32_t slot = geo.phys(geo.ver + 1);
       for (const Batch& b : inflight) {
         const uint32_t reads = (b.geo_stamp + geo.base) & (geo.slots() - 1u);
@@ -232,6 +241,21 @@ static void check_plans(std::mt19937& rng) {
             !may_split(false, 0, 1.25, 64, 2, false) && !may_split(false, 0, 1.25, 64, 0, true),
         "may_split");
   CHECK(split_worthwhile(300, 100) && !split_worthwhile(299, 100) && !split_worthwhile(0, 5) && !split_worthwhile(5, 0), "split_worthwhile");
+  {  // the wait / no-wait predicates of gsp_update_instances
+    GeoVersions none, ring;
+    ring.stride = 1000, ring.log2 = 2, ring.ver = 5;
+    CHECK(edit_wants_split(true, true, false, 1.0, 0, 9) && edit_wants_split(false, false, true, 1.25, 64, 0) && !edit_wants_split(false, true, true, 1.25, 64, 0) &&
+              !edit_wants_split(false, false, false, 1.25, 64, 0) && !edit_wants_split(false, false, true, 1.0, 64, 0) && !edit_wants_split(false, false, true, 1.25, 3, 0) &&
+              !edit_wants_split(false, false, true, 1.25, 64, 1),
+          "edit_wants_split");
+    CHECK(first_split_needs_no_wait(false, true, true, none) && !first_split_needs_no_wait(true, true, true, none) && !first_split_needs_no_wait(false, false, true, none) &&
+              !first_split_needs_no_wait(false, true, false, none) && !first_split_needs_no_wait(false, true, true, ring),
+          "first_split_needs_no_wait");
+    CHECK(whole_tree_refit_needs_no_wait(true, true, 1.25, ring, 3) && !whole_tree_refit_needs_no_wait(true, true, 1.25, ring, 2) && !whole_tree_refit_needs_no_wait(true, true, 1.0, ring, 5) &&
+              !whole_tree_refit_needs_no_wait(true, true, 1.25, none, 0) && !whole_tree_refit_needs_no_wait(false, true, 1.25, ring, 5),
+          "whole_tree_refit_needs_no_wait: 4 slots hold versions oldest .. oldest + 3");
+    CHECK(scene_may_still_split(false, 4, 0) && !scene_may_still_split(true, 4, 0) && !scene_may_still_split(false, 3, 0) && !scene_may_still_split(false, 4, 2), "scene_may_still_split");
+  }
   // ring sizes by bytes (r05 review: 64 slots of a 64-MB light table are 4 GB)
   CHECK(TableRing::slots_for(64u << 20, TableRing::budget_for((size_t)200 << 30)) == 16, "a 64-MB table gets 16 slots of a 1-GiB budget");
   CHECK(TableRing::slots_for(4096, TableRing::budget_for((size_t)200 << 30)) == kMaxTableVersions, "small tables get the whole field");

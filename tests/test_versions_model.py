@@ -47,7 +47,8 @@ def test_the_model_catches_an_off_by_one(tmp_path):
         exe = str(tmp_path / "vm")
         subprocess.check_call(["g++", "-O1", "-std=c++17", str(src), "-o", exe])
         r = subprocess.run([exe, "1", "40000"], capture_output=True, text=True)
-        assert r.returncode != 0 and "written while a batch" in r.stderr, (pattern, r.stdout, r.stderr)
+        # (the ring's slot test fails its own known-answer check first, the tables' the random stream's invariant)
+        assert r.returncode != 0 and ("written while a batch" in r.stderr or "needs_no_wait" in r.stderr), (pattern, r.stdout, r.stderr)
 
 
 def test_product_and_documentation_agree_on_the_limits():
