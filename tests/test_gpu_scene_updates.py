@@ -763,3 +763,57 @@ def test_reference_frame_loop_against_the_c_abi(oracle_mod, materials_scene):
             assert np.array_equal(ctx.download().reshape(-1, 4), acc)
         finally:
             hip.hipFree(dptr)
+
+
+def test_table_ring_is_made_lazily_and_capped_by_bytes():
+    """(r06) gsp_upload_scene holds ONE copy of the BSDF / light tables; the version ring behind per-frame
+    gsp_update_tables is made by the first edit that arrives with samples in flight, and its size is capped by bytes (a
+    sixteenth of the free memory, at most 1 GiB).  A mesh emitter of a million triangles = 64 MB of light records: r05 allocated
+    64 slots = 4 GB at upload; now the upload holds 64 MB and the ring gets 16 slots.  With 16 slots and paths that live for
+    dozens of one-sample frames some edits must wait (scene_drains > 0) -- and the frames equal those of a context that waits
+    before EVERY edit, bit for bit."""
+    import copy
+
+    import gpuspectral_amd as g
+    from gpuspectral_amd import scenes
+
+    b = scenes.SceneBuilder()
+    room = b.add_mesh(*scenes.box_mesh())
+    ball = b.add_mesh(*scenes.sphere_mesh(1024, 512))
+    b.add_object(room, scenes.trs((0, 1, 0), (2.0, 1.2, 2.0)), b.diffuse((0.7, 0.6, 0.5)), twofaced=True)
+    b.add_object(ball, scenes.trs((0.3, 1.4, -0.2), (0.3, 0.3, 0.3)), b.diffuse((0, 0, 0)), emission=(60.0, 50.0, 30.0))
+    b.camera_lookat((1.6, 1.1, 1.7), (0, 0.9, 0), fov_deg=60)
+    sc0 = b.build()
+    slot_bytes = len(sc0.lights) * 64
+    assert slot_bytes > 60e6
+    W, H, frames = 40, 32, 24
+
+    def edit(sc, k):
+        lights = sc.lights.copy()
+        lights["radiance"][:, :3] = np.array([60.0, 50.0, 30.0], np.float32) * np.float32(0.5 + 0.1 * (k % 6))
+        sc.lights = lights
+
+    def run(sync_every_frame):
+        sc = copy.deepcopy(sc0)
+        with g.Context(0) as ctx:
+            ctx.upload_scene(sc)
+            ctx.frame_begin(W, H)
+            ctx.render(spp=1, first_timestamp=0)
+            for k in range(1, frames):  # (no gsp_get_stats in this loop: it completes the queued samples, like gsp_sync)
+                edit(sc, k)
+                if sync_every_frame:
+                    ctx.sync()
+                ctx.update_tables(sc)
+                ctx.render(spp=1, first_timestamp=k)
+            return ctx.download().reshape(-1, 4), ctx.stats()
+
+    img, st = run(False)
+    ref, st_ref = run(True)
+    assert np.array_equal(img, ref), "%d pixels differ" % int((img != ref).any(1).sum())
+    # the context that waits before every edit never needs a ring (nothing is in flight when an edit arrives): what the other one
+    # holds beyond it IS the ring -- made by its first in-flight edit, within the byte budget
+    ring = int(st["device_bytes"]) - int(st_ref["device_bytes"])
+    assert 7 * slot_bytes <= ring <= (1 << 30), (ring, slot_bytes)
+    assert abs(ring / slot_bytes - 15.0) < 0.01, ring / slot_bytes  # 15 more slots (a slot = the light records + the few BSDF records): 16 = floor(1 GiB / 64 MB)
+    assert st["scene_updates"] == frames - 1 == st_ref["scene_updates"]
+    assert st["scene_drains"] > 0  # (16 slots, paths of up to 52 bounces in one-sample frames: some edits wait)
