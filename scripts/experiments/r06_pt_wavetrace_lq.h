@@ -31,6 +31,12 @@ constexpr uint32_t kLqEntries = 128;  // queued groups per wave (a node step may
 #ifndef GSP_LQ_MIN_NODE_LANES
 #define GSP_LQ_MIN_NODE_LANES 16  // fewer lanes than this able to take a node step + something queued: run the leaf step first
 #endif
+#ifndef GSP_LQ_BATCH
+#define GSP_LQ_BATCH 64  // queued groups that trigger a leaf step (a step takes at most 64)
+#endif
+#ifndef GSP_LQ_WAIT_LANES
+#define GSP_LQ_WAIT_LANES 65  // this many lanes waiting for their queued tests + something queued: leaf step (65 = off)
+#endif
 #ifndef GSP_LQ_COMMIT
 #define GSP_LQ_COMMIT (ANY ? 32 : 24)
 #endif
@@ -97,11 +103,13 @@ __global__ __launch_bounds__(kTraceBlock, GSP_LQ_WAVES) void k_trace_lq(const q4
     ++wp[4];
 #endif
     // ---- commit: traversal over AND every queued triangle of the ray tested -----------------------------------------
+    uint32_t waiting = 0;  // lanes whose traversal is over and whose queued triangles are not all tested yet
     {
       const bool fin = ri != 0xffffffffu && group_empty<ANY>(gs);
       bool complete = false;
       if (__ballot(fin)) complete = fin && *(volatile uint32_t*)&lq_done[threadIdx.x] == pushed;
       const uint64_t pend_m = __ballot(complete);
+      waiting = (uint32_t)wave_count(__ballot(fin && !complete));
       if (pend_m) {
         const uint64_t out_m = pend_m | __ballot(ri == 0xffffffffu);
         if (wave_count(out_m) >= GSP_LQ_COMMIT || out_m == ~0ull) {
@@ -169,7 +177,8 @@ __global__ __launch_bounds__(kTraceBlock, GSP_LQ_WAVES) void k_trace_lq(const q4
       if (exhausted || idle_m == 0) break;
       continue;
     }
-    const bool leaf_step = q_count >= 64u || node_m == 0 || (q_count != 0u && wave_count(node_m) < GSP_LQ_MIN_NODE_LANES);
+    const bool leaf_step = q_count >= (uint32_t)GSP_LQ_BATCH || node_m == 0 ||
+                           (q_count != 0u && (wave_count(node_m) < GSP_LQ_MIN_NODE_LANES || waiting >= (uint32_t)GSP_LQ_WAIT_LANES));
     if (!leaf_step) {
       for (int rep = 0; rep < GSP_NODE_REPS; ++rep) {
         const bool on = ri != 0xffffffffu && !group_empty<ANY>(gs);
@@ -267,7 +276,9 @@ __global__ __launch_bounds__(kTraceBlock, GSP_LQ_WAVES) void k_trace_lq(const q4
       }
       if (act) atomicAdd(&lq_done[wbase + (uint32_t)own], 1u);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      if (ANY) {
+      if (__ballot(hit) == 0) {
+        // nothing accepted in this batch: no record changed
+      } else if (ANY) {
         if (ri != 0xffffffffu && *(volatile unsigned long long*)&lq_rec[threadIdx.x] != empty_rec(tmax)) gs = no_group<ANY>();  // occluded: the traversal ends
       } else {
         if (hit && *(volatile unsigned long long*)orec == key) ((volatile uint8_t*)lq_win)[wbase + (uint32_t)own] = (uint8_t)lane;
