@@ -168,6 +168,12 @@ def test_bench_one_rank_through_nccl(tmp_path):
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["config"]["collective"] is None and j2["config"]["collective"].startswith("nccl, 1 rank")
+    # r06: the N = 1 line has the frame read-back inside the timed region and BASELINE's other configs behind it
+    assert 0.0 < j1["config"]["download_ms"] < 1e3 * j1["ms_per_step"] and j2["config"]["download_ms"] is None
+    ow = j1["config"]["other_workloads"]
+    assert [w["workload"].split(":")[0] for w in ow] == ["config2", "config3", "config5"] and all(w["mrays_per_s"] > 100 and w["spp"] >= 8 for w in ow)
+    assert ow[2]["max_depth"] == 32 and ow[2]["resolution"] == "4096x4096" and ow[2]["pixels"] == 4096 * 4096 // 8
+    assert j1["roofline"]["bound"] in (None, "valu_issue", "l1_request", "hbm") and set(j1["cpu_baseline"] if "cpu_baseline" in j1 else ()) == set()
     assert j1["config"]["extension_rays"] == j2["config"]["extension_rays"] and j1["config"]["shadow_rays"] == j2["config"]["shadow_rays"]
     a, b = np.load(f1), np.load(f2)
     assert a.shape == (240, 416, 4) and np.array_equal(a.reshape(-1, 4), b.reshape(-1, 4))
