@@ -19,19 +19,20 @@ scene at 1920x1080, on 1/2/4/8 MI355X.
 * Scene upload and BVH build are outside the timed region (reported separately).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, k_trace<ExtendIO> (closest-hit BVH traversal).
-It is bound by VALU ISSUE (no dense contraction: MFMA unused; HBM at about a third of its peak), so
-  frac = achieved / peak = wave64 VALU instructions per second (rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from
-         the committed PMC passes over this same command line, profiles/pmc_bench_*.json -- `counters_from` says which file --
-         over THIS run's HIP-event kernel time) / 1228.8 G/s (1024 SIMD-32 x 2.4 GHz / 2 cycles, MI355X_MICROARCH.md).
-`fractions` carries the other ceilings next to it, each defined in one line in DESIGN.md 5:
+No dense contraction: MFMA unused; HBM at about a third of its peak.  `bound` / `achieved` / `peak` / `frac` name the LARGEST of the three
+datasheet fractions this kernel can run against, picked from the data (r06; r05 hard-coded VALU issue):
+  valu_issue   wave64 VALU instructions per second (rocprofv3 SQ_INSTS_VALU of exactly the timed launches, from the committed PMC
+               passes over this same command line, profiles/pmc_bench_*.json -- `counters_from` says which file -- over THIS run's
+               HIP-event kernel time) / 1228.8 G/s (1024 SIMD-32 x 2.4 GHz / 2 cycles, MI355X_MICROARCH.md)
+  l1_request   16-B lane loads per second (live statistics pass) against one per cycle and CU (614 G/s, measured)
+  hbm          counter bytes (FETCH_SIZE + WRITE_SIZE, corrected as the guide prescribes) per second / 8 TB/s
+`fractions` carries all three plus the class-weighted issue figures, each defined in one line in DESIGN.md 5:
   valu_issue_weighted            the same rate against 1024 x 2.4 GHz / the kernel's mean issue cost, where the class mix is
                                  DYNAMIC (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 / INT32 / INT64 / CVT of the same
                                  launches; cost of a class = static mix inside the class, lib/valu_mix.json; class membership
                                  calibrated by profiles/r05_valu_class_calib.txt); `valu_issue_weighted_static` = r04's figure
                                  (static mix of the binary), kept for comparison
   valu_issue_weighted_at_clock   ... at the clock the chip HELD under the kernel (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)
-  l1_request                     16-B lane loads per second (live statistics pass) against one per cycle and CU
-  hbm                            counter bytes (FETCH_SIZE + WRITE_SIZE, corrected as the guide prescribes) per second / 8 TB/s
 `traffic` = those counter bytes per launch.  SURVEY 8(d)'s byte model (every node / triangle record the traversal reads,
 charged as if it came from HBM) is reported as `survey_byte_model`: it is NOT a bound for a 31-MB tree -- half of the node
 visits are served by the LDS copy of the top of the tree and L2 hits 56 % -- so it is printed with
@@ -40,7 +41,10 @@ that executes more instructions per ray scores higher), so the work-normalised f
 frac x lanes enabled per instruction, `valu_instr_per_ray`, `valu_lane_instr_per_ray`; `other_kernels` carries the same
 figures for k_trace<ConnectIO> and k_shade.  A PMC file must carry the digest of the render kernels' instruction streams
 (`config.kernel_digest`, lib/valu_mix.json) of the loaded library: a file from other device code is refused and the fields
-stay null.  `cpu_baseline` times the scalar CPU oracle on this box's host cores on a bounded sample of the same workload (N = 1 only).
+stay null; a file whose launch shape (rays of the timed region) differs from this run's is used scaled, and the line says so.
+`cpu_baseline` times the scalar CPU oracle on this box's host cores on a bounded sample of the same workload (N = 1 only).
+N = 1: the read-back of the frame into host memory is INSIDE the timed region (config.download_ms), like the gather of N > 1;
+BASELINE's other single-GPU configs (2, 3, 5) run behind it, outside `value`: config.other_workloads.
 """
 import argparse
 import json
