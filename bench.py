@@ -36,7 +36,7 @@ datasheet fractions this kernel can run against, picked from the data (r06; r05 
 `traffic` = those counter bytes per launch.  SURVEY 8(d)'s byte model (every node / triangle record the traversal reads,
 charged as if it came from HBM) is reported as `survey_byte_model`: it is NOT a bound for a 31-MB tree -- half of the node
 visits are served by the LDS copy of the top of the tree and L2 hits 56 % -- so it is printed with
-`traffic_over_survey_model` (~0.25) instead of as a rate against the HBM peak.  `frac` is an issue-rate UTILISATION (a build
+`traffic_over_survey_model` (~0.25) instead of as a rate against the HBM peak.  The fractions are UTILISATIONS (a build
 that executes more instructions per ray scores higher), so the work-normalised figures stand next to it: `effective` =
 frac x lanes enabled per instruction, `valu_instr_per_ray`, `valu_lane_instr_per_ray`; `other_kernels` carries the same
 figures for k_trace<ConnectIO> and k_shade.  A PMC file must carry the digest of the render kernels' instruction streams
